@@ -1,0 +1,377 @@
+// Scaled-dot-product attention (softmax over keys) for every attention site of the path:
+// YOLO C2PSA (400 tokens), Hiera windowed / global attention (head_dim 72, optional 2x2 q max-pool),
+// SAM mask-decoder self / cross attention.
+//
+// fp16: flash-style, one wave per 32 queries, 32x32x16 MFMA, "swapped" products so that nothing
+// crosses lanes between the two GEMMs:
+//     S^T[key][q] = K . Q^T        (A = K rows from LDS, B = Q rows held in registers)
+//     O^T[d][q]  += V^T . P^T      (A = V^T from a transposed LDS image, B = P^T = the S^T
+//                                   accumulator itself, converted to fp16 in place)
+// Each lane owns ONE query column, so the online-softmax state (max, sum) is a per-lane scalar and
+// the row reductions are 15 in-register ops + one cross-half shuffle.
+// K/V tiles (32 keys) are staged through LDS by a loader group of GS threads: GS = 256 shares one
+// tile among the 4 waves of a workgroup (same batch/head, long sequences), GS = 64 gives every wave
+// its own item (many small windows).
+// f32 (parity mode): plain VALU kernel, one wave per query.
+#include "common.hpp"
+
+namespace {
+
+struct AttnArgs {
+  const char* q; const char* k; const char* v; char* o;
+  long long q_sb, q_sh, q_st, k_sb, k_sh, k_st, v_sb, v_sh, v_st, o_sb, o_sh, o_st;
+  int B, heads, Nq, Nk, dqk, dv;
+  float scale;
+  int win, grid_h, grid_w, q_pool;
+  int qtiles;      // ceil(Nq / 32)
+  int items;       // B * heads * qtiles
+};
+
+// element offset of token t of batch entry b (window mode: b enumerates windows of an image grid)
+__device__ __forceinline__ long long tok_off(int b, int t, long long sb, long long st, int win, int gh, int gw) {
+  if (win <= 0) return (long long)b * sb + (long long)t * st;
+  const int wpr = gw / win, wpc = gh / win;
+  const int img = b / (wpr * wpc);
+  const int wi = b - img * (wpr * wpc);
+  const int wy = wi / wpr, wx = wi - wy * wpr;
+  const int ty = t / win, tx = t - ty * win;
+  const long long pix = ((long long)img * gh + (wy * win + ty)) * gw + (wx * win + tx);
+  return pix * st;
+}
+
+template <int DQKP, int DVP, int GS>
+__global__ __launch_bounds__(256) void attn_f16_kernel(const AttnArgs p) {
+  constexpr int KROW = DQKP * 2 + 16;          // K tile row stride (bytes): odd multiple of 16
+  constexpr int VROW = 32 * 2 + 8;             // V^T tile row stride (bytes): 72
+  constexpr int KTILE = 32 * KROW;
+  constexpr int VTILE = DVP * VROW;
+  constexpr int NGRP = 256 / GS;               // loader groups per workgroup
+  constexpr int QS = DQKP / 16;                // k16 steps of the S product
+  constexpr int DT = DVP / 32;                 // 32-row tiles of O^T
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+  const int lr = lane & 31, lh = lane >> 5;
+  const int grp = tid / GS, gt = tid % GS;
+  char* const Ks = smem + grp * (KTILE + VTILE);
+  char* const Vs = Ks + KTILE;
+
+  // work item of this wave
+  int item, qt;
+  if (GS == 256) {                             // workgroup = 4 consecutive q-tiles of one (b, h)
+    const int qgroups = (p.qtiles + 3) / 4;
+    const int bh = blockIdx.x / qgroups;
+    qt = (blockIdx.x - bh * qgroups) * 4 + wv;
+    item = bh;
+  } else {
+    const int it = blockIdx.x * 4 + wv;
+    item = it / p.qtiles;
+    qt = it - item * p.qtiles;
+  }
+  const int nbh = p.B * p.heads;
+  const bool live = item < nbh && qt < p.qtiles;
+  const int itc = item < nbh ? item : nbh - 1;
+  const int b = itc / p.heads, h = itc - b * p.heads;
+  // loader group's (b, h): for GS == 64 it is the wave's own; for GS == 256 all waves agree
+  const int qwin = p.q_pool ? p.win / 2 : p.win;
+
+  // ---- Q fragments (B operand of S^T = K Q^T): lane (q = lr, half lh) holds Q[q][16s + 8lh .. +7]
+  const int qi = qt * 32 + lr;
+  const bool q_ok = live && qi < p.Nq;
+  u32x4 qf[QS];
+  {
+#pragma unroll
+    for (int s = 0; s < QS; ++s) {
+      const int d0 = 16 * s + 8 * lh;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (q_ok && d0 < p.dqk) {
+        if (!p.q_pool) {
+          const long long off = tok_off(b, qi, p.q_sb, p.q_st, p.win, p.grid_h, p.grid_w) + (long long)h * p.q_sh + d0;
+          v = *reinterpret_cast<const u32x4*>(p.q + off * 2);
+        } else {                               // q = 2x2 max-pool of the window's projected q tokens
+          const int py = qi / qwin, px = qi - py * qwin;
+          f16x8 m;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) m[e] = (f16)(-65504.f);
+#pragma unroll
+          for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+              const int t = (2 * py + dy) * p.win + 2 * px + dx;
+              const long long off = tok_off(b, t, p.q_sb, p.q_st, p.win, p.grid_h, p.grid_w) + (long long)h * p.q_sh + d0;
+              const f16x8 x = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(p.q + off * 2));
+#pragma unroll
+              for (int e = 0; e < 8; ++e) m[e] = x[e] > m[e] ? x[e] : m[e];
+            }
+          v = __builtin_bit_cast(u32x4, m);
+        }
+      }
+      qf[s] = v;
+    }
+  }
+
+  f32x16 oacc[DT];
+#pragma unroll
+  for (int t = 0; t < DT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[t][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+  const float c = p.scale * 1.44269504088896340736f;   // softmax in base 2
+
+  // loader identity: group grp loads for item of wave (grp * GS / 64)
+  int lb, lhd;
+  {
+    int litem;
+    if (GS == 256) litem = item; else litem = (blockIdx.x * 4 + grp) / p.qtiles;
+    if (litem >= nbh) litem = nbh - 1;
+    lb = litem / p.heads; lhd = litem - lb * p.heads;
+  }
+
+  const int nkt = (p.Nk + 31) / 32;
+  for (int kt = 0; kt < nkt; ++kt) {
+    __syncthreads();                           // previous tile fully consumed
+    // ---- stage K tile [32][DQKP] and V^T tile [DVP][32] -------------------------------------------
+    for (int idx = gt; idx < 32 * (DQKP / 8); idx += GS) {
+      const int row = idx / (DQKP / 8), ch = idx - row * (DQKP / 8);
+      const int key = kt * 32 + row;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (key < p.Nk && ch * 8 < p.dqk) {
+        const long long off = tok_off(lb, key, p.k_sb, p.k_st, p.win, p.grid_h, p.grid_w) + (long long)lhd * p.k_sh + ch * 8;
+        v = *reinterpret_cast<const u32x4*>(p.k + off * 2);
+      }
+      *reinterpret_cast<u32x4*>(Ks + row * KROW + ch * 16) = v;
+    }
+    for (int idx = gt; idx < 32 * (DVP / 8); idx += GS) {
+      const int ch = idx / 32, key_l = idx - ch * 32;       // consecutive threads -> consecutive keys
+      const int key = kt * 32 + key_l;
+      f16x8 v;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = (f16)0.f;
+      if (key < p.Nk && ch * 8 < p.dv) {
+        const long long off = tok_off(lb, key, p.v_sb, p.v_st, p.win, p.grid_h, p.grid_w) + (long long)lhd * p.v_sh + ch * 8;
+        v = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(p.v + off * 2));
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) *reinterpret_cast<f16*>(Vs + (ch * 8 + e) * VROW + key_l * 2) = v[e];
+    }
+    __syncthreads();
+
+    // ---- S^T tile: 32 keys x 32 queries ------------------------------------------------------------
+    f32x16 sacc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < QS; ++s) {
+      const f16x8 kf = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(Ks + lr * KROW + s * 32 + lh * 16));
+      sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, __builtin_bit_cast(f16x8, qf[s]), sacc, 0, 0, 0);
+    }
+    // mask keys past Nk, running max
+    float mx = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (key >= p.Nk) sacc[r] = -INFINITY;
+      mx = fmaxf(mx, sacc[r]);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = exp2f((m_run - m_new) * c);
+    float psum = 0.f;
+    f16x8 pf[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float pv = exp2f((sacc[r] - m_new) * c);
+      psum += pv;
+      pf[r >> 3][r & 7] = (f16)pv;
+    }
+    psum += __shfl_xor(psum, 32);
+    l_run = l_run * alpha + psum;
+    m_run = m_new;
+#pragma unroll
+    for (int t = 0; t < DT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[t][r] *= alpha;
+    // ---- O^T += V^T P^T ---------------------------------------------------------------------------
+#pragma unroll
+    for (int t = 0; t < DT; ++t) {
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const char* vp = Vs + (t * 32 + lr) * VROW + (16 * s + 4 * lh) * 2;
+        const u32x2 lo = *reinterpret_cast<const u32x2*>(vp);
+        const u32x2 hi = *reinterpret_cast<const u32x2*>(vp + 16);
+        const u32x4 vv = {lo[0], lo[1], hi[0], hi[1]};
+        oacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, vv), pf[s], oacc[t], 0, 0, 0);
+      }
+    }
+  }
+
+  // ---- normalise and store O[q][d] (lane holds runs of 4 consecutive d) ---------------------------
+  if (q_ok) {
+    const float inv = 1.f / l_run;
+    long long obase;
+    if (p.win > 0) {
+      const int ow = p.q_pool ? p.win / 2 : p.win, ogh = p.q_pool ? p.grid_h / 2 : p.grid_h, ogw = p.q_pool ? p.grid_w / 2 : p.grid_w;
+      obase = tok_off(b, qi, p.o_sb, p.o_st, ow, ogh, ogw);
+    } else {
+      obase = (long long)b * p.o_sb + (long long)qi * p.o_st;
+    }
+    obase += (long long)h * p.o_sh;
+#pragma unroll
+    for (int t = 0; t < DT; ++t)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d0 = t * 32 + 8 * g + 4 * lh;
+        if (d0 < p.dv) {
+          f16x4 ov;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) ov[e] = (f16)(oacc[t][4 * g + e] * inv);
+          *reinterpret_cast<f16x4*>(p.o + (obase + d0) * 2) = ov;
+        }
+      }
+  }
+}
+
+// ---- f32 parity kernel: one wave per query; lanes = keys for S, lanes = d for the PV sum ----------
+__global__ __launch_bounds__(256) void attn_f32_kernel(const AttnArgs p) {
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const long long total = (long long)p.B * p.heads * p.Nq;
+  const long long row_raw = (long long)blockIdx.x * 4 + wv;      // (b, h, q)
+  const bool valid = row_raw < total;
+  const long long row = valid ? row_raw : total - 1;
+  const int qi = (int)(row % p.Nq);
+  const int bh = (int)(row / p.Nq);
+  const int b = bh / p.heads, h = bh - b * p.heads;
+  const float* Q = reinterpret_cast<const float*>(p.q);
+  const float* K = reinterpret_cast<const float*>(p.k);
+  const float* V = reinterpret_cast<const float*>(p.v);
+  float* O = reinterpret_cast<float*>(p.o);
+  __shared__ float qs[4][128];
+  const int qwin = p.q_pool ? p.win / 2 : p.win;
+  for (int d = lane; d < p.dqk; d += 64) {
+    float v;
+    if (!p.q_pool) {
+      v = Q[tok_off(b, qi, p.q_sb, p.q_st, p.win, p.grid_h, p.grid_w) + (long long)h * p.q_sh + d];
+    } else {
+      const int py = qi / qwin, px = qi - py * qwin;
+      v = -INFINITY;
+      for (int dy = 0; dy < 2; ++dy)
+        for (int dx = 0; dx < 2; ++dx) {
+          const int t = (2 * py + dy) * p.win + 2 * px + dx;
+          v = fmaxf(v, Q[tok_off(b, t, p.q_sb, p.q_st, p.win, p.grid_h, p.grid_w) + (long long)h * p.q_sh + d]);
+        }
+    }
+    qs[wv][d] = v;
+  }
+  __syncthreads();
+  float m_run = -INFINITY, l_run = 0.f;
+  float o0 = 0.f, o1 = 0.f;                                       // d = lane, lane + 64
+  for (int k0 = 0; k0 < p.Nk; k0 += 64) {
+    const int key = k0 + lane;
+    float s = -INFINITY;
+    if (key < p.Nk) {
+      const float* kp = K + tok_off(b, key, p.k_sb, p.k_st, p.win, p.grid_h, p.grid_w) + (long long)h * p.k_sh;
+      float acc = 0.f;
+      for (int d = 0; d < p.dqk; ++d) acc = fmaf(qs[wv][d], kp[d], acc);
+      s = acc * p.scale;
+    }
+    float mx = s;
+    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = expf(m_run - m_new);
+    const float pv = key < p.Nk ? expf(s - m_new) : 0.f;
+    float ps = pv;
+    for (int off = 32; off > 0; off >>= 1) ps += __shfl_xor(ps, off);
+    l_run = l_run * alpha + ps;
+    m_run = m_new;
+    o0 *= alpha; o1 *= alpha;
+    const int nk = p.Nk - k0 < 64 ? p.Nk - k0 : 64;
+    for (int j = 0; j < nk; ++j) {
+      const float pj = __shfl(pv, j);
+      const float* vp = V + tok_off(b, k0 + j, p.v_sb, p.v_st, p.win, p.grid_h, p.grid_w) + (long long)h * p.v_sh;
+      if (lane < p.dv) o0 = fmaf(pj, vp[lane], o0);
+      if (lane + 64 < p.dv) o1 = fmaf(pj, vp[lane + 64], o1);
+    }
+  }
+  long long obase;
+  if (p.win > 0) {
+    const int ow = p.q_pool ? p.win / 2 : p.win, ogh = p.q_pool ? p.grid_h / 2 : p.grid_h, ogw = p.q_pool ? p.grid_w / 2 : p.grid_w;
+    obase = tok_off(b, qi, p.o_sb, p.o_st, ow, ogh, ogw);
+  } else {
+    obase = (long long)b * p.o_sb + (long long)qi * p.o_st;
+  }
+  obase += (long long)h * p.o_sh;
+  const float inv = 1.f / l_run;
+  if (valid && lane < p.dv) O[obase + lane] = o0 * inv;
+  if (valid && lane + 64 < p.dv) O[obase + lane + 64] = o1 * inv;
+}
+
+template <int DQKP, int DVP, int GS>
+int launch_f16(const AttnArgs& a, hipStream_t stream) {
+  constexpr int KROW = DQKP * 2 + 16, VROW = 72;
+  constexpr size_t lds = (size_t)(256 / GS) * (32 * KROW + DVP * VROW);
+  long long blocks;
+  if (GS == 256) blocks = (long long)a.B * a.heads * ((a.qtiles + 3) / 4);
+  else blocks = ((long long)a.items + 3) / 4;
+  CVMI_CHECK(blocks > 0 && blocks < (1ll << 31), "attention: bad grid");
+  static bool attr_done = false;
+  if (!attr_done && lds > 64 * 1024) {
+    CVMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_f16_kernel<DQKP, DVP, GS>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((attn_f16_kernel<DQKP, DVP, GS>), dim3((unsigned)blocks), dim3(256), lds, stream, a);
+  CVMI_LAUNCH_CHECK();
+  return 0;
+}
+
+template <int DQKP, int DVP>
+int launch_f16_gs(const AttnArgs& a, hipStream_t stream) {
+  // share K/V tiles across the workgroup when each (batch, head) has >= 4 query tiles
+  if (a.qtiles >= 4) return launch_f16<DQKP, DVP, 256>(a, stream);
+  return launch_f16<DQKP, DVP, 64>(a, stream);
+}
+
+}  // namespace
+
+extern "C" int cvmi_attention(const cvmi_attn_desc* d, cvmi_stream_t stream_) {
+  CVMI_CHECK(d && d->q && d->k && d->v && d->o, "attention: null pointer");
+  CVMI_CHECK(d->dtype == CVMI_F16 || d->dtype == CVMI_F32, "attention: bad dtype");
+  CVMI_CHECK(d->B > 0 && d->heads > 0 && d->Nq > 0 && d->Nk > 0 && d->dqk > 0 && d->dv > 0, "attention: bad shape");
+  AttnArgs a;
+  a.q = (const char*)d->q; a.k = (const char*)d->k; a.v = (const char*)d->v; a.o = (char*)d->o;
+  a.q_sb = d->q_sb; a.q_sh = d->q_sh; a.q_st = d->q_st; a.k_sb = d->k_sb; a.k_sh = d->k_sh; a.k_st = d->k_st;
+  a.v_sb = d->v_sb; a.v_sh = d->v_sh; a.v_st = d->v_st; a.o_sb = d->o_sb; a.o_sh = d->o_sh; a.o_st = d->o_st;
+  a.B = d->B; a.heads = d->heads; a.Nq = d->Nq; a.Nk = d->Nk; a.dqk = d->dqk; a.dv = d->dv; a.scale = d->scale;
+  a.win = d->win; a.grid_h = d->grid_h; a.grid_w = d->grid_w; a.q_pool = d->q_pool;
+  a.qtiles = (d->Nq + 31) / 32;
+  a.items = d->B * d->heads * a.qtiles;
+  if (d->win > 0) {
+    CVMI_CHECK(d->grid_h % d->win == 0 && d->grid_w % d->win == 0, "attention: grid %dx%d not divisible by window %d", d->grid_h, d->grid_w, d->win);
+    CVMI_CHECK(d->Nk == d->win * d->win, "attention: window mode needs Nk == win^2");
+    CVMI_CHECK(d->B % ((d->grid_h / d->win) * (d->grid_w / d->win)) == 0, "attention: B is not a whole number of images");
+    if (d->q_pool) CVMI_CHECK(d->win % 2 == 0 && d->Nq == (d->win / 2) * (d->win / 2), "attention: q_pool needs Nq == (win/2)^2");
+    else CVMI_CHECK(d->Nq == d->Nk, "attention: window mode needs Nq == Nk");
+  } else {
+    CVMI_CHECK(!d->q_pool, "attention: q_pool requires window mode");
+  }
+  hipStream_t stream = (hipStream_t)stream_;
+  if (d->dtype == CVMI_F32) {
+    CVMI_CHECK(d->dqk <= 128 && d->dv <= 128, "attention(f32): head dims up to 128");
+    const long long rows = (long long)d->B * d->heads * d->Nq;
+    hipLaunchKernelGGL(attn_f32_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, a);
+    CVMI_LAUNCH_CHECK();
+    return 0;
+  }
+  CVMI_CHECK(d->dqk % 8 == 0 && d->dv % 8 == 0, "attention(f16): head dims must be multiples of 8");
+  const long long strides[] = {d->q_sb, d->q_sh, d->q_st, d->k_sb, d->k_sh, d->k_st, d->v_sb, d->v_sh, d->v_st, d->o_sb, d->o_sh, d->o_st};
+  for (long long s : strides) CVMI_CHECK(s % 4 == 0, "attention(f16): strides must be multiples of 4 elements");
+  CVMI_CHECK(d->q_st % 8 == 0 && d->k_st % 8 == 0 && d->v_st % 8 == 0 && d->q_sh % 8 == 0 && d->k_sh % 8 == 0 && d->v_sh % 8 == 0 &&
+             d->q_sb % 8 == 0 && d->k_sb % 8 == 0 && d->v_sb % 8 == 0, "attention(f16): q/k/v strides must be multiples of 8 elements");
+  CVMI_CHECK((((uintptr_t)d->q | (uintptr_t)d->k | (uintptr_t)d->v) & 15) == 0 && ((uintptr_t)d->o & 7) == 0, "attention(f16): misaligned pointer");
+  if (d->dqk <= 32 && d->dv <= 32) return launch_f16_gs<32, 32>(a, stream);
+  if (d->dqk <= 32 && d->dv <= 64) return launch_f16_gs<32, 64>(a, stream);
+  if (d->dqk <= 64 && d->dv <= 64) return launch_f16_gs<64, 64>(a, stream);
+  if (d->dqk <= 96 && d->dv <= 96) return launch_f16_gs<96, 96>(a, stream);
+  if (d->dqk <= 128 && d->dv <= 128) return launch_f16_gs<128, 128>(a, stream);
+  CVMI_FAIL("attention(f16): head dims (%d, %d) unsupported", d->dqk, d->dv);
+}

@@ -1,0 +1,101 @@
+// Shared device/host helpers for libcvmi355 (gfx950 only; wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/cvmi355.h"
+
+typedef _Float16 f16;
+typedef f16 f16x8 __attribute__((ext_vector_type(8)));
+typedef f16 f16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+// ---- error plumbing ----------------------------------------------------------------------------
+void cvmi_set_error(const char* fmt, ...);
+#define CVMI_FAIL(...)            \
+  do {                            \
+    cvmi_set_error(__VA_ARGS__);  \
+    return 1;                     \
+  } while (0)
+#define CVMI_CHECK(cond, ...)          \
+  do {                                 \
+    if (!(cond)) CVMI_FAIL(__VA_ARGS__); \
+  } while (0)
+#define CVMI_HIP(expr)                                                                  \
+  do {                                                                                  \
+    hipError_t e_ = (expr);                                                             \
+    if (e_ != hipSuccess) CVMI_FAIL("%s failed: %s", #expr, hipGetErrorString(e_));     \
+  } while (0)
+#define CVMI_LAUNCH_CHECK()                                                             \
+  do {                                                                                  \
+    hipError_t e_ = hipGetLastError();                                                  \
+    if (e_ != hipSuccess) CVMI_FAIL("kernel launch failed: %s", hipGetErrorString(e_)); \
+  } while (0)
+
+static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// ---- exact division of n < 65536 by d <= 65536 via one 64-bit multiply --------------------------
+struct FastDiv {
+  unsigned long long mul;
+  __host__ void init(unsigned d) { mul = ((1ull << 32) + d - 1) / d; }
+  __device__ __forceinline__ unsigned div(unsigned n) const { return (unsigned)((n * mul) >> 32); }
+};
+
+// ---- element traits ----------------------------------------------------------------------------
+template <typename T> struct Elem;
+template <> struct Elem<f16> {
+  static constexpr int VEC = 8;
+  __device__ static __forceinline__ float to_f(f16 v) { return (float)v; }
+  __device__ static __forceinline__ f16 from_f(float v) { return (f16)v; }
+};
+template <> struct Elem<float> {
+  static constexpr int VEC = 4;
+  __device__ static __forceinline__ float to_f(float v) { return v; }
+  __device__ static __forceinline__ float from_f(float v) { return v; }
+};
+
+// FAST = true: v_exp/v_rcp based (fp16 storage mode); false: precise libm (f32 parity mode)
+template <bool FAST> __device__ __forceinline__ float act_apply(float v, int act) {
+  switch (act) {
+    case CVMI_ACT_SILU:
+      return FAST ? v * __frcp_rn(1.0f + __expf(-v)) : v / (1.0f + expf(-v));
+    case CVMI_ACT_RELU: return v > 0.f ? v : 0.f;
+    case CVMI_ACT_GELU: return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+    case CVMI_ACT_SIGMOID:
+      return FAST ? __frcp_rn(1.0f + __expf(-v)) : 1.0f / (1.0f + expf(-v));
+    default: return v;
+  }
+}
+template <typename T> struct FastMath { static constexpr bool value = true; };
+template <> struct FastMath<float> { static constexpr bool value = false; };
+
+// 16-byte chunk <-> float[VEC]
+template <typename T> __device__ __forceinline__ void unpack16(const u32x4& v, float* out);
+template <> __device__ __forceinline__ void unpack16<f16>(const u32x4& v, float* out) {
+  const f16x8 h = __builtin_bit_cast(f16x8, v);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) out[i] = (float)h[i];
+}
+template <> __device__ __forceinline__ void unpack16<float>(const u32x4& v, float* out) {
+  const f32x4 f = __builtin_bit_cast(f32x4, v);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) out[i] = f[i];
+}
+template <typename T> __device__ __forceinline__ u32x4 pack16(const float* in);
+template <> __device__ __forceinline__ u32x4 pack16<f16>(const float* in) {
+  f16x8 h;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) h[i] = (f16)in[i];
+  return __builtin_bit_cast(u32x4, h);
+}
+template <> __device__ __forceinline__ u32x4 pack16<float>(const float* in) {
+  f32x4 f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) f[i] = in[i];
+  return __builtin_bit_cast(u32x4, f);
+}

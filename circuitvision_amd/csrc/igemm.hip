@@ -1,0 +1,342 @@
+// Implicit-GEMM convolution / linear layer on MFMA (gfx950).
+//
+//   y[m, n] = act( sum_k A[m, k] * w[n, k] + bias[n] ) (+ res[m, n])
+//
+// A (pixels x K) is never materialised: each 16-byte chunk of a K-row is gathered from the NHWC
+// source(s) while the K-tile is staged into LDS (im2col on the fly; two channel-concatenated
+// sources, each optionally nearest-2x upsampled, so YOLO's Upsample+Concat cost no HBM traffic).
+// Operand roles are swapped on purpose: the MFMA "A" operand is the WEIGHT tile (rows = n) and the
+// "B" operand the PIXEL tile (cols = m).  The 32x32 accumulator then holds, per lane, runs of 4
+// consecutive output channels of ONE pixel, which pack into 8/16-byte LDS writes for the
+// transposing epilogue and leave the global stores as full 16-byte, channel-contiguous chunks.
+//
+// LDS image per K-tile: rows of BKB data bytes + 16 pad bytes (row stride = odd multiple of 16 B,
+// so the 32 lanes of a ds_read_b128 lane group hit 16 distinct 16-byte slots: conflict-free).
+// The same byte geometry serves fp16 (32x32x16 MFMA, 8 k per lane) and exact-f32 (32x32x2 MFMA,
+// 4 k per lane per 16-byte read, 4 MFMAs per read) -- only the inner MFMA call differs.
+//
+// Pipeline: register-staged double buffer (global loads for tile t+1 are issued before the MFMAs
+// of tile t and written to the other LDS buffer after them; one barrier per K-tile).
+#include "common.hpp"
+
+namespace {
+
+struct ConvKArgs {
+  const char* x0; const char* x1; const char* w; const float* bias; const char* res; char* y;
+  int x0_ld, x1_ld, res_ld, y_ld;
+  int c0, ctot;
+  int up0, up1;
+  int H, W, OH, OW, KW, stride, pad;
+  int M, N, K, Kpad;
+  int act, scalar_gather;
+  int nb_n;
+  FastDiv div_ctot, div_kw;
+};
+
+template <typename T> struct Mma;
+template <> struct Mma<f16> {
+  __device__ static __forceinline__ void run(const u32x4& a, const u32x4& b, f32x16& c) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  }
+};
+template <> struct Mma<float> {
+  __device__ static __forceinline__ void run(const u32x4& a, const u32x4& b, f32x16& c) {
+    const f32x4 fa = __builtin_bit_cast(f32x4, a), fb = __builtin_bit_cast(f32x4, b);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) c = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[e], fb[e], c, 0, 0, 0);
+  }
+};
+
+template <typename T>
+__device__ __forceinline__ u32x4 gather_chunk(const ConvKArgs& p, int k, int b, int iy0, int ix0, bool row_ok) {
+  u32x4 v = {0u, 0u, 0u, 0u};
+  constexpr int VEC = Elem<T>::VEC;
+  if (!p.scalar_gather) {
+    const unsigned tap = p.div_ctot.div((unsigned)k);
+    int ci = k - (int)tap * p.ctot;
+    const unsigned ky = p.div_kw.div(tap);
+    const int kx = (int)tap - (int)ky * p.KW;
+    const int iy = iy0 + (int)ky, ix = ix0 + kx;
+    if (row_ok && k < p.K && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) {
+      const char* base; int ld, up;
+      if (ci < p.c0) { base = p.x0; ld = p.x0_ld; up = p.up0; }
+      else { base = p.x1; ld = p.x1_ld; up = p.up1; ci -= p.c0; }
+      const size_t pix = ((size_t)b * (p.H >> up) + (iy >> up)) * (size_t)(p.W >> up) + (ix >> up);
+      v = *reinterpret_cast<const u32x4*>(base + (pix * ld + ci) * sizeof(T));
+    }
+  } else {
+    T tmp[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      const int ke = k + e;
+      T val = (T)0;
+      const unsigned tap = p.div_ctot.div((unsigned)ke);
+      int ci = ke - (int)tap * p.ctot;
+      const unsigned ky = p.div_kw.div(tap);
+      const int kx = (int)tap - (int)ky * p.KW;
+      const int iy = iy0 + (int)ky, ix = ix0 + kx;
+      if (row_ok && ke < p.K && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) {
+        const char* base; int ld, up;
+        if (ci < p.c0) { base = p.x0; ld = p.x0_ld; up = p.up0; }
+        else { base = p.x1; ld = p.x1_ld; up = p.up1; ci -= p.c0; }
+        const size_t pix = ((size_t)b * (p.H >> up) + (iy >> up)) * (size_t)(p.W >> up) + (ix >> up);
+        val = *reinterpret_cast<const T*>(base + (pix * ld + ci) * sizeof(T));
+      }
+      tmp[e] = val;
+    }
+    v = *reinterpret_cast<const u32x4*>(tmp);
+  }
+  return v;
+}
+
+template <typename T, typename TO, int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void igemm_kernel(const ConvKArgs p) {
+  constexpr int BKB = 64;                 // data bytes per LDS row per K-tile
+  constexpr int ES = sizeof(T);
+  constexpr int VEC = 16 / ES;
+  constexpr int BK = BKB / ES;
+  constexpr int CH = BKB / 16;            // 16-byte chunks per row
+  constexpr int ROWB = BKB + 16;
+  constexpr int A_IT = (BM * CH + 255) / 256;
+  constexpr int B_IT = (BN * CH + 255) / 256;
+  constexpr int WTM = BM / WM, WTN = BN / WN;
+  constexpr int TM = WTM / 32, TN = WTN / 32;
+  static_assert(WM * WN == 4 && TM >= 1 && TN >= 1, "4 waves, 32x32 tiles");
+  constexpr int OES = sizeof(TO);
+  constexpr int OVEC = 16 / OES;
+  constexpr int CROWB = BN * OES + 16;    // epilogue tile row stride (bytes)
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const As = smem;                          // pixels  [2][BM][ROWB]
+  char* const Bs = smem + 2 * BM * ROWB;          // weights [2][BN][ROWB]
+
+  const int tid = threadIdx.x;
+  const int bn = blockIdx.x % p.nb_n, bm = blockIdx.x / p.nb_n;
+  const int m0 = bm * BM, n0 = bn * BN;
+
+  // ---- per-thread staging slots ---------------------------------------------------------------
+  const int cchunk = tid % CH;                    // same chunk column for every slot of a thread
+  int a_b[A_IT], a_iy0[A_IT], a_ix0[A_IT];
+  bool a_ok[A_IT];
+  const int ohow = p.OH * p.OW;
+#pragma unroll
+  for (int i = 0; i < A_IT; ++i) {
+    const int row = (tid + i * 256) / CH;
+    const int m = m0 + row;
+    a_ok[i] = (row < BM) && (m < p.M);
+    const int mm = a_ok[i] ? m : 0;
+    const int b = mm / ohow;
+    const int r = mm - b * ohow;
+    const int oy = r / p.OW, ox = r - oy * p.OW;
+    a_b[i] = b;
+    a_iy0[i] = oy * p.stride - p.pad;
+    a_ix0[i] = ox * p.stride - p.pad;
+  }
+
+  u32x4 a_reg[A_IT], b_reg[B_IT];
+  auto load_tile = [&](int kt) {
+    const int k = kt * BK + cchunk * VEC;
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i)
+      a_reg[i] = gather_chunk<T>(p, k, a_b[i], a_iy0[i], a_ix0[i], a_ok[i]);
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) {
+      const int row = (tid + i * 256) / CH;
+      if (BN * CH >= 256 * (i + 1) || row < BN)
+        b_reg[i] = *reinterpret_cast<const u32x4*>(p.w + ((size_t)(n0 + row) * p.Kpad + k) * ES);
+    }
+  };
+  auto store_tile = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+      const int row = (tid + i * 256) / CH;
+      if (BM * CH >= 256 * (i + 1) || row < BM)
+        *reinterpret_cast<u32x4*>(As + (buf * BM + row) * ROWB + cchunk * 16) = a_reg[i];
+    }
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) {
+      const int row = (tid + i * 256) / CH;
+      if (BN * CH >= 256 * (i + 1) || row < BN)
+        *reinterpret_cast<u32x4*>(Bs + (buf * BN + row) * ROWB + cchunk * 16) = b_reg[i];
+    }
+  };
+
+  const int wv = tid >> 6, lane = tid & 63;
+  const int wm = wv % WM, wn = wv / WM;
+  const int lr = lane & 31, lh = lane >> 5;
+
+  f32x16 acc[TN][TM];
+#pragma unroll
+  for (int i = 0; i < TN; ++i)
+#pragma unroll
+    for (int j = 0; j < TM; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nk = p.Kpad / BK;
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) load_tile(kt + 1);
+    const char* Ab = As + (buf * BM + wm * WTM + lr) * ROWB + lh * 16;
+    const char* Bb = Bs + (buf * BN + wn * WTN + lr) * ROWB + lh * 16;
+#pragma unroll
+    for (int s = 0; s < BKB / 32; ++s) {
+      u32x4 wf[TN], xf[TM];
+#pragma unroll
+      for (int i = 0; i < TN; ++i) wf[i] = *reinterpret_cast<const u32x4*>(Bb + i * 32 * ROWB + s * 32);
+#pragma unroll
+      for (int j = 0; j < TM; ++j) xf[j] = *reinterpret_cast<const u32x4*>(Ab + j * 32 * ROWB + s * 32);
+#pragma unroll
+      for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) Mma<T>::run(wf[i], xf[j], acc[i][j]);
+    }
+    if (kt + 1 < nk) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: bias + act in registers -> LDS tile [BM][BN] (TO) -> coalesced 16-byte stores --
+  char* const Ct = smem;
+  constexpr bool FAST = FastMath<T>::value;
+#pragma unroll
+  for (int i = 0; i < TN; ++i) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int nl = wn * WTN + i * 32 + 8 * q + 4 * lh;      // 4 consecutive channels
+      const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + n0 + nl);
+#pragma unroll
+      for (int j = 0; j < TM; ++j) {
+        const int ml = wm * WTM + j * 32 + lr;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = act_apply<FAST>(acc[i][j][4 * q + e] + bv[e], p.act);
+        char* dst = Ct + ml * CROWB + nl * OES;
+        if constexpr (OES == 2) {
+          f16x4 hv = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
+          *reinterpret_cast<f16x4*>(dst) = hv;
+        } else {
+          f32x4 fv = {v[0], v[1], v[2], v[3]};
+          *reinterpret_cast<f32x4*>(dst) = fv;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  constexpr int NCH = BN / OVEC;                  // 16-byte chunks per output row
+  for (int idx = tid; idx < BM * NCH; idx += 256) {
+    const int row = idx / NCH, ch = idx - row * NCH;
+    const int m = m0 + row, n = n0 + ch * OVEC;
+    if (m >= p.M || n >= p.N) continue;
+    u32x4 cv = *reinterpret_cast<const u32x4*>(Ct + row * CROWB + ch * 16);
+    char* yp = p.y + ((size_t)m * p.y_ld + n) * OES;
+    if (n + OVEC <= p.N) {
+      if (p.res) {
+        const u32x4 rv = *reinterpret_cast<const u32x4*>(p.res + ((size_t)m * p.res_ld + n) * OES);
+        float a[OVEC], r[OVEC];
+        unpack16<TO>(cv, a);
+        unpack16<TO>(rv, r);
+#pragma unroll
+        for (int e = 0; e < OVEC; ++e) a[e] += r[e];
+        cv = pack16<TO>(a);
+      }
+      *reinterpret_cast<u32x4*>(yp) = cv;
+    } else {                                       // ragged channel tail: element-wise
+      const TO* cs = reinterpret_cast<const TO*>(&cv);
+      for (int e = 0; e < p.N - n; ++e) {
+        float a = (float)cs[e];
+        if (p.res) a += (float)reinterpret_cast<const TO*>(p.res + ((size_t)m * p.res_ld + n) * OES)[e];
+        reinterpret_cast<TO*>(yp)[e] = (TO)a;
+      }
+    }
+  }
+}
+
+template <typename T, typename TO, int BM, int BN, int WM, int WN>
+int launch_cfg(ConvKArgs& a, hipStream_t stream) {
+  constexpr int ROWB = 64 + 16;
+  constexpr size_t stage = (size_t)2 * (BM + BN) * ROWB;
+  constexpr size_t epi = (size_t)BM * (BN * sizeof(TO) + 16);
+  constexpr size_t lds = stage > epi ? stage : epi;
+  static bool attr_done = false;
+  if (!attr_done && lds > 64 * 1024) {
+    CVMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<T, TO, BM, BN, WM, WN>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_done = true;
+  }
+  a.nb_n = cdiv(a.N, BN);
+  const long long blocks = (long long)cdiv(a.M, BM) * a.nb_n;
+  CVMI_CHECK(blocks > 0 && blocks < (1ll << 31), "conv2d: bad grid %lld", blocks);
+  hipLaunchKernelGGL((igemm_kernel<T, TO, BM, BN, WM, WN>), dim3((unsigned)blocks), dim3(256), lds, stream, a);
+  CVMI_LAUNCH_CHECK();
+  return 0;
+}
+
+template <typename T, typename TO>
+int launch_typed(ConvKArgs& a, hipStream_t stream) {
+  const long long M = a.M;
+  const int N = a.N;
+  // Tile choice: BN covers Cout where it can (each gathered pixel row is then read once); BM
+  // shrinks when the grid would not fill 256 CUs x 2.
+  if (N <= 32) {
+    if (M >= 256 * 512) return launch_cfg<T, TO, 256, 32, 4, 1>(a, stream);
+    return launch_cfg<T, TO, 128, 32, 4, 1>(a, stream);
+  }
+  if (N <= 64) {
+    if (M >= 128 * 512) return launch_cfg<T, TO, 128, 64, 2, 2>(a, stream);
+    return launch_cfg<T, TO, 64, 64, 2, 2>(a, stream);
+  }
+  const long long blocks128 = (long long)cdiv(M, 128) * cdiv(N, 128);
+  if (blocks128 >= 512) return launch_cfg<T, TO, 128, 128, 2, 2>(a, stream);
+  return launch_cfg<T, TO, 64, 128, 2, 2>(a, stream);
+}
+
+}  // namespace
+
+extern "C" int cvmi_conv2d(const cvmi_conv_desc* d, cvmi_stream_t stream_) {
+  CVMI_CHECK(d != nullptr, "conv2d: null descriptor");
+  CVMI_CHECK(d->x0 && d->w && d->bias && d->y, "conv2d: null pointer");
+  CVMI_CHECK(d->dtype == CVMI_F16 || d->dtype == CVMI_F32, "conv2d: bad dtype %d", d->dtype);
+  const int es = d->dtype == CVMI_F16 ? 2 : 4;
+  const int vec = 16 / es;
+  const int oes = (d->dtype == CVMI_F32 || d->out_f32) ? 4 : 2;
+  const int ovec = 16 / oes;
+  CVMI_CHECK(d->B > 0 && d->H > 0 && d->W > 0 && d->OH > 0 && d->OW > 0 && d->N > 0, "conv2d: bad shape");
+  CVMI_CHECK(d->KH > 0 && d->KW > 0 && d->stride > 0 && d->pad >= 0, "conv2d: bad kernel geometry");
+  CVMI_CHECK(d->c0 > 0 && d->c1 >= 0 && (d->c1 == 0 || d->x1), "conv2d: bad sources");
+  CVMI_CHECK((d->OH - 1) * d->stride - d->pad + d->KH - 1 < d->H + d->pad &&
+             (d->OW - 1) * d->stride - d->pad + d->KW - 1 < d->W + d->pad, "conv2d: output larger than input allows");
+  const int ctot = d->c0 + d->c1;
+  const long long K = (long long)d->KH * d->KW * ctot;
+  CVMI_CHECK(K < 65536 && d->Kpad >= K && d->Kpad % 32 == 0 && d->Kpad < 65536 + 32, "conv2d: K=%lld Kpad=%d unsupported", K, d->Kpad);
+  if (!d->scalar_gather) {
+    CVMI_CHECK(d->c0 % vec == 0 && d->c1 % vec == 0, "conv2d: channels (%d,%d) not multiples of %d", d->c0, d->c1, vec);
+    CVMI_CHECK(d->x0_ld % vec == 0 && (d->c1 == 0 || d->x1_ld % vec == 0), "conv2d: source ld not 16-byte aligned");
+    CVMI_CHECK(((uintptr_t)d->x0 & 15) == 0 && ((uintptr_t)d->x1 & 15) == 0, "conv2d: source not 16-byte aligned");
+  }
+  CVMI_CHECK(d->x0_ld >= d->c0 && (d->c1 == 0 || d->x1_ld >= d->c1), "conv2d: ld smaller than channels");
+  CVMI_CHECK(d->y_ld % ovec == 0 && ((uintptr_t)d->y & 15) == 0, "conv2d: output not 16-byte aligned");
+  CVMI_CHECK(d->y_ld >= d->N, "conv2d: y_ld < N");
+  CVMI_CHECK(!d->res || (d->res_ld % ovec == 0 && ((uintptr_t)d->res & 15) == 0 && d->res_ld >= d->N), "conv2d: residual misaligned");
+  CVMI_CHECK(((uintptr_t)d->w & 15) == 0 && ((uintptr_t)d->bias & 15) == 0, "conv2d: weights misaligned");
+  CVMI_CHECK(d->up0 == 0 || (d->H % 2 == 0 && d->W % 2 == 0), "conv2d: upsampled source needs even H, W");
+  CVMI_CHECK(d->up1 == 0 || (d->H % 2 == 0 && d->W % 2 == 0), "conv2d: upsampled source needs even H, W");
+  const long long M = (long long)d->B * d->OH * d->OW;
+  CVMI_CHECK(M < (1ll << 31), "conv2d: M too large");
+
+  ConvKArgs a;
+  a.x0 = (const char*)d->x0; a.x1 = (const char*)d->x1; a.w = (const char*)d->w; a.bias = d->bias;
+  a.res = (const char*)d->res; a.y = (char*)d->y;
+  a.x0_ld = d->x0_ld; a.x1_ld = d->x1_ld; a.res_ld = d->res_ld; a.y_ld = d->y_ld;
+  a.c0 = d->c0; a.ctot = ctot; a.up0 = d->up0; a.up1 = d->up1;
+  a.H = d->H; a.W = d->W; a.OH = d->OH; a.OW = d->OW; a.KW = d->KW; a.stride = d->stride; a.pad = d->pad;
+  a.M = (int)M; a.N = d->N; a.K = (int)K; a.Kpad = d->Kpad;
+  a.act = d->act; a.scalar_gather = d->scalar_gather; a.nb_n = 1;
+  a.div_ctot.init((unsigned)ctot); a.div_kw.init((unsigned)d->KW);
+  hipStream_t stream = (hipStream_t)stream_;
+  if (d->dtype == CVMI_F32) return launch_typed<float, float>(a, stream);
+  if (d->out_f32) return launch_typed<f16, float>(a, stream);
+  return launch_typed<f16, f16>(a, stream);
+}

@@ -1,0 +1,155 @@
+// Detector NMS with ultralytics / torchvision CPU semantics, one 1024-thread workgroup per image.
+// (compiled with -ffp-contract=off: IoU arithmetic must round exactly like the fp32 CPU kernel)
+//
+//   1. per anchor: best class score (first maximum), candidate iff score > conf_thres;
+//      key = (score bits << 32) | ~anchor  -> unique, so the order is deterministic
+//   2. bitonic sort of the keys in LDS, descending  (= score desc, anchor index asc on ties)
+//   3. boxes -> xyxy (xy -/+ wh/2), offset by cls * max_wh, area; staged in the workspace
+//   4. greedy pass: next unsuppressed candidate is kept, every later candidate with
+//      inter / (area_i + area_j - inter) > iou_thres is marked in an LDS bitmask; stops at max_det.
+#include "common.hpp"
+
+namespace {
+
+constexpr int NMS_THREADS = 1024;
+constexpr int NMS_MAX_A = 16384;
+
+struct Cand { float x1, y1, x2, y2, area; };   // offset boxes (class * max_wh added)
+
+__global__ __launch_bounds__(NMS_THREADS) void yolo_nms_kernel(const float* __restrict__ pred, int nc, int A, float conf_thres,
+                                                              float iou_thres, int max_det, float max_wh, float* __restrict__ out_det,
+                                                              int* __restrict__ out_idx, int* __restrict__ out_count,
+                                                              char* __restrict__ workspace, int P) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem);           // [P]
+  unsigned long long* supp = keys + P;                                               // [P/64] bitmask
+  int& s_count = *reinterpret_cast<int*>(supp + (P >> 6));                           // all LDS dynamic (16-B aligned base)
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const float* pb = pred + (size_t)b * (4 + nc) * A;
+  int* cls_ws = reinterpret_cast<int*>(workspace + (size_t)b * ((size_t)A * (sizeof(int) + sizeof(Cand))));
+  Cand* cand = reinterpret_cast<Cand*>(cls_ws + A);
+
+  if (tid == 0) s_count = 0;
+  for (int i = tid; i < P; i += NMS_THREADS) keys[i] = 0ull;
+  __syncthreads();
+
+  // 1. candidates
+  for (int a = tid; a < A; a += NMS_THREADS) {
+    float best = pb[(size_t)4 * A + a];
+    int bc = 0;
+    for (int c = 1; c < nc; ++c) {
+      const float v = pb[(size_t)(4 + c) * A + a];
+      if (v > best) { best = v; bc = c; }
+    }
+    cls_ws[a] = bc;
+    if (best > conf_thres) {
+      const int slot = atomicAdd(&s_count, 1);
+      keys[slot] = ((unsigned long long)__float_as_uint(best) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)a);
+    }
+  }
+  __syncthreads();
+  const int n = s_count;
+
+  // 2. bitonic sort, descending, over the smallest power of two >= n
+  int Ps = 1;
+  while (Ps < n) Ps <<= 1;
+  for (int k = 2; k <= Ps; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int t = tid; t < Ps / 2; t += NMS_THREADS) {
+        const int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+        const int hi = lo | j;
+        const bool desc = (lo & k) == 0;
+        const unsigned long long x = keys[lo], y = keys[hi];
+        if ((x < y) == desc) { keys[lo] = y; keys[hi] = x; }
+      }
+      __syncthreads();
+    }
+  }
+
+  // 3. candidate geometry in sorted order
+  for (int i = tid; i < n; i += NMS_THREADS) {
+    const int a = (int)(0xFFFFFFFFu - (unsigned)(keys[i] & 0xFFFFFFFFull));
+    const float cx = pb[a], cy = pb[(size_t)A + a], w = pb[(size_t)2 * A + a], h = pb[(size_t)3 * A + a];
+    const float hw = w / 2.f, hh = h / 2.f;
+    const float off = (float)cls_ws[a] * max_wh;
+    Cand c;
+    c.x1 = (cx - hw) + off; c.y1 = (cy - hh) + off; c.x2 = (cx + hw) + off; c.y2 = (cy + hh) + off;
+    c.area = (c.x2 - c.x1) * (c.y2 - c.y1);
+    cand[i] = c;
+  }
+  for (int i = tid; i < (P >> 6); i += NMS_THREADS) supp[i] = 0ull;
+  __threadfence_block();
+  __syncthreads();
+
+  // 4. greedy suppression
+  int kept = 0;
+  int i = 0;
+  while (kept < max_det) {
+    // next unsuppressed candidate at or after i (uniform across the block: all threads read LDS)
+    int word = i >> 6;
+    const int nwords = (n + 63) >> 6;
+    int found = -1;
+    while (word < nwords) {
+      unsigned long long m = ~supp[word];
+      if (word == (i >> 6)) m &= ~0ull << (i & 63);
+      if (m) { found = (word << 6) + __builtin_ctzll(m); break; }
+      ++word;
+    }
+    if (found < 0 || found >= n) break;
+    i = found;
+    const Cand ci = cand[i];
+    if (tid == 0) {
+      const int a = (int)(0xFFFFFFFFu - (unsigned)(keys[i] & 0xFFFFFFFFull));
+      const float cx = pb[a], cy = pb[(size_t)A + a], w = pb[(size_t)2 * A + a], h = pb[(size_t)3 * A + a];
+      const float hw = w / 2.f, hh = h / 2.f;
+      float* o = out_det + ((size_t)b * max_det + kept) * 6;
+      o[0] = cx - hw; o[1] = cy - hh; o[2] = cx + hw; o[3] = cy + hh;
+      o[4] = __uint_as_float((unsigned)(keys[i] >> 32));
+      o[5] = (float)cls_ws[a];
+      out_idx[(size_t)b * max_det + kept] = a;
+    }
+    ++kept;
+    for (int j = i + 1 + tid; j < n; j += NMS_THREADS) {
+      if ((supp[j >> 6] >> (j & 63)) & 1ull) continue;
+      const Cand cj = cand[j];
+      const float xx1 = fmaxf(ci.x1, cj.x1), yy1 = fmaxf(ci.y1, cj.y1);
+      const float xx2 = fminf(ci.x2, cj.x2), yy2 = fminf(ci.y2, cj.y2);
+      const float w = fmaxf(0.f, xx2 - xx1), h = fmaxf(0.f, yy2 - yy1);
+      const float inter = w * h;
+      const float ovr = inter / (ci.area + cj.area - inter);
+      if (ovr > iou_thres) atomicOr(&supp[j >> 6], 1ull << (j & 63));
+    }
+    ++i;
+    __syncthreads();
+  }
+  if (tid == 0) out_count[b] = kept;
+}
+
+}  // namespace
+
+extern "C" size_t cvmi_yolo_nms_workspace(int B, int A) {
+  if (B <= 0 || A <= 0) return 0;
+  return (size_t)B * (size_t)A * (sizeof(int) + sizeof(Cand)) + 256;
+}
+
+extern "C" int cvmi_yolo_nms(const float* pred, int B, int nc, int A, float conf_thres, float iou_thres, int max_det, float max_wh,
+                             float* out_det, int* out_idx, int* out_count, void* workspace, cvmi_stream_t stream_) {
+  CVMI_CHECK(pred && out_det && out_idx && out_count && workspace, "yolo_nms: null pointer");
+  CVMI_CHECK(B > 0 && nc > 0 && A > 0 && max_det > 0, "yolo_nms: bad shape");
+  CVMI_CHECK(A <= NMS_MAX_A, "yolo_nms: A=%d exceeds %d anchors", A, NMS_MAX_A);
+  CVMI_CHECK(conf_thres >= 0.f, "yolo_nms: conf_thres must be >= 0 (keys rely on non-negative scores)");
+  int P = 1024;
+  while (P < A) P <<= 1;
+  const size_t lds = (size_t)P * 8 + (size_t)(P / 64) * 8 + 16;
+  static bool attr_done = false;
+  if (!attr_done) {
+    CVMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&yolo_nms_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 NMS_MAX_A * 8 + (NMS_MAX_A / 64) * 8 + 16));
+    attr_done = true;
+  }
+  hipStream_t stream = (hipStream_t)stream_;
+  hipLaunchKernelGGL(yolo_nms_kernel, dim3(B), dim3(NMS_THREADS), lds, stream, pred, nc, A, conf_thres, iou_thres, max_det, max_wh, out_det,
+                     out_idx, out_count, (char*)workspace, P);
+  CVMI_LAUNCH_CHECK();
+  return 0;
+}

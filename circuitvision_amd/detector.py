@@ -1,0 +1,182 @@
+"""Drop-in for `ultralytics.YOLO` as the reference uses it:
+
+    self.yolo = YOLO(yolo_path)                      circuit_analyzer.py:45
+    self.yolo.model.names -> {int: str}              circuit_analyzer.py:111, 121, 2160, 2264
+    r = self.yolo.predict(image, verbose=True)[0]    circuit_analyzer.py:268
+    r.boxes.cls / .conf / .xyxy (.cpu().numpy().tolist()),  r.names[int]     :270-273
+
+Everything between the uint8 HxWx3 image and the [n,6] detections runs in HIP kernels: letterbox,
+the YOLO11 network, Detect decode and NMS (one captured HIP graph per letterboxed shape).
+"""
+import math
+import threading
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import F16, F32
+from .engine import require_gpu
+from .yolo11 import StateDictParams, SyntheticParams, Yolo11Plan, Yolo11Weights
+
+
+def letterbox_geometry(h, w, new_shape=640, stride=32, auto=True):
+    """ultralytics LetterBox(new_shape, auto=True, stride=32) geometry."""
+    r = min(new_shape / h, new_shape / w)
+    nw, nh = int(round(w * r)), int(round(h * r))
+    dw, dh = new_shape - nw, new_shape - nh
+    if auto:
+        dw, dh = dw % stride, dh % stride
+    dw /= 2
+    dh /= 2
+    top, bottom = int(round(dh - 0.1)), int(round(dh + 0.1))
+    left, right = int(round(dw - 0.1)), int(round(dw + 0.1))
+    return nw, nh, top, bottom, left, right
+
+
+class Boxes:
+    def __init__(self, det):
+        self.data = det                      # [n, 6] x1,y1,x2,y2,conf,cls (device tensor)
+
+    xyxy = property(lambda s: s.data[:, :4])
+    conf = property(lambda s: s.data[:, 4])
+    cls = property(lambda s: s.data[:, 5])
+
+    def __len__(self):
+        return self.data.shape[0]
+
+
+class Results:
+    def __init__(self, det, names, orig_shape, anchor_idx=None):
+        self.boxes = Boxes(det)
+        self.names = names
+        self.orig_shape = orig_shape
+        self.anchor_idx = anchor_idx
+
+    def __len__(self):
+        return len(self.boxes)
+
+
+def parse_spec(path):
+    """'synthetic:<scale>:<nc>[:seed]' -> (scale, nc, seed) or None."""
+    if isinstance(path, str) and path.startswith("synthetic:"):
+        parts = path.split(":")
+        return parts[1], int(parts[2]), int(parts[3]) if len(parts) > 3 else 0
+    return None
+
+
+class YOLO:
+    """`YOLO(path)`; path is a checkpoint (torch-saved dict with 'state_dict' (ultralytics keys),
+    'names', 'scale') or 'synthetic:<scale>:<nc>[:seed]' for seeded random weights."""
+
+    def __init__(self, path, dtype="f16", device="cuda", imgsz=640):
+        require_gpu()
+        self.dtype = {"f16": F16, "fp16": F16, "f32": F32, "fp32": F32}[dtype] if isinstance(dtype, str) else dtype
+        self.device = device
+        self.imgsz = imgsz
+        spec = parse_spec(path)
+        if spec is not None:
+            scale, nc, seed = spec
+            params = SyntheticParams(seed=seed, nc=nc)
+            names = {i: f"class{i}" for i in range(nc)}
+        else:
+            ck = torch.load(path, map_location="cpu", weights_only=True)
+            if "state_dict" not in ck or "scale" not in ck:
+                raise ValueError("checkpoint must hold {'state_dict', 'names', 'scale'} (see INTEGRATION.md for the "
+                                 "one-off converter from an ultralytics .pt)")
+            scale, names = ck["scale"], {int(k): v for k, v in ck["names"].items()}
+            nc = len(names)
+            params = StateDictParams(ck["state_dict"])
+        self.params = params
+        self.weights = Yolo11Weights(scale, nc, params, self.dtype, device)
+        self.model = SimpleNamespace(names=names, nc=nc, scale=scale, stride=32)
+        self.names = names
+        self.stream = torch.cuda.Stream(device=device)
+        self._plans = {}
+        self._lock = threading.Lock()      # one analyzer is shared by all Streamlit sessions (app.py:134)
+
+    # ---- plans ---------------------------------------------------------------------------------
+    def plan(self, B, H, W, conf=0.25, iou=0.7, max_det=300):
+        key = (B, H, W, conf, iou, max_det)
+        if key not in self._plans:
+            with torch.cuda.device(self.device):
+                self._plans[key] = Yolo11Plan(self.weights, B, H, W, self.stream, conf, iou, max_det)
+        return self._plans[key]
+
+    # ---- reference entry point -----------------------------------------------------------------
+    def predict(self, image, verbose=True, conf=0.25, iou=0.7, max_det=300, **_):
+        """image: uint8 HxWx3 numpy array (or a list of same-shaped ones).  Returns [Results]."""
+        images = image if isinstance(image, (list, tuple)) else [image]
+        for im in images:
+            if not (isinstance(im, np.ndarray) and im.ndim == 3 and im.shape[2] == 3 and im.dtype == np.uint8):
+                raise TypeError("predict expects uint8 HxWx3 numpy images")
+        h0, w0 = images[0].shape[:2]
+        if any(im.shape[:2] != (h0, w0) for im in images):
+            raise ValueError("a batch must share one image size")
+        nw, nh, top, bottom, left, right = letterbox_geometry(h0, w0, self.imgsz)
+        H, W = nh + top + bottom, nw + left + right
+        lib = _lib.load()
+        with self._lock, torch.cuda.device(self.device):
+            p = self.plan(len(images), H, W, conf, iou, max_det)
+            sp = self.stream.cuda_stream
+            srcs = []
+            with torch.cuda.stream(self.stream):
+                for b, im in enumerate(images):
+                    src = torch.from_numpy(np.ascontiguousarray(im)).to(self.device, non_blocking=False)
+                    srcs.append(src)
+                    dst = p.x_in.t[b]
+                    _lib.check(lib.cvmi_letterbox(src.data_ptr(), h0, w0, dst.data_ptr(), H, W, nh, nw, top, left, self.dtype, sp), "letterbox")
+                p.plan.run()
+                self.stream.synchronize()
+                counts = p.det_count.cpu().tolist()
+                out = []
+                for b, n in enumerate(counts):
+                    det = p.det[b, :n].clone()
+                    det[:, :4] = scale_boxes((H, W), det[:, :4], (h0, w0))
+                    out.append(Results(det, self.names, (h0, w0), p.det_idx[b, :n].clone()))
+        if verbose:
+            print(f"cvmi355 YOLO11{self.model.scale}: {H}x{W} {', '.join(str(len(r)) + ' boxes' for r in out)}")
+        return out
+
+    __call__ = predict
+
+
+def scale_boxes(img1_shape, boxes, img0_shape):
+    """ultralytics ops.scale_boxes + clip_boxes (fp32, same op order as the CPU path)."""
+    gain = min(img1_shape[0] / img0_shape[0], img1_shape[1] / img0_shape[1])
+    pad_x = round((img1_shape[1] - img0_shape[1] * gain) / 2 - 0.1)
+    pad_y = round((img1_shape[0] - img0_shape[0] * gain) / 2 - 0.1)
+    boxes = boxes.clone()
+    boxes[..., 0] -= pad_x
+    boxes[..., 1] -= pad_y
+    boxes[..., 2] -= pad_x
+    boxes[..., 3] -= pad_y
+    boxes[..., :4] /= gain
+    boxes[..., 0].clamp_(0, img0_shape[1])
+    boxes[..., 1].clamp_(0, img0_shape[0])
+    boxes[..., 2].clamp_(0, img0_shape[1])
+    boxes[..., 3].clamp_(0, img0_shape[0])
+    return boxes
+
+
+# ---- second-stage NMS (reference-owned, analysis_pipeline.py:106 / utils.py:346-361) ---------------
+def calculate_iou(b1, b2):
+    iw = max(min(b1["xmax"], b2["xmax"]) - max(b1["xmin"], b2["xmin"]), 0)
+    ih = max(min(b1["ymax"], b2["ymax"]) - max(b1["ymin"], b2["ymin"]), 0)
+    inter = iw * ih
+    union = ((b1["xmax"] - b1["xmin"]) * (b1["ymax"] - b1["ymin"]) +
+             (b2["xmax"] - b2["xmin"]) * (b2["ymax"] - b2["ymin"]) - inter)
+    return inter / union if union > 0 else 0.0
+
+
+def non_max_suppression_by_confidence(bboxes, iou_threshold=0.5):
+    """Host-side mirror of utils.py:346-361 (<= 300 integer boxes; stays on the CPU in the
+    reference too -- the caller, analysis_pipeline.py:106, is untouched and keeps using its own)."""
+    rest = sorted(bboxes, key=lambda b: b["confidence"], reverse=True)
+    kept = []
+    while rest:
+        top = rest.pop(0)
+        kept.append(top)
+        rest = [b for b in rest if calculate_iou(top, b) < iou_threshold]
+    return kept

@@ -1,0 +1,248 @@
+"""Launch-plan engine: NHWC buffers, op wrappers over the C ABI, HIP-graph capture.
+
+PyTorch is used only as plumbing (device memory, streams, events).  A `Plan` is a static list of
+kernel launches over pre-allocated buffers for one input shape; it runs either launch by launch
+(parity tests, per-kernel timing) or as one captured HIP graph (throughput path).
+"""
+import ctypes as C
+import threading
+
+import torch
+
+from . import _lib
+from ._lib import F16, F32, AttnDesc, ConvDesc
+
+TORCH_DTYPE = {F16: torch.float16, F32: torch.float32}
+ESIZE = {F16: 2, F32: 4}
+
+
+def require_gpu():
+    if not torch.cuda.is_available():
+        raise _lib.CvmiError("circuitvision_amd needs an MI355X (gfx950) GPU: torch.cuda.is_available() is False; "
+                             "there is no CPU fallback")
+    _lib.load()
+
+
+class Buf:
+    """NHWC activation buffer [B, H, W, C] of one dtype."""
+
+    def __init__(self, B, H, W, C, dtype, device="cuda", zero=False):
+        self.B, self.H, self.W, self.C, self.dtype = B, H, W, C, dtype
+        alloc = torch.zeros if zero else torch.empty
+        self.t = alloc((B, H, W, C), dtype=TORCH_DTYPE[dtype], device=device)
+
+    def view(self, c0=0, c=None):
+        return View(self, c0, self.C - c0 if c is None else c)
+
+    @property
+    def nbytes(self):
+        return self.t.numel() * self.t.element_size()
+
+
+class View:
+    """Channel slice [c0, c0+c) of a Buf: (ptr, ld) as the C ABI wants it."""
+
+    def __init__(self, buf, c0, c):
+        assert 0 <= c0 and c0 + c <= buf.C, (c0, c, buf.C)
+        self.buf, self.c0, self.c = buf, c0, c
+
+    @property
+    def ptr(self):
+        return self.buf.t.data_ptr() + self.c0 * ESIZE[self.buf.dtype]
+
+    @property
+    def ld(self):
+        return self.buf.C
+
+    B = property(lambda s: s.buf.B)
+    H = property(lambda s: s.buf.H)
+    W = property(lambda s: s.buf.W)
+    dtype = property(lambda s: s.buf.dtype)
+
+    def tensor(self):
+        return self.buf.t[..., self.c0:self.c0 + self.c]
+
+
+class PackedConv:
+    """Weights of one fused conv / linear layer in the layout cvmi_conv2d reads:
+    w [Npad][Kpad] (k = (ky*KW + kx)*Cin + c), bias f32 [Npad]."""
+
+    def __init__(self, weight, bias, dtype, device="cuda"):
+        # weight: [N, Cin, KH, KW] float32 (BN already folded), bias: [N] or None
+        N, Cin, KH, KW = weight.shape
+        K = Cin * KH * KW
+        Npad = (N + 127) // 128 * 128
+        Kpad = (K + 31) // 32 * 32
+        w = torch.zeros(Npad, Kpad, dtype=torch.float32)
+        w[:N, :K] = weight.permute(0, 2, 3, 1).reshape(N, K)
+        b = torch.zeros(Npad, dtype=torch.float32)
+        if bias is not None:
+            b[:N] = bias
+        self.w = w.to(TORCH_DTYPE[dtype]).to(device)
+        self.bias = b.to(device)
+        self.N, self.Cin, self.KH, self.KW, self.K, self.Kpad, self.dtype = N, Cin, KH, KW, K, Kpad, dtype
+        self.param_bytes = N * K * ESIZE[dtype]
+
+
+class PackedDW:
+    """Depthwise 3x3 weights: w [9][C] tap-major, bias f32 [C]."""
+
+    def __init__(self, weight, bias, dtype, device="cuda"):
+        C_ = weight.shape[0]
+        assert weight.shape[1:] == (1, 3, 3)
+        self.w = weight.reshape(C_, 9).t().contiguous().to(TORCH_DTYPE[dtype]).to(device)
+        self.bias = (bias if bias is not None else torch.zeros(C_)).float().to(device)
+        self.C, self.dtype = C_, dtype
+        self.param_bytes = C_ * 9 * ESIZE[dtype]
+
+
+class Plan:
+    """Static launch list.  Each entry: (label, kind, thunk, algorithmic_bytes, flops)."""
+
+    def __init__(self, stream):
+        self.stream = stream
+        self.ops = []
+        self.keep = []          # objects that must outlive the plan (descriptors, buffers)
+        self.graph = None
+        self._lock = threading.Lock()
+
+    @property
+    def sptr(self):
+        return self.stream.cuda_stream
+
+    def add(self, label, kind, thunk, bytes_=0, flops=0):
+        self.ops.append((label, kind, thunk, bytes_, flops))
+
+    # ---- execution ---------------------------------------------------------------------------
+    def run_eager(self):
+        for _, _, thunk, _, _ in self.ops:
+            thunk()
+
+    def capture(self):
+        lib = _lib.load()
+        self.run_eager()                       # warm: first-use hipFuncSetAttribute etc. outside capture
+        self.stream.synchronize()
+        _lib.check(lib.cvmi_graph_begin(self.sptr), "graph_begin")
+        try:
+            self.run_eager()
+        finally:
+            g = C.c_void_p()
+            rc = lib.cvmi_graph_end(self.sptr, C.byref(g))
+        _lib.check(rc, "graph_end")
+        self.graph = g
+
+    def run(self):
+        if self.graph is None:
+            self.capture()
+        _lib.check(_lib.load().cvmi_graph_launch(self.graph, self.sptr), "graph_launch")
+
+    def timed_eager(self):
+        """One eager pass with an event pair around every launch (on the plan's stream).
+        Returns [(label, kind, ms, bytes, flops)]."""
+        evs = []
+        for label, kind, thunk, b, f in self.ops:
+            e0 = torch.cuda.Event(enable_timing=True)
+            e1 = torch.cuda.Event(enable_timing=True)
+            e0.record(self.stream)
+            thunk()
+            e1.record(self.stream)
+            evs.append((label, kind, e0, e1, b, f))
+        self.stream.synchronize()
+        return [(l, k, e0.elapsed_time(e1), b, f) for l, k, e0, e1, b, f in evs]
+
+    def __del__(self):
+        try:
+            if self.graph is not None:
+                _lib.load().cvmi_graph_destroy(self.graph)
+        except Exception:
+            pass
+
+
+# ---- op wrappers (each appends one launch to a plan) --------------------------------------------
+def op_conv(plan, label, pc, srcs, dst, stride=1, pad=None, act=_lib.ACT_NONE, res=None, out_hw=None,
+            scalar_gather=False, kind="conv"):
+    """srcs: [(View, up)] (1 or 2 channel-concatenated sources).  dst / res: View."""
+    lib = _lib.load()
+    (v0, up0) = srcs[0]
+    v1, up1 = (srcs[1] if len(srcs) > 1 else (None, 0))
+    H, W = v0.H << up0, v0.W << up0
+    if v1 is not None:
+        assert (v1.H << up1, v1.W << up1) == (H, W), "concatenated sources disagree on size"
+    ctot = v0.c + (v1.c if v1 is not None else 0)
+    assert ctot == pc.Cin, (label, ctot, pc.Cin)
+    pad = pc.KH // 2 if pad is None else pad
+    OH = (H + 2 * pad - pc.KH) // stride + 1
+    OW = (W + 2 * pad - pc.KW) // stride + 1
+    if out_hw is not None:
+        assert (OH, OW) == tuple(out_hw)
+    assert (dst.B, dst.H, dst.W) == (v0.B, OH, OW) and dst.c == pc.N, (label, (dst.B, dst.H, dst.W, dst.c), (v0.B, OH, OW, pc.N))
+    out_f32 = 1 if (dst.dtype == F32 and pc.dtype == F16) else 0
+    d = ConvDesc(
+        x0=v0.ptr, x1=(v1.ptr if v1 is not None else None), w=pc.w.data_ptr(), bias=pc.bias.data_ptr(),
+        res=(res.ptr if res is not None else None), y=dst.ptr,
+        x0_ld=v0.ld, x1_ld=(v1.ld if v1 is not None else 0), res_ld=(res.ld if res is not None else 0), y_ld=dst.ld,
+        c0=v0.c, c1=(v1.c if v1 is not None else 0), up0=up0, up1=up1,
+        B=v0.B, H=H, W=W, OH=OH, OW=OW, KH=pc.KH, KW=pc.KW, stride=stride, pad=pad,
+        N=pc.N, Kpad=pc.Kpad, act=act, dtype=pc.dtype, out_f32=out_f32, scalar_gather=1 if scalar_gather else 0)
+    plan.keep.append((d, pc, srcs, dst, res))
+    sp = plan.sptr
+    fn = lib.cvmi_conv2d
+
+    def thunk():
+        _lib.check(fn(C.byref(d), sp), label)
+
+    M = v0.B * OH * OW
+    es, oes = ESIZE[pc.dtype], ESIZE[dst.dtype]
+    in_elems = v0.B * (v0.H * v0.W * v0.c + (v1.H * v1.W * v1.c if v1 is not None else 0))
+    bytes_ = in_elems * es + M * pc.N * oes + (M * pc.N * oes if res is not None else 0)
+    plan.add(label, kind, thunk, bytes_, 2 * M * pc.N * pc.K)
+    return d
+
+
+def op_dwconv(plan, label, pd, src, dst, act=_lib.ACT_NONE, res=None):
+    lib = _lib.load()
+    assert src.c == pd.C == dst.c and (src.B, src.H, src.W) == (dst.B, dst.H, dst.W)
+    args = (src.ptr, src.ld, pd.w.data_ptr(), pd.bias.data_ptr(), res.ptr if res is not None else None,
+            res.ld if res is not None else 0, dst.ptr, dst.ld, src.B, src.H, src.W, pd.C, act, pd.dtype)
+    plan.keep.append((pd, src, dst, res))
+    sp = plan.sptr
+    fn = lib.cvmi_dwconv3x3
+
+    def thunk():
+        _lib.check(fn(*args, sp), label)
+
+    n = src.B * src.H * src.W * pd.C
+    plan.add(label, "dwconv", thunk, n * ESIZE[pd.dtype] * (3 if res is not None else 2), 18 * n)
+
+
+def op_sppf_pool(plan, label, buf, c):
+    lib = _lib.load()
+    args = (buf.t.data_ptr(), buf.C, buf.B, buf.H, buf.W, c, buf.dtype)
+    plan.keep.append(buf)
+    sp = plan.sptr
+    fn = lib.cvmi_sppf_pool
+
+    def thunk():
+        _lib.check(fn(*args, sp), label)
+
+    n = buf.B * buf.H * buf.W * c
+    plan.add(label, "pool", thunk, 4 * n * ESIZE[buf.dtype], 0)
+
+
+def op_attention(plan, label, desc, keep, bytes_=0, flops=0):
+    lib = _lib.load()
+    plan.keep.append((desc, keep))
+    sp = plan.sptr
+    fn = lib.cvmi_attention
+
+    def thunk():
+        _lib.check(fn(C.byref(desc), sp), label)
+
+    plan.add(label, "attention", thunk, bytes_, flops)
+
+
+def make_attn_desc(**kw):
+    d = AttnDesc()
+    for k, v in kw.items():
+        setattr(d, k, v)
+    return d

@@ -1,0 +1,145 @@
+/*
+ * cvmi355.h -- C ABI of libcvmi355.so: the MI355X (gfx950) kernels behind CircuitVision's
+ * dense-vision hot path (YOLO11 detector + SAM 2.1 forward).
+ *
+ * The reference (JKc66/CircuitVision) is pure Python: its boundary for this path is Python duck
+ * typing (`YOLO(path).predict(img)`, `get_modified_sam2(...)(x)`), and the
+ * arithmetic lives in torch / torchvision / ultralytics / sam2 wheels.  The entry points below are
+ * what a maintainer binds (ctypes) to replace those wheels' operators.  Each
+ * one cites the reference call site whose arithmetic it replaces (file:line under /root/reference).
+ *
+ * Conventions
+ *   - plain C: device pointers + sizes; no torch types.  All device buffers are owned by the
+ *     caller; kernels never allocate.  `stream` is a hipStream_t passed as void*.
+ *   - every function returns 0 on success, non-zero on error; cvmi_last_error() returns a
+ *     thread-local message.  Nothing aborts the process (circuit_analyzer.py:255-263, :381-386
+ *     catch ordinary exceptions).
+ *   - activations are NHWC ("pixels x channels", channel contiguous); a tensor view is
+ *     (ptr, ld) where ld = elements between consecutive pixels, so channel slices of a wider
+ *     buffer (zero-copy concat / split) are first-class.
+ *   - dtype: CVMI_F16 (fp16 storage, fp32 accumulate) or CVMI_F32 (exact-f32 MFMA, parity mode).
+ */
+#ifndef CVMI355_H
+#define CVMI355_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CVMI_VERSION 100
+
+typedef void* cvmi_stream_t; /* hipStream_t */
+
+enum { CVMI_F16 = 0, CVMI_F32 = 1 };
+enum { CVMI_ACT_NONE = 0, CVMI_ACT_SILU = 1, CVMI_ACT_RELU = 2, CVMI_ACT_GELU = 3, CVMI_ACT_SIGMOID = 4 };
+
+/* ---- library -------------------------------------------------------------------------------- */
+int cvmi_version(void);
+const char* cvmi_last_error(void);
+/* fills: [0] CU count, [1] wave size, [2] LDS bytes per CU-workgroup, [3] gfx arch number (950) */
+int cvmi_device_info(int device, int* out4);
+
+/* ---- HIP graph capture of a launch sequence (replaces per-op Python dispatch) ---------------- */
+int cvmi_graph_begin(cvmi_stream_t stream);
+int cvmi_graph_end(cvmi_stream_t stream, void** graph_exec_out);
+int cvmi_graph_launch(void* graph_exec, cvmi_stream_t stream);
+int cvmi_graph_destroy(void* graph_exec);
+
+/* ---- fused convolution / linear layer as implicit GEMM on MFMA -------------------------------
+ * y[m, n] = act( sum_k A[m, k] * w[n, k] + bias[n] ) (+ res[m, n])
+ * A is gathered on the fly (im2col) from up to two NHWC sources that are concatenated along the
+ * channel axis (source 0 first), each optionally nearest-2x upsampled (up = 1).
+ * k = (ky*KW + kx)*(c0+c1) + c.  m = (b*OH + oy)*OW + ox.
+ * Replaces: ultralytics Conv(+BN folded)+SiLU, Concat, Upsample inside YOLO.predict
+ * (circuit_analyzer.py:268); nn.Linear / 1x1 Conv2d of Hiera, FpnNeck, mask decoder inside
+ * SAM2ImageWrapper.forward (sam2_infer.py:226-260).
+ * w: [Npad][Kpad] (dtype), zero padded, Npad % 128 == 0, Kpad % 32 == 0.  bias: [Npad] f32.
+ * c0, c1 must be multiples of 16/sizeof(dtype) unless scalar_gather = 1 (e.g. 3-channel stems).
+ */
+typedef struct cvmi_conv_desc {
+  const void* x0; const void* x1;   /* sources (x1 may be NULL when c1 == 0) */
+  const void* w; const float* bias;
+  const void* res;                  /* optional residual, added after the activation */
+  void* y;
+  int x0_ld, x1_ld, res_ld, y_ld;   /* elements between consecutive pixels */
+  int c0, c1;                       /* channels taken from each source */
+  int up0, up1;                     /* 1: source is at half resolution (nearest 2x upsample) */
+  int B, H, W;                      /* logical input size (after upsampling) */
+  int OH, OW;
+  int KH, KW, stride, pad;
+  int N;                            /* output channels */
+  int Kpad;                         /* padded K (row length of w) */
+  int act;                          /* CVMI_ACT_* */
+  int dtype;                        /* CVMI_F16 / CVMI_F32: type of x, w */
+  int out_f32;                      /* 1: y and res are f32 even when dtype is F16 */
+  int scalar_gather;                /* 1: per-element gather (channel count not vectorizable) */
+} cvmi_conv_desc;
+int cvmi_conv2d(const cvmi_conv_desc* d, cvmi_stream_t stream);
+
+/* ---- depthwise 3x3 stride-1 conv + bias + act (YOLO Detect cls branch, C2PSA pe) -------------
+ * w: [9][C] (tap-major), bias [C] f32.  Replaces ultralytics DWConv inside YOLO.predict. */
+int cvmi_dwconv3x3(const void* x, int x_ld, const void* w, const float* bias, const void* res,
+                   int res_ld, void* y, int y_ld, int B, int H, int W, int C, int act, int dtype,
+                   cvmi_stream_t stream);
+
+/* ---- SPPF pooling: y1 = mp5(y0), y2 = mp5(y1), y3 = mp5(y2) (k=5,s=1,p=2) in one pass ---------
+ * buf is the [B,H,W,ld] concat buffer; channels [0,C) hold y0; writes [C,2C), [2C,3C), [3C,4C). */
+int cvmi_sppf_pool(void* buf, int ld, int B, int H, int W, int C, int dtype, cvmi_stream_t stream);
+
+/* ---- scaled-dot-product attention, softmax over keys, one launch for all (batch, head) --------
+ * Element (b, h, t, d) of q lives at q + b*q_sb + h*q_sh + t*q_st + d (elements); same for k, v, o.
+ * Replaces: ultralytics Attention in C2PSA (YOLO.predict); Hiera MultiScaleAttention and the
+ * mask decoder's Attention (sam2_infer.py:226, :252).
+ * Window mode (win > 0): tokens of batch entry b are the win x win pixels of window
+ *   (b / (gw*gh*...)) of a [img][gh*win][gw*win] grid laid out NHWC with pixel stride *_st;
+ *   q_pool = 1 takes q as the 2x2 max-pool of the window's q tokens (Hiera q-pooling). */
+typedef struct cvmi_attn_desc {
+  const void* q; const void* k; const void* v; void* o;
+  long long q_sb, q_sh, q_st, k_sb, k_sh, k_st, v_sb, v_sh, v_st, o_sb, o_sh, o_st;
+  int B, heads, Nq, Nk, dqk, dv;
+  float scale;
+  int dtype;
+  int win, grid_h, grid_w;   /* window mode (0 = off): window side, image grid size in pixels */
+  int q_pool;                /* 1: q window is max-pooled 2x2 (Nq = (win/2)^2) */
+} cvmi_attn_desc;
+int cvmi_attention(const cvmi_attn_desc* d, cvmi_stream_t stream);
+
+/* ---- YOLO Detect decode: DFL expectation + dist2bbox + stride scale + class sigmoid -----------
+ * box[l]: [B,Hl,Wl,64] (ld box_ld), cls[l]: [B,Hl,Wl,nc] (ld cls_ld) for l = 0..2.
+ * pred: f32 [B, 4+nc, A], A = sum Hl*Wl (ultralytics layout: xywh then class scores). */
+int cvmi_detect_decode(const void* const* box, const int* box_ld, const void* const* cls,
+                       const int* cls_ld, const int* hs, const int* ws, const float* strides,
+                       int nlevels, int B, int nc, int dtype, float* pred, cvmi_stream_t stream);
+
+/* ---- ultralytics-semantics NMS on the decoded predictions -------------------------------------
+ * pred f32 [B, 4+nc, A].  Candidates: max class score > conf_thres; sorted by score desc (ties:
+ * lower anchor index first); per-class via +cls*max_wh; greedy suppress IoU > iou_thres; first
+ * max_det kept.  out_det f32 [B, max_det, 6] (x1,y1,x2,y2,conf,cls), out_idx i32 [B, max_det]
+ * (anchor index), out_count i32 [B].  workspace: >= cvmi_yolo_nms_workspace(B, A) bytes.
+ * Replaces ultralytics ops.non_max_suppression + torchvision.ops.nms (circuit_analyzer.py:268). */
+size_t cvmi_yolo_nms_workspace(int B, int A);
+int cvmi_yolo_nms(const float* pred, int B, int nc, int A, float conf_thres, float iou_thres,
+                  int max_det, float max_wh, float* out_det, int* out_idx, int* out_count,
+                  void* workspace, cvmi_stream_t stream);
+
+/* ---- letterbox pre-processing (ultralytics LetterBox + BGR flip + /255) -----------------------
+ * src u8 [H,W,3] -> dst [1? no: one image] NHWC dtype [out_h,out_w,3] at dst; resized region
+ * new_w x new_h placed at (left, top); pad value 114.  8-bit fixed-point bilinear as OpenCV. */
+int cvmi_letterbox(const uint8_t* src, int H, int W, void* dst, int out_h, int out_w, int new_h,
+                   int new_w, int top, int left, int dtype, cvmi_stream_t stream);
+
+/* ---- dtype conversion / layout helpers -------------------------------------------------------- */
+/* NCHW (f32 or f16) -> NHWC dtype */
+int cvmi_nchw_to_nhwc(const void* src, int src_dtype, void* dst, int dst_dtype, int dst_ld, int B,
+                      int C, int H, int W, cvmi_stream_t stream);
+/* NHWC dtype -> NCHW f32 */
+int cvmi_nhwc_to_nchw_f32(const void* src, int src_dtype, int src_ld, float* dst, int B, int C,
+                          int H, int W, cvmi_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CVMI355_H */

@@ -1,0 +1,248 @@
+"""GPU parity: every HIP op through the C ABI vs a CPU fp32 statement of the same op.
+
+Tolerances: f32 mode 1e-4 (exact-f32 MFMA, only the summation order differs from the CPU);
+f16 mode 2e-2 (fp16 storage of inputs/outputs, fp32 accumulate; inputs are pre-rounded to fp16
+so the oracle sees the same numbers).  NMS / integer outputs: bit-exact.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from circuitvision_amd import _lib
+from circuitvision_amd._lib import ACT_GELU, ACT_NONE, ACT_RELU, ACT_SILU, F16, F32
+from circuitvision_amd.engine import (Buf, PackedConv, PackedDW, Plan, make_attn_desc, op_attention, op_conv, op_dwconv,
+                                      op_sppf_pool)
+from helpers import TOL, from_view, quant, run, stream, to_buf
+
+pytestmark = pytest.mark.gpu
+DTYPES = [F16, F32]
+ACT_FN = {ACT_NONE: lambda x: x, ACT_SILU: F.silu, ACT_RELU: F.relu, ACT_GELU: F.gelu}
+
+
+def _conv_case(dtype, B, Cin, H, W, Cout, k, s, act, res=False, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    x = quant(torch.randn(B, Cin, H, W, generator=g), dtype)
+    w = quant(torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5, dtype)
+    b = torch.randn(Cout, generator=g)
+    ref = ACT_FN[act](F.conv2d(x, w, b, stride=s, padding=k // 2))
+    OH, OW = ref.shape[2:]
+    r = quant(torch.randn(B, Cout, OH, OW, generator=g), dtype) if res else None
+    if res:
+        ref = ref + r
+    plan = Plan(stream())
+    xb = to_buf(x, dtype)
+    yb = Buf(B, OH, OW, (Cout + 7) // 8 * 8, dtype, zero=True)
+    rb = to_buf(r, dtype, c_total=yb.C) if res else None
+    pc = PackedConv(w, b, dtype)
+    op_conv(plan, "t", pc, [(xb.view(), 0)], yb.view(0, Cout), stride=s, act=act,
+            res=rb.view(0, Cout) if res else None, scalar_gather=(Cin % 8 != 0))
+    run(plan)
+    torch.testing.assert_close(from_view(yb.view(0, Cout)), ref, **TOL[dtype])
+    if yb.C > Cout:                                   # padding lanes of the output buffer untouched
+        assert float(yb.t[..., Cout:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cfg", [
+    # B, Cin, H, W, Cout, k, s, act, res
+    (2, 16, 20, 24, 32, 1, 1, ACT_SILU, False),      # 1x1, N<=32 tile
+    (2, 32, 17, 13, 64, 3, 1, ACT_SILU, True),       # 3x3 + residual, odd spatial, N<=64 tile
+    (1, 64, 32, 32, 128, 3, 2, ACT_SILU, False),     # stride 2, N=128 tile
+    (3, 8, 9, 7, 16, 3, 1, ACT_NONE, False),         # tiny channels (K=72 -> Kpad 96)
+    (1, 128, 40, 40, 62, 1, 1, ACT_NONE, False),     # ragged Cout (class logits)
+    (2, 3, 32, 48, 16, 3, 2, ACT_SILU, False),       # 3-channel stem, scalar gather
+    (1, 256, 20, 20, 256, 3, 1, ACT_RELU, True),     # K=2304
+    (1, 144, 16, 16, 432, 1, 1, ACT_GELU, False),    # Hiera-like linear: several N tiles
+    (4, 32, 80, 80, 24, 3, 1, ACT_SILU, False),      # big-M path (BM=256 tile when M large)
+])
+def test_conv2d(dtype, cfg):
+    _conv_case(dtype, *cfg)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_conv2d_large_m_tiles(dtype):
+    _conv_case(dtype, 2, 16, 264, 256, 16, 3, 2, ACT_SILU)      # M = 2*132*128 -> BM=256 config for N<=32? (M>=131072 not reached) still covers tails
+    _conv_case(dtype, 8, 16, 128, 130, 32, 1, 1, ACT_SILU)      # M = 133120 >= 256*512 -> 256x32 tile
+    _conv_case(dtype, 8, 64, 100, 90, 64, 1, 1, ACT_SILU)       # M = 72000 >= 65536 -> 128x64 tile
+    _conv_case(dtype, 8, 64, 100, 90, 160, 1, 1, ACT_SILU)      # 128x128 tiles, ragged N tile
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_conv2d_two_sources_upsample(dtype):
+    """Upsample(2x nearest) + Concat + 1x1 conv in one launch, reading channel slices of wider buffers."""
+    g = torch.Generator().manual_seed(3)
+    B, H, W = 2, 12, 10
+    a = quant(torch.randn(B, 32, H // 2, W // 2, generator=g), dtype)     # half-res source
+    b = quant(torch.randn(B, 16, H, W, generator=g), dtype)
+    w = quant(torch.randn(40, 48, 1, 1, generator=g) / 7, dtype)
+    bias = torch.randn(40, generator=g)
+    ref = F.silu(F.conv2d(torch.cat((F.interpolate(a, scale_factor=2, mode="nearest"), b), 1), w, bias))
+    plan = Plan(stream())
+    ab = to_buf(a, dtype, c_total=48, c0=8)           # embedded at channel offset 8
+    bb = to_buf(b, dtype, c_total=32, c0=16)
+    yb = Buf(B, H, W, 64, dtype, zero=True)
+    op_conv(plan, "t", PackedConv(w, bias, dtype), [(ab.view(8, 32), 1), (bb.view(16, 16), 0)], yb.view(16, 40), act=ACT_SILU)
+    run(plan)
+    torch.testing.assert_close(from_view(yb.view(16, 40)), ref, **TOL[dtype])
+    assert float(yb.t[..., :16].abs().max()) == 0.0 and float(yb.t[..., 56:].abs().max()) == 0.0
+
+
+def test_conv2d_f16_in_f32_out():
+    g = torch.Generator().manual_seed(5)
+    x = quant(torch.randn(2, 64, 8, 8, generator=g), F16)
+    w = quant(torch.randn(96, 64, 1, 1, generator=g) / 8, F16)
+    b = torch.randn(96, generator=g)
+    r = torch.randn(2, 96, 8, 8, generator=g)
+    ref = F.conv2d(x, w, b) + r
+    plan = Plan(stream())
+    xb, rb = to_buf(x, F16), to_buf(r, F32)
+    yb = Buf(2, 8, 8, 96, F32, zero=True)
+    op_conv(plan, "t", PackedConv(w, b, F16), [(xb.view(), 0)], yb.view(), res=rb.view())
+    run(plan)
+    torch.testing.assert_close(from_view(yb.view()), ref, rtol=1e-3, atol=1e-3)
+
+
+def test_conv2d_rejects_bad_arguments():
+    lib = _lib.load()
+    d = _lib.ConvDesc()
+    assert lib.cvmi_conv2d(C.byref(d), None) != 0
+    assert b"null" in lib.cvmi_last_error()
+    x = Buf(1, 4, 4, 12, F16, zero=True)              # 12 channels: not a multiple of 8
+    y = Buf(1, 4, 4, 16, F16, zero=True)
+    pc = PackedConv(torch.zeros(16, 12, 1, 1), None, F16)
+    plan = Plan(stream())
+    op_conv(plan, "bad", pc, [(x.view(), 0)], y.view())
+    with pytest.raises(_lib.CvmiError, match="multiples"):
+        plan.run_eager()
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_dwconv3x3(dtype):
+    g = torch.Generator().manual_seed(1)
+    x = quant(torch.randn(2, 64, 13, 11, generator=g), dtype)
+    w = quant(torch.randn(64, 1, 3, 3, generator=g) / 3, dtype)
+    b = torch.randn(64, generator=g)
+    r = quant(torch.randn(2, 64, 13, 11, generator=g), dtype)
+    ref = F.silu(F.conv2d(x, w, b, padding=1, groups=64)) + r
+    plan = Plan(stream())
+    xb, rb = to_buf(x, dtype, c_total=80, c0=16), to_buf(r, dtype)
+    yb = Buf(2, 13, 11, 64, dtype, zero=True)
+    op_dwconv(plan, "t", PackedDW(w, b, dtype), xb.view(16, 64), yb.view(), act=ACT_SILU, res=rb.view())
+    run(plan)
+    torch.testing.assert_close(from_view(yb.view()), ref, **TOL[dtype])
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_sppf_pool(dtype):
+    g = torch.Generator().manual_seed(2)
+    x = quant(torch.randn(2, 32, 20, 12, generator=g), dtype)
+    y1 = F.max_pool2d(x, 5, 1, 2); y2 = F.max_pool2d(y1, 5, 1, 2); y3 = F.max_pool2d(y2, 5, 1, 2)
+    ref = torch.cat((x, y1, y2, y3), 1)
+    plan = Plan(stream())
+    buf = to_buf(x, dtype, c_total=128)
+    op_sppf_pool(plan, "t", buf, 32)
+    run(plan)
+    torch.testing.assert_close(from_view(buf.view()), ref, rtol=0, atol=0)
+
+
+def _attn_ref(q, k, v, scale):
+    return torch.softmax((q @ k.transpose(-1, -2)) * scale, -1) @ v
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape", [
+    # B, heads, Nq, Nk, dqk, dv
+    (2, 2, 400, 400, 32, 64),      # YOLO C2PSA
+    (3, 4, 64, 64, 72, 72),        # Hiera window, head_dim 72
+    (1, 8, 38, 300, 16, 16),       # decoder token->image (internal dim 128 / 8 heads)
+    (1, 8, 300, 38, 32, 32),       # decoder image->token
+    (1, 2, 130, 257, 72, 72),      # ragged q and key tiles
+    (5, 3, 16, 16, 72, 72),        # tiny windows, private K/V tiles
+])
+def test_attention(dtype, shape):
+    B, Hh, Nq, Nk, dqk, dv = shape
+    g = torch.Generator().manual_seed(11)
+    q = quant(torch.randn(B, Hh, Nq, dqk, generator=g), dtype)
+    k = quant(torch.randn(B, Hh, Nk, dqk, generator=g), dtype)
+    v = quant(torch.randn(B, Hh, Nk, dv, generator=g), dtype)
+    scale = dqk ** -0.5
+    ref = _attn_ref(q, k, v, scale)
+    # device layout: tokens x (heads * d), like a fused projection output
+    from circuitvision_amd.engine import TORCH_DTYPE
+    td = TORCH_DTYPE[dtype]
+    qd = q.permute(0, 2, 1, 3).reshape(B, Nq, Hh * dqk).to(td).cuda().contiguous()
+    kd = k.permute(0, 2, 1, 3).reshape(B, Nk, Hh * dqk).to(td).cuda().contiguous()
+    vd = v.permute(0, 2, 1, 3).reshape(B, Nk, Hh * dv).to(td).cuda().contiguous()
+    od = torch.zeros(B, Nq, Hh * dv, dtype=td, device="cuda")
+    desc = make_attn_desc(q=qd.data_ptr(), k=kd.data_ptr(), v=vd.data_ptr(), o=od.data_ptr(),
+                          q_sb=Nq * Hh * dqk, q_sh=dqk, q_st=Hh * dqk, k_sb=Nk * Hh * dqk, k_sh=dqk, k_st=Hh * dqk,
+                          v_sb=Nk * Hh * dv, v_sh=dv, v_st=Hh * dv, o_sb=Nq * Hh * dv, o_sh=dv, o_st=Hh * dv,
+                          B=B, heads=Hh, Nq=Nq, Nk=Nk, dqk=dqk, dv=dv, scale=scale, dtype=dtype,
+                          win=0, grid_h=0, grid_w=0, q_pool=0)
+    plan = Plan(stream())
+    op_attention(plan, "t", desc, (qd, kd, vd, od))
+    run(plan)
+    out = od.float().cpu().view(B, Nq, Hh, dv).permute(0, 2, 1, 3)
+    tol = dict(rtol=1e-2, atol=5e-3) if dtype == F16 else dict(rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(out, ref, **tol)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("q_pool", [0, 1])
+def test_attention_window_mode(dtype, q_pool):
+    """Hiera windowed attention straight off the NHWC token grid (+ 2x2 q max-pool)."""
+    from circuitvision_amd.engine import TORCH_DTYPE
+    td = TORCH_DTYPE[dtype]
+    g = torch.Generator().manual_seed(13)
+    imgs, gh, gw, win, heads, hd = 2, 16, 24, 8, 2, 72
+    C_ = heads * hd
+    qkv = quant(torch.randn(imgs, gh, gw, 3 * C_, generator=g), dtype)
+    # reference: partition windows
+    def part(t):                                                 # [imgs,gh,gw,C] -> [imgs*nwin, win*win, heads, hd]
+        t = t.view(imgs, gh // win, win, gw // win, win, heads, hd).permute(0, 1, 3, 2, 4, 5, 6)
+        return t.reshape(-1, win * win, heads, hd)
+    q, k, v = (part(qkv[..., i * C_:(i + 1) * C_]) for i in range(3))
+    if q_pool:
+        qq = q.view(-1, win, win, heads * hd).permute(0, 3, 1, 2)
+        qq = F.max_pool2d(qq, 2, 2).permute(0, 2, 3, 1)
+        q = qq.reshape(-1, (win // 2) ** 2, heads, hd)
+    scale = hd ** -0.5
+    ref = _attn_ref(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2), scale).transpose(1, 2)   # [nw, Nq, heads, hd]
+    ow = win // 2 if q_pool else win
+    ogh, ogw = (gh // 2, gw // 2) if q_pool else (gh, gw)
+    ref = ref.reshape(imgs, gh // win, gw // win, ow, ow, C_).permute(0, 1, 3, 2, 4, 5).reshape(imgs, ogh, ogw, C_)
+    qkv_d = qkv.to(td).cuda().contiguous()
+    od = torch.zeros(imgs, ogh, ogw, C_, dtype=td, device="cuda")
+    es = qkv_d.element_size()
+    nwin = imgs * (gh // win) * (gw // win)
+    desc = make_attn_desc(q=qkv_d.data_ptr(), k=qkv_d.data_ptr() + C_ * es, v=qkv_d.data_ptr() + 2 * C_ * es, o=od.data_ptr(),
+                          q_sb=0, q_sh=hd, q_st=3 * C_, k_sb=0, k_sh=hd, k_st=3 * C_, v_sb=0, v_sh=hd, v_st=3 * C_,
+                          o_sb=0, o_sh=hd, o_st=C_, B=nwin, heads=heads, Nq=(ow * ow), Nk=win * win, dqk=hd, dv=hd,
+                          scale=scale, dtype=dtype, win=win, grid_h=gh, grid_w=gw, q_pool=q_pool)
+    plan = Plan(stream())
+    op_attention(plan, "t", desc, (qkv_d, od))
+    run(plan)
+    tol = dict(rtol=1e-2, atol=5e-3) if dtype == F16 else dict(rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(od.float().cpu(), ref, **tol)
+
+
+def test_graph_capture_replays_identically():
+    g = torch.Generator().manual_seed(9)
+    x = quant(torch.randn(2, 32, 16, 16, generator=g), F16)
+    w = quant(torch.randn(32, 32, 3, 3, generator=g) / 17, F16)
+    plan = Plan(stream())
+    xb = to_buf(x, F16)
+    y1, y2 = Buf(2, 16, 16, 32, F16, zero=True), Buf(2, 16, 16, 32, F16, zero=True)
+    pc = PackedConv(w, None, F16)
+    op_conv(plan, "a", pc, [(xb.view(), 0)], y1.view(), act=ACT_SILU)
+    op_conv(plan, "b", pc, [(y1.view(), 0)], y2.view(), act=ACT_SILU, res=xb.view())
+    run(plan)
+    eager = y2.t.clone()
+    y1.t.zero_(); y2.t.zero_()
+    torch.cuda.synchronize()
+    plan.run(); plan.run()
+    plan.stream.synchronize()
+    assert torch.equal(eager, y2.t)

@@ -1,0 +1,138 @@
+"""CPU suite: the oracle against the reference's golden vectors / known-answer anchors, host logic,
+and the C-ABI library's symbol table (no GPU compute)."""
+import ctypes
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import nms as onms
+from oracle import preprocess as opre
+from oracle.yolo11 import YOLO11, count_params
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+# ---- stage-2 NMS pinned by the reference's own functions (src/utils.py:297-361) ------------------
+def test_stage2_nms_matches_reference_golden():
+    with open(os.path.join(GOLD, "nms_stage2.json")) as f:
+        gold = json.load(f)
+    assert len(gold["cases"]) >= 18
+    for case in gold["cases"]:
+        kept = onms.nms_by_confidence([dict(b) for b in case["boxes"]], case["iou_threshold"])
+        assert [b["persistent_uid"] for b in kept] == case["kept_by_confidence"], case["name"]
+        kept = onms.nms_by_area([dict(b) for b in case["boxes"]], case["iou_threshold"])
+        assert [b["persistent_uid"] for b in kept] == case["kept_by_area"], case["name"]
+    for pr in gold["iou_pairs"]:
+        assert onms.calculate_iou(pr["a"], pr["b"]) == pr["iou"]
+
+
+def test_product_stage2_nms_matches_reference_golden():
+    from circuitvision_amd.detector import calculate_iou, non_max_suppression_by_confidence
+    with open(os.path.join(GOLD, "nms_stage2.json")) as f:
+        gold = json.load(f)
+    for case in gold["cases"]:
+        kept = non_max_suppression_by_confidence([dict(b) for b in case["boxes"]], case["iou_threshold"])
+        assert [b["persistent_uid"] for b in kept] == case["kept_by_confidence"], case["name"]
+    for pr in gold["iou_pairs"]:
+        assert calculate_iou(pr["a"], pr["b"]) == pr["iou"]
+
+
+# ---- YOLO11 known-answer anchors -------------------------------------------------
+@pytest.mark.parametrize("scale,params", [("n", 2_624_080), ("l", 25_372_160)])
+def test_yolo11_param_counts(scale, params):
+    assert count_params(YOLO11(scale, 80)) == params
+
+
+def test_yolo11_output_shape_and_decode_ranges():
+    m = YOLO11("n", 62).eval()
+    with torch.no_grad():
+        y = m(torch.rand(1, 3, 96, 128))
+    assert y.shape == (1, 66, 12 * 16 + 6 * 8 + 3 * 4)
+    assert float(y[:, 4:].min()) >= 0 and float(y[:, 4:].max()) <= 1
+
+
+def test_product_synthetic_checkpoint_loads_strictly_into_oracle():
+    """Two independent statements of the architecture (product graph walker, oracle nn.Module) must
+    agree on every parameter name and shape."""
+    from circuitvision_amd._lib import F32
+    from circuitvision_amd.yolo11 import SyntheticParams, Yolo11Weights
+    for scale in ("n", "l"):
+        p = SyntheticParams(seed=1, nc=62)
+        wt = Yolo11Weights(scale, 62, p, F32, device="cpu")
+        m = YOLO11(scale, 62)
+        m.load_state_dict(p.state_dict(), strict=True)
+        n_packed = sum(pc.param_bytes for pc in wt.packed.values()) // 4
+        n_conv = sum(v.numel() for k, v in p.state_dict().items() if k.endswith("conv.weight") or re.search(r"cv[23]\.\d\.2\.weight$", k))
+        assert n_packed == n_conv - 16        # everything but the DFL's constant arange(16) conv
+
+
+# ---- ultralytics-semantics NMS restatement: self-consistency properties ---------------------------
+def test_yolo_nms_properties():
+    import sys
+    sys.path.insert(0, os.path.dirname(__file__))
+    from synth import nms_stress_pred
+    pred = nms_stress_pred(2, 20, (320, 320), seed=7)
+    out, idx = onms.yolo_nms(pred, return_indices=True)
+    for b, det in enumerate(out):
+        assert det.shape[0] <= 300 and det.shape[0] > 0
+        assert bool((det[:-1, 4] >= det[1:, 4]).all())              # sorted by confidence
+        assert bool((det[:, 4] > 0.25).all())
+        # idempotence: NMS of the survivors keeps all of them
+        keep = onms.torchvision_nms(det[:, :4] + det[:, 5:6] * 7680, det[:, 4], 0.7)
+        assert keep.numel() == det.shape[0]
+        # the reported anchor reproduces the box
+        a = idx[b]
+        cx, cy, w, h = pred[b, 0, a], pred[b, 1, a], pred[b, 2, a], pred[b, 3, a]
+        assert torch.equal(det[:, 0], cx - w / 2) and torch.equal(det[:, 3], cy + h / 2)
+
+
+def test_scale_boxes_roundtrip():
+    boxes = torch.tensor([[10.0, 20.0, 200.0, 300.0]])
+    out = onms.scale_boxes((384, 640), boxes, (720, 1280))
+    assert torch.allclose(out, torch.tensor([[20.0, 16.0, 400.0, 576.0]]))
+
+
+# ---- letterbox restatement -------------------------------------------------------------------------
+def test_letterbox_geometry_and_identity():
+    assert opre.letterbox_geometry(720, 1280) == (640, 360, 12, 12, 0, 0)
+    assert opre.letterbox_geometry(640, 640) == (640, 640, 0, 0, 0, 0)
+    from circuitvision_amd.detector import letterbox_geometry
+    for hw in ((720, 1280), (493, 712), (33, 900), (1000, 1000)):
+        assert letterbox_geometry(*hw) == opre.letterbox_geometry(*hw)
+    img = np.arange(64 * 64 * 3, dtype=np.uint8).reshape(64, 64, 3)
+    assert np.array_equal(opre.resize_linear_u8(img, 64, 64), img)
+    flat = np.full((50, 70, 3), 77, np.uint8)
+    assert np.all(opre.resize_linear_u8(flat, 31, 23) == 77)       # constants survive the fixed-point path
+    x = opre.yolo_preprocess(np.full((720, 1280, 3), 255, np.uint8))
+    assert x.shape == (1, 3, 384, 640)
+    assert x[0, 0, 0, 0] == np.float32(114 / 255) and x[0, 0, 100, 100] == 1.0
+
+
+# ---- C ABI: the library loads and exports every symbol the header declares ------------------------
+def test_library_exports_every_declared_symbol():
+    from circuitvision_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "cvmi355.h")).read()
+    declared = set(re.findall(r"\b(cvmi_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"cvmi_conv_desc", "cvmi_attn_desc"}
+    assert declared, "no declarations parsed"
+    if not os.path.exists(_lib.LIB_PATH):
+        pytest.skip("libcvmi355.so not built (python -c 'import __graft_entry__ as g; g.build()')")
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in cvmi355.h but not exported"
+    assert set(_lib.SIGNATURES) == declared
+    assert lib.cvmi_version() >= 100
+
+
+def test_product_fails_loudly_without_gpu():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from circuitvision_amd import CvmiError
+    from circuitvision_amd.detector import YOLO
+    with pytest.raises(CvmiError, match="no CPU fallback"):
+        YOLO("synthetic:n:62")

@@ -1,0 +1,183 @@
+"""GPU parity of the detector path: decode, NMS (bit-exact), letterbox (bit-exact), whole YOLO11
+forward vs the CPU fp32 oracle, and the `YOLO.predict` boundary."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from circuitvision_amd import _lib
+from circuitvision_amd._lib import F16, F32
+from circuitvision_amd.detector import YOLO, letterbox_geometry
+from circuitvision_amd.engine import TORCH_DTYPE
+from circuitvision_amd.yolo11 import SyntheticParams, Yolo11Plan, Yolo11Weights
+from oracle import nms as onms
+from oracle import preprocess as opre
+from oracle.yolo11 import YOLO11
+from synth import circuit_image, nms_stress_pred
+
+pytestmark = pytest.mark.gpu
+
+
+def _gpu_nms(pred, conf=0.25, iou=0.7, max_det=300):
+    lib = _lib.load()
+    B, no, A = pred.shape
+    nc = no - 4
+    p = pred.cuda().contiguous()
+    det = torch.zeros(B, max_det, 6, device="cuda")
+    idx = torch.zeros(B, max_det, dtype=torch.int32, device="cuda")
+    cnt = torch.zeros(B, dtype=torch.int32, device="cuda")
+    ws = torch.empty(lib.cvmi_yolo_nms_workspace(B, A), dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    _lib.check(lib.cvmi_yolo_nms(p.data_ptr(), B, nc, A, conf, iou, max_det, 7680.0, det.data_ptr(), idx.data_ptr(),
+                                 cnt.data_ptr(), ws.data_ptr(), None), "nms")
+    torch.cuda.synchronize()
+    return det.cpu(), idx.cpu(), cnt.cpu()
+
+
+@pytest.mark.parametrize("case", ["stress", "dense", "empty", "ties", "full_size"])
+def test_nms_bit_exact(case):
+    if case == "stress":
+        pred = nms_stress_pred(4, 62, (640, 640), seed=1)
+    elif case == "dense":                     # every anchor is a candidate, > max_det survivors
+        pred = nms_stress_pred(2, 10, (320, 320), seed=2, frac_logit=1.0)
+    elif case == "empty":
+        pred = nms_stress_pred(2, 5, (160, 160), seed=3, frac_logit=-12.0)
+    elif case == "ties":                      # equal scores: order must fall back to the anchor index
+        pred = nms_stress_pred(2, 8, (320, 320), seed=4)
+        pred[:, 4:] = (pred[:, 4:] * 8).round() / 8
+    else:
+        pred = nms_stress_pred(32, 62, (640, 640), seed=5)
+    ref, ref_idx = onms.yolo_nms(pred, 0.25, 0.7, 300, return_indices=True)
+    det, idx, cnt = _gpu_nms(pred)
+    for b in range(pred.shape[0]):
+        n = int(cnt[b])
+        assert n == ref[b].shape[0], (case, b, n, ref[b].shape[0])
+        assert torch.equal(idx[b, :n].long(), ref_idx[b]), (case, b)
+        assert torch.equal(det[b, :n], ref[b]), (case, b)
+    if case == "dense":
+        assert int(cnt.max()) == 300
+    if case == "empty":
+        assert int(cnt.max()) == 0
+
+
+@pytest.mark.parametrize("dtype", [F16, F32])
+def test_detect_decode(dtype):
+    from oracle.yolo11 import Detect
+    lib = _lib.load()
+    nc, B = 62, 2
+    head = Detect(nc, (64, 128, 256)).eval()
+    g = torch.Generator().manual_seed(0)
+    td = TORCH_DTYPE[dtype]
+    raw, box_d, cls_d = [], [], []
+    for (h, w) in ((12, 20), (6, 10), (3, 5)):
+        x = (torch.randn(B, 64 + nc, h, w, generator=g) * 2).to(td).float()
+        raw.append(x)
+        box_d.append(x[:, :64].permute(0, 2, 3, 1).contiguous().to(td).cuda())
+        cl = torch.zeros(B, h, w, 64, dtype=td)
+        cl[..., :nc] = x[:, 64:].permute(0, 2, 3, 1).to(td)
+        cls_d.append(cl.cuda())
+    ref = head.decode(raw)
+    A = ref.shape[2]
+    pred = torch.zeros(B, 4 + nc, A, device="cuda")
+    nl = 3
+    box_p = (C.c_void_p * nl)(*[t.data_ptr() for t in box_d])
+    cls_p = (C.c_void_p * nl)(*[t.data_ptr() for t in cls_d])
+    ld64 = (C.c_int * nl)(64, 64, 64)
+    hs = (C.c_int * nl)(12, 6, 3)
+    ws = (C.c_int * nl)(20, 10, 5)
+    st = (C.c_float * nl)(8.0, 16.0, 32.0)
+    torch.cuda.synchronize()
+    _lib.check(lib.cvmi_detect_decode(box_p, ld64, cls_p, ld64, hs, ws, st, nl, B, nc, dtype, pred.data_ptr(), None), "decode")
+    torch.cuda.synchronize()
+    tol = dict(rtol=2e-3, atol=2e-3) if dtype == F16 else dict(rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(pred.cpu(), ref, **tol)
+
+
+@pytest.mark.parametrize("hw", [(720, 1280), (493, 712), (640, 640), (300, 200), (1000, 37)])
+def test_letterbox_bit_exact(hw):
+    lib = _lib.load()
+    img = circuit_image(*hw, seed=hw[0])
+    ref = opre.yolo_preprocess(img)[0]                       # f32 [3, h, w]
+    nw, nh, top, bottom, left, right = letterbox_geometry(*hw)
+    assert (nw, nh, top, bottom, left, right) == opre.letterbox_geometry(*hw)
+    H, W = nh + top + bottom, nw + left + right
+    src = torch.from_numpy(img).cuda()
+    dst = torch.zeros(H, W, 3, device="cuda")
+    torch.cuda.synchronize()
+    _lib.check(lib.cvmi_letterbox(src.data_ptr(), hw[0], hw[1], dst.data_ptr(), H, W, nh, nw, top, left, F32, None), "letterbox")
+    torch.cuda.synchronize()
+    assert torch.equal(dst.cpu().permute(2, 0, 1), torch.from_numpy(ref))
+
+
+def _oracle_from(params, scale, nc):
+    m = YOLO11(scale, nc).eval()
+    sd = {k: v for k, v in params.state_dict().items()}
+    missing, unexpected = m.load_state_dict(sd, strict=True)
+    return m
+
+
+@pytest.mark.parametrize("dtype,scale", [(F32, "n"), (F16, "n"), (F32, "l")])
+def test_yolo11_forward_matches_oracle(dtype, scale):
+    nc, B, H, W = 62, 2, 96, 160
+    params = SyntheticParams(seed=3, nc=nc)
+    wt = Yolo11Weights(scale, nc, params, dtype)
+    oracle = _oracle_from(params, scale, nc)
+    g = torch.Generator().manual_seed(0)
+    x = torch.rand(B, 3, H, W, generator=g).to(TORCH_DTYPE[dtype]).float()
+    with torch.no_grad():
+        ref, raw, feats = oracle(x, return_feats=True)
+    plan = Yolo11Plan(wt, B, H, W, torch.cuda.Stream())
+    plan.x_in.t.copy_(x.permute(0, 2, 3, 1).to(TORCH_DTYPE[dtype]))
+    torch.cuda.synchronize()
+    plan.plan.run_eager()
+    torch.cuda.synchronize()
+    got = plan.pred.cpu()
+    # neck features first (localises a failure), then the decoded predictions
+    for name, v, r in zip(("h16", "h19", "h22"), plan.feats, feats):
+        gv = v.tensor().float().permute(0, 3, 1, 2).cpu()
+        tol = dict(rtol=1e-3, atol=1e-3) if dtype == F32 else dict(rtol=5e-2, atol=5e-2)
+        torch.testing.assert_close(gv, r, **tol, msg=lambda m: f"{name}: {m}")
+    if dtype == F32:
+        # north_star tolerance: 1e-3 on logits/scores; boxes in pixels
+        torch.testing.assert_close(got[:, 4:], ref[:, 4:], rtol=0, atol=1e-3)
+        torch.testing.assert_close(got[:, :4], ref[:, :4], rtol=1e-4, atol=1e-2)
+    else:
+        torch.testing.assert_close(got[:, 4:], ref[:, 4:], rtol=0, atol=2e-2)
+        torch.testing.assert_close(got[:, :4], ref[:, :4], rtol=2e-2, atol=1.0)
+    # the GPU NMS on the GPU predictions == the oracle NMS on the same tensor (bit-exact)
+    ref_det, ref_idx = onms.yolo_nms(got, 0.25, 0.7, 300, return_indices=True)
+    cnt = plan.det_count.cpu()
+    for b in range(B):
+        n = int(cnt[b])
+        assert n == ref_det[b].shape[0]
+        assert torch.equal(plan.det_idx[b, :n].cpu().long(), ref_idx[b])
+        assert torch.equal(plan.det[b, :n].cpu(), ref_det[b])
+
+
+def test_predict_boundary_matches_oracle_pipeline():
+    """`YOLO(path).predict(img)[0].boxes` as circuit_analyzer.py:268-287 consumes it, f32 mode,
+    vs oracle letterbox -> oracle network -> oracle NMS -> scale_boxes -> round -> stage-2 NMS."""
+    from circuitvision_amd.detector import non_max_suppression_by_confidence
+    det = YOLO("synthetic:n:62:3", dtype="f32")
+    oracle = _oracle_from(det.params, "n", 62)
+    img = circuit_image(360, 500, seed=7)
+    r = det.predict(img, verbose=False)[0]
+    cls = r.boxes.cls.cpu().numpy().tolist()
+    conf = r.boxes.conf.cpu().numpy().tolist()
+    xyxy = r.boxes.xyxy.cpu().numpy().tolist()
+    assert all(conf[i] >= conf[i + 1] for i in range(len(conf) - 1))
+    x = torch.from_numpy(opre.yolo_preprocess(img))
+    with torch.no_grad():
+        pred = oracle(x)
+    ref = onms.yolo_nms(pred, 0.25, 0.7, 300)[0]
+    ref[:, :4] = onms.scale_boxes(x.shape[2:], ref[:, :4], img.shape[:2])
+    assert len(cls) == ref.shape[0]
+    assert cls == ref[:, 5].tolist()
+    np.testing.assert_allclose(conf, ref[:, 4].numpy(), atol=1e-3)
+    np.testing.assert_allclose(np.asarray(xyxy).reshape(-1, 4), ref[:, :4].numpy().reshape(-1, 4), atol=0.05)
+    got_d = onms.boxes_to_dicts(xyxy, conf, cls, r.names)
+    ref_d = onms.boxes_to_dicts(ref[:, :4].tolist(), ref[:, 4].tolist(), ref[:, 5].tolist(), r.names)
+    a = [b["persistent_uid"] for b in non_max_suppression_by_confidence(got_d, 0.6)]
+    b = [b["persistent_uid"] for b in onms.nms_by_confidence(ref_d, 0.6)]
+    assert a == b
