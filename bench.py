@@ -1,0 +1,175 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the detector hot path on N MI355X (one process per GPU).
+
+Workload (BASELINE.json configs[1]): YOLO11-n, 640x640, batch 32 per GPU, fp16 storage / fp32
+accumulate, synthetic letterboxed circuit images already resident in HBM (NHWC fp16), seeded random
+weights (nc = 62).  A "step" = network forward + Detect decode + NMS for one batch, replayed as one
+captured HIP graph.  N > 1: every rank runs its own batch shard (weak scaling), weights are
+broadcast once from rank 0 over RCCL; there is no per-step collective.
+
+Prints ONE JSON line (rank 0).  Extra objects:
+  roofline     conv stack (all network launches of one step) against the HBM roof; `achieved` =
+               SURVEY.md 8(d) algorithmic bytes (81.8 MB fp16 activations / image + 5.2 MB weights
+               per batch) / the summed duration of those launches, measured with event pairs on the
+               engine's stream in un-captured passes.
+  cpu_baseline the CPU fp32 oracle (oracle/yolo11.py + oracle/nms.py) on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+ALGO_ACT_MB_PER_IMAGE = 81.8     # 40.9 M fp16 activation elements moved / image
+ALGO_WEIGHT_MB = 5.2             # 2.59 M params fp16, once per batch
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=32, help="images per GPU per step")
+    ap.add_argument("--scale", default="n")
+    ap.add_argument("--dtype", default="f16")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile-pass", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(scale, nc, state_dict, seconds=12.0):
+    """Oracle timed on the host cores on a bounded sample: batches of 4 synthetic 640x640 images,
+    forward + NMS, until ~`seconds` of CPU work."""
+    import torch
+    from oracle import nms as onms
+    from oracle.yolo11 import YOLO11
+    m = YOLO11(scale, nc).eval()
+    m.load_state_dict(state_dict, strict=True)
+    x = torch.rand(4, 3, 640, 640, generator=torch.Generator().manual_seed(0))
+    with torch.no_grad():
+        onms.yolo_nms(m(x[:1]))                       # warm-up
+        n, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < seconds:
+            onms.yolo_nms(m(x))
+            n += x.shape[0]
+        dt = time.perf_counter() - t0
+    return {"value": round(n / dt, 3), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n} synthetic 640x640 images (batches of 4), YOLO11-{scale} fp32 oracle forward + NMS, {dt:.1f} s"}
+
+
+def main():
+    a = parse()
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus and world > 1:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from circuitvision_amd import _lib
+    from circuitvision_amd.distributed import broadcast_packed
+    from circuitvision_amd.yolo11 import SyntheticParams, Yolo11Plan, Yolo11Weights
+    from synth import circuit_image
+
+    nc = 62
+    dtype = {"f16": _lib.F16, "f32": _lib.F32}[a.dtype]
+    params = SyntheticParams(seed=0, nc=nc)
+    wt = Yolo11Weights(a.scale, nc, params, dtype, device=f"cuda:{local_rank}")
+    if world > 1:
+        broadcast_packed(wt.packed, src=0)            # one-time RCCL broadcast of the packed weights
+    stream = torch.cuda.Stream()
+    yp = Yolo11Plan(wt, a.batch, 640, 640, stream)
+
+    # synthetic circuit images of this rank's shard, letterboxed on the GPU into the plan's input
+    lib = _lib.load()
+    for b in range(a.batch):
+        img = torch.from_numpy(circuit_image(640, 640, seed=20250704 + rank * a.batch + b)).cuda()
+        _lib.check(lib.cvmi_letterbox(img.data_ptr(), 640, 640, yp.x_in.t[b].data_ptr(), 640, 640, 640, 640, 0, 0, dtype,
+                                      stream.cuda_stream), "letterbox")
+    stream.synchronize()
+
+    plan = yp.plan
+    plan.capture()
+    for _ in range(a.warmup):
+        plan.run()
+    stream.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        plan.run()
+    stream.synchronize()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        dist.barrier()
+    ms_per_step = dt / a.steps * 1e3
+    value = world * a.batch * a.steps / dt
+
+    # ---- per-launch timing pass (un-captured, event pairs on the engine stream) ------------------
+    roofline, breakdown = None, None
+    if rank == 0 and not a.no_profile_pass:
+        acc = {}
+        reps = 5
+        plan.timed_eager()
+        for _ in range(reps):
+            for label, kind, ms, b, f in plan.timed_eager():
+                k = acc.setdefault(kind, [0.0, 0, 0, 0])
+                k[0] += ms / reps; k[1] += 1; k[2] += b / reps; k[3] += f / reps
+        stack_kinds = ("stem", "conv", "head", "dwconv", "pool", "attention")
+        stack_ms = sum(acc[k][0] for k in stack_kinds if k in acc)
+        algo_bytes = (a.batch * ALGO_ACT_MB_PER_IMAGE + ALGO_WEIGHT_MB) * 1e6 if (a.scale == "n" and a.dtype == "f16") \
+            else float(sum(acc[k][2] for k in stack_kinds if k in acc)) + wt.param_bytes
+        achieved = algo_bytes / (stack_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("hbm_bytes_per_step")
+            except Exception:
+                traffic = None
+        roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                    "kernel": "conv stack (igemm_kernel + dwconv/pool/attention) per step",
+                    "kernel_ms_per_step": round(stack_ms, 4), "algorithmic_bytes_per_step": int(algo_bytes)}
+        breakdown = {k: {"ms": round(v[0], 4), "launches": v[1] // reps if v[1] >= reps else v[1],
+                         "plan_bytes": int(v[2]), "gflop": round(v[3] / 1e9, 3)} for k, v in acc.items()}
+
+    cpu = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        cpu = cpu_baseline(a.scale, nc, params.state_dict())
+
+    if rank == 0:
+        counts = yp.det_count.cpu().tolist()
+        line = {
+            "metric": "circuit images/sec (YOLOv11 640² + SAM2.1-L 1024²) at 1/2/4/8 MI355X",
+            "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f16" if dtype == _lib.F16 else "f32", "data": "synthetic",
+            "config": {"workload": f"YOLO11-{a.scale} 640x640 batch={a.batch}/GPU fp16 forward+decode+NMS (BASELINE configs[1])",
+                       "images_per_step": world * a.batch, "nc": nc, "weights": "seeded random",
+                       "mean_detections_per_image": round(sum(counts) / len(counts), 1)},
+            "roofline": roofline, "cpu_baseline": cpu, "breakdown": breakdown,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -76,6 +76,9 @@ def load():
         raise CvmiError(
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(or `make -C circuitvision_amd/csrc`).  There is no CPU fallback.")
+    # torch first: it carries its own HIP runtime (libamdhip64) and the process must hold exactly one;
+    # loading ours first would bring in /opt/rocm's copy beside torch's ("no ROCm-capable device").
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError here = header / library mismatch
