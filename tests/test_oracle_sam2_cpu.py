@@ -1,0 +1,190 @@
+"""CPU suite for the SAM 2 oracle: pinned against the reference's own code (golden vectors) where
+the reference owns the code, and cross-checked against the independent `transformers` SAM2
+implementation for the un-vendored network (build container only; skipped when absent)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import sam2_model as osam
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_refinement_head_matches_reference_golden():
+    g = np.load(os.path.join(GOLD, "refinement.npz"))
+    m = osam.MultiKernelRefinement((3, 5, 7, 11), 4).eval()
+    assert sum(p.numel() for p in m.parameters()) == 849
+    sd = {k.replace("__", "."): torch.from_numpy(g[k]) for k in g.files if k not in ("x1", "y1", "x2", "y2")}
+    m.load_state_dict(sd, strict=True)
+    with torch.no_grad():
+        for xk, yk in (("x1", "y1"), ("x2", "y2")):
+            torch.testing.assert_close(m(torch.from_numpy(g[xk])), torch.from_numpy(g[yk]), rtol=1e-5, atol=1e-5)
+
+
+def test_postprocess_matches_reference_golden():
+    g = np.load(os.path.join(GOLD, "postprocess.npz"))
+    masks = torch.from_numpy(g["masks"])
+    for k in g.files:
+        if k.startswith("out_"):
+            h, w = map(int, k[4:].split("x"))
+            assert torch.equal(osam.postprocess_masks(masks, (h, w)), torch.from_numpy(g[k]))
+
+
+def test_dense_prompt_product_matches_reference_golden():
+    g = np.load(os.path.join(GOLD, "dense_prompt.npz"))
+    dense = (torch.from_numpy(g["e1"]) @ torch.from_numpy(g["e2"])).view(1, 256, 64, 64)
+    assert torch.equal(dense[:, ::4, ::4, ::4], torch.from_numpy(g["dense_sub"]))
+
+
+def test_hiera_l_known_answer_param_counts():
+    core = osam.SAM2Core(osam.HIERA_L, lora=False)
+    n = lambda m: sum(p.numel() for p in m.parameters())
+    assert n(core.image_encoder.trunk) == 212_149_296        # 212.1 M
+    assert round(n(core.image_encoder.neck) / 1e6, 2) == 0.55
+    assert round(n(core.sam_mask_decoder) / 1e6, 2) == 4.22
+    blocks = core.image_encoder.trunk.blocks
+    assert [i for i, b in enumerate(blocks) if b.q_stride] == [2, 8, 44]
+    assert [i for i, b in enumerate(blocks) if b.window == 0] == [23, 33, 43]
+    assert [blocks[i].window for i in (0, 2, 3, 8, 9, 44, 45)] == [8, 8, 4, 4, 16, 16, 8]
+
+
+def test_lora_targets_match_reference_list():
+    """36 LoRA-wrapped modules, named as circuit_analyzer.py:156-199 lists them."""
+    core = osam.SAM2Core(osam.HIERA_L, lora=True)
+    names = sorted(k[:-len(".lora_A.default.weight")] for k in core.state_dict() if k.endswith(".lora_A.default.weight"))
+    assert len(names) == 36
+    assert "image_encoder.trunk.blocks.44.proj" in names and "image_encoder.neck.convs.3.conv" in names
+    assert "sam_mask_decoder.transformer.layers.1.cross_attn_image_to_token.v_proj" in names
+    assert "sam_mask_decoder.transformer.layers.0.cross_attn_image_to_token.out_proj" not in names
+    assert "sam_mask_decoder.iou_prediction_head.layers.2" in names
+
+
+def _hf_models(cfg_small):
+    tr = pytest.importorskip("transformers")
+    from transformers.models.sam2 import configuration_sam2 as C
+    from transformers.models.sam2 import modeling_sam2 as M
+    return C, M
+
+
+def _map_trunk(sd):
+    out = {}
+    for k, v in sd.items():
+        k2 = (k.replace("patch_embed.proj.", "patch_embed.projection.").replace(".norm1.", ".layer_norm1.")
+               .replace(".norm2.", ".layer_norm2.").replace(".mlp.layers.0.", ".mlp.proj_in.").replace(".mlp.layers.1.", ".mlp.proj_out."))
+        out[k2] = v
+    return out
+
+
+def test_trunk_and_neck_match_independent_implementation():
+    C, M = _hf_models(True)
+    hiera = dict(embed_dim=16, num_heads=1, stages=(1, 2, 3, 2), global_att_blocks=(4, 5), window_spec=(8, 4, 16, 8))
+    trunk = osam.randomize_(osam.Hiera(**hiera), seed=1, std=0.2).eval()
+    neck = osam.randomize_(osam.FpnNeck(trunk.channel_list[::-1], 32, (2, 3)), seed=2, std=0.2).eval()
+    bcfg = C.Sam2HieraDetConfig(hidden_size=16, num_attention_heads=1, blocks_per_stage=[1, 2, 3, 2],
+                                embed_dim_per_stage=[16, 32, 64, 128], num_attention_heads_per_stage=[1, 2, 4, 8],
+                                window_size_per_stage=[8, 4, 16, 8], global_attention_blocks=[4, 5], image_size=[256, 256])
+    vcfg = C.Sam2VisionConfig(backbone_config=bcfg, backbone_channel_list=[128, 64, 32, 16], fpn_hidden_size=32,
+                              fpn_top_down_levels=[2, 3], num_feature_levels=3)
+    hf = M.Sam2VisionModel(vcfg).eval()
+    hf.backbone.load_state_dict(_map_trunk(trunk.state_dict()), strict=True)
+    hf.neck.load_state_dict({k.replace(".conv.", "."): v for k, v in neck.state_dict().items()}, strict=True)
+    x = torch.randn(2, 3, 256, 256, generator=torch.Generator().manual_seed(0))
+    with torch.no_grad():
+        mine = neck(trunk(x))
+        ref = hf(x)
+    # HF returns fpn states deepest-first, scalp already applied
+    ref_fpn = list(ref.fpn_hidden_states)
+    assert len(ref_fpn) == 3
+    for a, b in zip(mine[:3], ref_fpn[::-1] if ref_fpn[0].shape[-1] < ref_fpn[-1].shape[-1] else ref_fpn):
+        torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-4)
+
+
+def test_hiera_tiny_padding_path_matches_independent_implementation():
+    """window 14 on a 64-grid does not divide: the pad / un-pad branch (Hiera-T, BASELINE config 1)."""
+    C, M = _hf_models(True)
+    hiera = dict(embed_dim=16, num_heads=1, stages=(1, 1, 2, 1), global_att_blocks=(3,), window_spec=(8, 4, 14, 7))
+    trunk = osam.randomize_(osam.Hiera(**hiera), seed=3, std=0.2).eval()
+    bcfg = C.Sam2HieraDetConfig(hidden_size=16, num_attention_heads=1, blocks_per_stage=[1, 1, 2, 1],
+                                embed_dim_per_stage=[16, 32, 64, 128], num_attention_heads_per_stage=[1, 2, 4, 8],
+                                window_size_per_stage=[8, 4, 14, 7], global_attention_blocks=[3], image_size=[1024, 1024])
+    hf = M.Sam2HieraDetModel(bcfg).eval()
+    hf.load_state_dict(_map_trunk(trunk.state_dict()), strict=True)
+    x = torch.randn(1, 3, 1024, 1024, generator=torch.Generator().manual_seed(0))
+    with torch.no_grad():
+        mine = trunk(x)
+        ref = hf(x).intermediate_hidden_states
+    for a, b in zip(mine, ref):
+        torch.testing.assert_close(a, b.permute(0, 3, 1, 2), rtol=1e-4, atol=1e-4)
+
+
+def _map_decoder(sd):
+    out = {}
+    for k, v in sd.items():
+        k2 = k
+        k2 = k2.replace(".out_proj.", ".o_proj.").replace(".norm1.", ".layer_norm1.").replace(".norm2.", ".layer_norm2.")
+        k2 = k2.replace(".norm3.", ".layer_norm3.").replace(".norm4.", ".layer_norm4.").replace("norm_final_attn", "layer_norm_final_attn")
+        k2 = k2.replace("output_upscaling.0.", "upscale_conv1.").replace("output_upscaling.1.", "upscale_layer_norm.").replace("output_upscaling.3.", "upscale_conv2.")
+        if ".mlp.layers." in k2:                      # 2-layer transformer MLP
+            k2 = k2.replace(".mlp.layers.0.", ".mlp.proj_in.").replace(".mlp.layers.1.", ".mlp.proj_out.")
+        elif ".layers." in k2 and ("hypernetworks" in k2 or "iou_prediction_head" in k2 or "pred_obj_score_head" in k2):
+            k2 = k2.replace(".layers.0.", ".proj_in.").replace(".layers.1.", ".layers.0.").replace(".layers.2.", ".proj_out.")
+        out[k2] = v
+    return out
+
+
+@pytest.mark.parametrize("dynamic", [False, True])
+def test_mask_decoder_matches_independent_implementation(dynamic):
+    C, M = _hf_models(True)
+    dec = osam.randomize_(osam.MaskDecoder(256, 3, lora=False, dynamic_multimask_via_stability=dynamic), seed=5, std=0.08).eval()
+    cfg = C.Sam2MaskDecoderConfig(dynamic_multimask_via_stability=dynamic)
+    hf = M.Sam2MaskDecoder(cfg).eval()
+    hf.load_state_dict(_map_decoder(dec.state_dict()), strict=True)
+    g = torch.Generator().manual_seed(1)
+    emb = torch.randn(1, 256, 16, 16, generator=g)
+    pe = torch.randn(1, 256, 16, 16, generator=g)
+    sparse = torch.randn(1, 32, 256, generator=g)
+    dense = torch.randn(1, 256, 16, 16, generator=g)
+    s0, s1 = torch.randn(1, 32, 64, 64, generator=g), torch.randn(1, 64, 32, 32, generator=g)
+    with torch.no_grad():
+        m, iou, obj = dec(emb, pe, sparse, dense, [s0, s1], multimask_output=False)
+        rm, riou, _, robj = hf(image_embeddings=emb, image_positional_embeddings=pe, sparse_prompt_embeddings=sparse[:, None],
+                               dense_prompt_embeddings=dense, multimask_output=False, high_resolution_features=[s0, s1])
+    torch.testing.assert_close(m, rm[:, 0], rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(iou, riou[:, 0], rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(obj, robj[:, 0], rtol=1e-4, atol=1e-4)
+
+
+def test_dense_pe_matches_independent_implementation():
+    C, M = _hf_models(True)
+    pe_mod = M.Sam2PositionalEmbedding(C.Sam2PromptEncoderConfig())
+    G = pe_mod.positional_embedding.clone()
+    h = w = 64
+    grid = torch.ones((h, w))
+    y = (grid.cumsum(0) - 0.5) / h
+    x = (grid.cumsum(1) - 0.5) / w
+    ref = pe_mod(torch.stack([x, y], -1)).permute(2, 0, 1)[None]
+    torch.testing.assert_close(osam.dense_pe(G, h, w), ref, rtol=1e-5, atol=1e-5)
+
+
+def test_lora_forward_equals_merged_weights():
+    lin = osam.LoRALinear(24, 16).eval()
+    osam.randomize_(lin, seed=9, std=0.3)
+    x = torch.randn(5, 24)
+    W = lin.base_layer.weight + (osam.LORA_ALPHA / osam.LORA_R) * lin.lora_B["default"].weight @ lin.lora_A["default"].weight
+    torch.testing.assert_close(lin(x), x @ W.t() + lin.base_layer.bias, rtol=1e-5, atol=1e-5)
+
+
+def test_wrapper_shapes_tiny_trunk():
+    hiera = dict(embed_dim=16, num_heads=1, stages=(1, 1, 2, 1), global_att_blocks=(3,), window_spec=(8, 4, 16, 8))
+    core = osam.SAM2Core(hiera, lora=True, lora_trunk={2: ("attn.qkv", "mlp.layers.0", "proj"), 3: ("attn.qkv",)}, image_size=256)
+    w = osam.randomize_(osam.SAM2ImageWrapper(core), seed=0, std=0.1).eval()
+    with torch.no_grad():
+        hi, lo, iou = w(torch.randn(2, 3, 256, 256))
+    assert hi.shape == (2, 1, 256, 256) and lo.shape == (2, 1, 64, 64) and iou.shape == (2, 1)
+    out = osam.postprocess_masks(hi, (100, 37))
+    assert out.shape == (2, 1, 100, 37)
+    t = osam.sam2_transform(np.zeros((50, 70, 3), np.uint8), 256)
+    assert t.shape == (3, 256, 256)
+    torch.testing.assert_close(t[:, 0, 0], -torch.tensor(osam.IMAGENET_MEAN) / torch.tensor(osam.IMAGENET_STD))
