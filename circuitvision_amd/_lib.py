@@ -25,6 +25,7 @@ class ConvDesc(C.Structure):
         ("KH", C.c_int), ("KW", C.c_int), ("stride", C.c_int), ("pad", C.c_int),
         ("N", C.c_int), ("Kpad", C.c_int), ("act", C.c_int), ("dtype", C.c_int),
         ("out_f32", C.c_int), ("scalar_gather", C.c_int),
+        ("res_mod", C.c_int), ("act_after_res", C.c_int), ("shuffle_cout", C.c_int),
     ]
 
 
@@ -62,6 +63,14 @@ SIGNATURES = {
     "cvmi_letterbox": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "cvmi_nchw_to_nhwc": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "cvmi_nhwc_to_nchw_f32": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _i, _vp]),
+    "cvmi_layernorm": (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _i, C.c_longlong, _i, _f, _i, _vp]),
+    "cvmi_maxpool2x2": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "cvmi_cast": (_i, [_vp, _i, _i, _vp, _i, _i, C.c_longlong, _i, _vp]),
+    "cvmi_hyper_masks": (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _vp, _i, _i, _f, _vp]),
+    "cvmi_select_mask": (_i, [_vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp, _i, _i, _vp]),
+    "cvmi_bilinear_f32": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _vp, _f, _vp]),
+    "cvmi_upsample_refine": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _vp, C.POINTER(_i), _i, _i, _vp]),
+    "cvmi_sam2_transform": (_i, [_vp, _i, _i, _vp, _i, _i, _vp]),
 }
 
 _lib = None

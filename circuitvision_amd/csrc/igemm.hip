@@ -29,6 +29,7 @@ struct ConvKArgs {
   int H, W, OH, OW, KW, stride, pad;
   int M, N, K, Kpad;
   int act, scalar_gather;
+  int res_mod, act_after_res, shuf_c;
   int nb_n;
   FastDiv div_ctot, div_kw;
 };
@@ -212,7 +213,10 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ConvKArgs p) {
         const int ml = wm * WTM + j * 32 + lr;
         float v[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = act_apply<FAST>(acc[i][j][4 * q + e] + bv[e], p.act);
+        for (int e = 0; e < 4; ++e) {
+          v[e] = acc[i][j][4 * q + e] + bv[e];
+          if (!p.act_after_res) v[e] = act_apply<FAST>(v[e], p.act);
+        }
         char* dst = Ct + ml * CROWB + nl * OES;
         if constexpr (OES == 2) {
           f16x4 hv = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
@@ -231,15 +235,31 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ConvKArgs p) {
     const int m = m0 + row, n = n0 + ch * OVEC;
     if (m >= p.M || n >= p.N) continue;
     u32x4 cv = *reinterpret_cast<const u32x4*>(Ct + row * CROWB + ch * 16);
-    char* yp = p.y + ((size_t)m * p.y_ld + n) * OES;
+    size_t ypix = (size_t)m, rpix = p.res_mod > 0 ? (size_t)(m % p.res_mod) : (size_t)m;
+    int nn = n;
+    if (p.shuf_c > 0) {                            // ConvTranspose 2x2/s2: scatter to the 2x grid
+      const int q = n / p.shuf_c;
+      nn = n - q * p.shuf_c;
+      const int b = m / ohow, r = m - b * ohow;
+      const int oy = r / p.OW, ox = r - oy * p.OW;
+      ypix = ((size_t)b * (2 * p.OH) + 2 * oy + (q >> 1)) * (size_t)(2 * p.OW) + 2 * ox + (q & 1);
+      rpix = ypix;
+    }
+    char* yp = p.y + (ypix * p.y_ld + nn) * OES;
     if (n + OVEC <= p.N) {
-      if (p.res) {
-        const u32x4 rv = *reinterpret_cast<const u32x4*>(p.res + ((size_t)m * p.res_ld + n) * OES);
-        float a[OVEC], r[OVEC];
+      if (p.res || p.act_after_res) {
+        float a[OVEC];
         unpack16<TO>(cv, a);
-        unpack16<TO>(rv, r);
+        if (p.res) {
+          float r[OVEC];
+          unpack16<TO>(*reinterpret_cast<const u32x4*>(p.res + (rpix * p.res_ld + nn) * OES), r);
 #pragma unroll
-        for (int e = 0; e < OVEC; ++e) a[e] += r[e];
+          for (int e = 0; e < OVEC; ++e) a[e] += r[e];
+        }
+        if (p.act_after_res) {
+#pragma unroll
+          for (int e = 0; e < OVEC; ++e) a[e] = act_apply<FAST>(a[e], p.act);
+        }
         cv = pack16<TO>(a);
       }
       *reinterpret_cast<u32x4*>(yp) = cv;
@@ -247,7 +267,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ConvKArgs p) {
       const TO* cs = reinterpret_cast<const TO*>(&cv);
       for (int e = 0; e < p.N - n; ++e) {
         float a = (float)cs[e];
-        if (p.res) a += (float)reinterpret_cast<const TO*>(p.res + ((size_t)m * p.res_ld + n) * OES)[e];
+        if (p.res) a += (float)reinterpret_cast<const TO*>(p.res + (rpix * p.res_ld + nn) * OES)[e];
+        if (p.act_after_res) a = act_apply<FAST>(a, p.act);
         reinterpret_cast<TO*>(yp)[e] = (TO)a;
       }
     }
@@ -310,7 +331,7 @@ extern "C" int cvmi_conv2d(const cvmi_conv_desc* d, cvmi_stream_t stream_) {
              (d->OW - 1) * d->stride - d->pad + d->KW - 1 < d->W + d->pad, "conv2d: output larger than input allows");
   const int ctot = d->c0 + d->c1;
   const long long K = (long long)d->KH * d->KW * ctot;
-  CVMI_CHECK(K < 65536 && d->Kpad >= K && d->Kpad % 32 == 0 && d->Kpad < 65536 + 32, "conv2d: K=%lld Kpad=%d unsupported", K, d->Kpad);
+  CVMI_CHECK(K < 65536 && d->Kpad >= K && d->Kpad % 32 == 0 && d->Kpad <= 65536, "conv2d: K=%lld Kpad=%d unsupported", K, d->Kpad);
   if (!d->scalar_gather) {
     CVMI_CHECK(d->c0 % vec == 0 && d->c1 % vec == 0, "conv2d: channels (%d,%d) not multiples of %d", d->c0, d->c1, vec);
     CVMI_CHECK(d->x0_ld % vec == 0 && (d->c1 == 0 || d->x1_ld % vec == 0), "conv2d: source ld not 16-byte aligned");
@@ -318,8 +339,8 @@ extern "C" int cvmi_conv2d(const cvmi_conv_desc* d, cvmi_stream_t stream_) {
   }
   CVMI_CHECK(d->x0_ld >= d->c0 && (d->c1 == 0 || d->x1_ld >= d->c1), "conv2d: ld smaller than channels");
   CVMI_CHECK(d->y_ld % ovec == 0 && ((uintptr_t)d->y & 15) == 0, "conv2d: output not 16-byte aligned");
-  CVMI_CHECK(d->y_ld >= d->N, "conv2d: y_ld < N");
-  CVMI_CHECK(!d->res || (d->res_ld % ovec == 0 && ((uintptr_t)d->res & 15) == 0 && d->res_ld >= d->N), "conv2d: residual misaligned");
+  CVMI_CHECK(d->y_ld >= d->N || d->shuffle_cout > 0, "conv2d: y_ld < N");
+  CVMI_CHECK(!d->res || (d->res_ld % ovec == 0 && ((uintptr_t)d->res & 15) == 0 && (d->res_ld >= d->N || d->shuffle_cout > 0)), "conv2d: residual misaligned");
   CVMI_CHECK(((uintptr_t)d->w & 15) == 0 && ((uintptr_t)d->bias & 15) == 0, "conv2d: weights misaligned");
   CVMI_CHECK(d->up0 == 0 || (d->H % 2 == 0 && d->W % 2 == 0), "conv2d: upsampled source needs even H, W");
   CVMI_CHECK(d->up1 == 0 || (d->H % 2 == 0 && d->W % 2 == 0), "conv2d: upsampled source needs even H, W");
@@ -334,6 +355,13 @@ extern "C" int cvmi_conv2d(const cvmi_conv_desc* d, cvmi_stream_t stream_) {
   a.H = d->H; a.W = d->W; a.OH = d->OH; a.OW = d->OW; a.KW = d->KW; a.stride = d->stride; a.pad = d->pad;
   a.M = (int)M; a.N = d->N; a.K = (int)K; a.Kpad = d->Kpad;
   a.act = d->act; a.scalar_gather = d->scalar_gather; a.nb_n = 1;
+  a.res_mod = d->res_mod; a.act_after_res = d->act_after_res; a.shuf_c = d->shuffle_cout;
+  CVMI_CHECK(d->res_mod >= 0 && d->shuffle_cout >= 0, "conv2d: negative res_mod / shuffle_cout");
+  if (d->shuffle_cout > 0) {
+    CVMI_CHECK(d->N == 4 * d->shuffle_cout && d->shuffle_cout % ovec == 0 && d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0 &&
+               d->res_mod == 0, "conv2d: shuffle_cout needs a 1x1 conv with N == 4*shuffle_cout (multiple of %d)", ovec);
+    CVMI_CHECK(d->y_ld >= d->shuffle_cout && (!d->res || d->res_ld >= d->shuffle_cout), "conv2d: shuffle output ld too small");
+  }
   a.div_ctot.init((unsigned)ctot); a.div_kw.init((unsigned)d->KW);
   hipStream_t stream = (hipStream_t)stream_;
   if (d->dtype == CVMI_F32) return launch_typed<float, float>(a, stream);

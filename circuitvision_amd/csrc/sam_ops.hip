@@ -1,0 +1,420 @@
+// SAM 2.1 path helpers (everything that is not a GEMM or an attention): LayerNorm, 2x2 max-pool, casts,
+// the mask-decoder tail (hypernetwork product + stability selection), bilinear resizes, the fused
+// upsample + multi-kernel refinement head, and the antialiased input transform.
+#include "common.hpp"
+
+namespace {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
+
+// ---- LayerNorm: one wave per row, row held in registers (C <= 64 * VEC * MAXCH) ---------------------
+template <typename TI, typename TO, int MAXCH>
+__global__ __launch_bounds__(256) void layernorm_kernel(const TI* __restrict__ x, int x_ld, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, TO* __restrict__ y, int y_ld, long long rows, int C,
+                                                       float eps, int act) {
+  constexpr int VI = Elem<TI>::VEC;
+  const int lane = threadIdx.x & 63;
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const TI* xr = x + row * x_ld;
+  float v[MAXCH][VI];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXCH; ++i) {
+    const int c = (i * 64 + lane) * VI;
+    if (c < C) {
+      unpack16<TI>(*reinterpret_cast<const u32x4*>(xr + c), v[i]);
+#pragma unroll
+      for (int e = 0; e < VI; ++e) s += v[i][e];
+    }
+  }
+  const float mean = wave_sum(s) / (float)C;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXCH; ++i) {
+    const int c = (i * 64 + lane) * VI;
+    if (c < C) {
+#pragma unroll
+      for (int e = 0; e < VI; ++e) { const float d = v[i][e] - mean; q += d * d; }
+    }
+  }
+  const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)C + eps);
+  TO* yr = y + row * y_ld;
+#pragma unroll
+  for (int i = 0; i < MAXCH; ++i) {
+    const int c = (i * 64 + lane) * VI;
+    if (c < C) {
+      struct alignas(sizeof(TO) * VI) Pack { TO v[VI]; } pk;
+#pragma unroll
+      for (int e = 0; e < VI; ++e) {
+        float o = (v[i][e] - mean) * rstd * gamma[c + e] + beta[c + e];
+        pk.v[e] = (TO)act_apply<false>(o, act);
+      }
+      *reinterpret_cast<Pack*>(yr + c) = pk;
+    }
+  }
+}
+
+// ---- 2x2 / s2 max-pool (NHWC) --------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool2_kernel(const char* __restrict__ x, int x_ld, char* __restrict__ y, int y_ld, int B, int H, int W, int C) {
+  constexpr int VEC = Elem<T>::VEC;
+  const int nch = C / VEC, OH = H / 2, OW = W / 2;
+  const long long total = (long long)B * OH * OW * nch;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+    const int ch = (int)(idx % nch);
+    const long long pix = idx / nch;
+    const int ox = (int)(pix % OW);
+    const long long t = pix / OW;
+    const int oy = (int)(t % OH);
+    const long long b = t / OH;
+    float m[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) m[e] = -INFINITY;
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 2; ++dx) {
+        float v[VEC];
+        const size_t ip = ((size_t)b * H + 2 * oy + dy) * W + 2 * ox + dx;
+        unpack16<T>(*reinterpret_cast<const u32x4*>(x + (ip * x_ld + ch * VEC) * sizeof(T)), v);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) m[e] = fmaxf(m[e], v[e]);
+      }
+    *reinterpret_cast<u32x4*>(y + ((size_t)pix * y_ld + ch * VEC) * sizeof(T)) = pack16<T>(m);
+  }
+}
+
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void cast_kernel(const TI* __restrict__ x, int x_ld, TO* __restrict__ y, int y_ld, long long rows, int C) {
+  const long long total = rows * C;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+    const long long r = idx / C;
+    const int c = (int)(idx - r * C);
+    y[r * y_ld + c] = (TO)(float)x[r * x_ld + c];
+  }
+}
+
+// ---- mask decoder tail ------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void hyper_masks_kernel(const float* __restrict__ hyper, int hyper_ld, const T* __restrict__ up, int up_ld, int C,
+                                                         float* __restrict__ masks, int* __restrict__ areas, int P, float delta) {
+  __shared__ float hs[4 * 64];
+  const int b = blockIdx.y;
+  for (int i = threadIdx.x; i < 4 * C; i += blockDim.x) hs[i] = hyper[((size_t)b * 4 + i / C) * hyper_ld + (i % C)];
+  __syncthreads();
+  int ai = 0, au = 0;
+  for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x) {
+    const T* u = up + ((size_t)b * P + p) * up_ld;
+    float m0 = 0.f, m1 = 0.f, m2 = 0.f, m3 = 0.f;
+    for (int c = 0; c < C; ++c) {
+      const float v = (float)u[c];
+      m0 = fmaf(hs[c], v, m0); m1 = fmaf(hs[C + c], v, m1); m2 = fmaf(hs[2 * C + c], v, m2); m3 = fmaf(hs[3 * C + c], v, m3);
+    }
+    float* o = masks + (size_t)b * 4 * P + p;
+    o[0] = m0; o[(size_t)P] = m1; o[(size_t)2 * P] = m2; o[(size_t)3 * P] = m3;
+    ai += m0 > delta;
+    au += m0 > -delta;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { ai += __shfl_xor(ai, off); au += __shfl_xor(au, off); }
+  if ((threadIdx.x & 63) == 0) { atomicAdd(&areas[b * 2], ai); atomicAdd(&areas[b * 2 + 1], au); }
+}
+
+__global__ __launch_bounds__(256) void select_mask_kernel(const float* __restrict__ masks, const int* __restrict__ areas, const float* __restrict__ iou,
+                                                         int iou_ld, int dynamic, float thresh, float* __restrict__ low, float* __restrict__ iou_out,
+                                                         int* __restrict__ sel, int P) {
+  const int b = blockIdx.y;
+  int idx = 0;
+  if (dynamic) {
+    const float ai = (float)areas[b * 2], au = (float)areas[b * 2 + 1];
+    const float stab = au > 0.f ? ai / au : 1.0f;
+    if (!(stab >= thresh)) {
+      const float* io = iou + (size_t)b * iou_ld;
+      idx = 1;
+      float best = io[1];
+      if (io[2] > best) { best = io[2]; idx = 2; }
+      if (io[3] > best) { best = io[3]; idx = 3; }
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) { sel[b] = idx; iou_out[b] = iou[(size_t)b * iou_ld + idx]; }
+  const float* src = masks + ((size_t)b * 4 + idx) * P;
+  for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x) low[(size_t)b * P + p] = src[p];
+}
+
+// ---- bilinear, align_corners = False (PyTorch semantics) ----------------------------------------------------
+__device__ __forceinline__ void bil_axis(int d, float scale, int in, int& i0, int& i1, float& l1) {
+  float s = ((float)d + 0.5f) * scale - 0.5f;
+  if (s < 0.f) s = 0.f;
+  i0 = (int)s;
+  if (i0 > in - 1) i0 = in - 1;
+  i1 = i0 + (i0 < in - 1 ? 1 : 0);
+  l1 = s - (float)i0;
+}
+
+__device__ __forceinline__ float bil_sample(const float* __restrict__ pl, int w, int y0, int y1, float ly, int x0, int x1, float lx) {
+  const float hy = 1.f - ly, hx = 1.f - lx;
+  return hy * (hx * pl[(size_t)y0 * w + x0] + lx * pl[(size_t)y0 * w + x1]) + ly * (hx * pl[(size_t)y1 * w + x0] + lx * pl[(size_t)y1 * w + x1]);
+}
+
+__global__ __launch_bounds__(256) void bilinear_kernel(const float* __restrict__ x, int h, int w, float* __restrict__ y, int H, int W,
+                                                      uint8_t* __restrict__ mask, float thresh, float sy, float sx) {
+  const int n = blockIdx.y;
+  const float* pl = x + (size_t)n * h * w;
+  const int total = H * W;
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+    const int oy = idx / W, ox = idx - oy * W;
+    int y0, y1, x0, x1; float ly, lx;
+    bil_axis(oy, sy, h, y0, y1, ly);
+    bil_axis(ox, sx, w, x0, x1, lx);
+    const float v = bil_sample(pl, w, y0, y1, ly, x0, x1, lx);
+    y[(size_t)n * total + idx] = v;
+    if (mask) mask[(size_t)n * total + idx] = v > thresh ? 255 : 0;
+  }
+}
+
+// ---- fused upsample + MultiKernelRefinement -------------------------------------------------------------------
+// 16x16 output tile per workgroup; the bilinear-upsampled tile (+ halo of max(ks)/2, zero outside the
+// image = the convs' 'same' zero padding) lives in LDS; every thread walks the largest window once and
+// feeds each branch whose kernel covers the tap.
+constexpr int RF_TILE = 16;
+constexpr int RF_MAXK = 4;
+struct RefineArgs { int ks[RF_MAXK]; int woff[RF_MAXK]; int boff[RF_MAXK]; int nk, ic, comb_w, comb_b, halo; };
+
+template <int IC>
+__global__ __launch_bounds__(256) void upsample_refine_kernel(const float* __restrict__ low, int h, int w, float* __restrict__ high, int H, int W,
+                                                             const float* __restrict__ prm, const RefineArgs a, float sy, float sx) {
+  extern __shared__ __attribute__((aligned(16))) float tile[];
+  const int halo = a.halo, TS = RF_TILE + 2 * halo, TSP = TS + 1;
+  const int n = blockIdx.z;
+  const int ty0 = blockIdx.y * RF_TILE - halo, tx0 = blockIdx.x * RF_TILE - halo;
+  const float* pl = low + (size_t)n * h * w;
+  for (int i = threadIdx.x; i < TS * TS; i += 256) {
+    const int ly = i / TS, lx = i - ly * TS;
+    const int gy = ty0 + ly, gx = tx0 + lx;
+    float v = 0.f;
+    if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
+      int y0, y1, x0, x1; float fy, fx;
+      bil_axis(gy, sy, h, y0, y1, fy);
+      bil_axis(gx, sx, w, x0, x1, fx);
+      v = bil_sample(pl, w, y0, y1, fy, x0, x1, fx);
+    }
+    tile[ly * TSP + lx] = v;
+  }
+  __syncthreads();
+  const int py = threadIdx.x / RF_TILE, px = threadIdx.x % RF_TILE;
+  const int oy = blockIdx.y * RF_TILE + py, ox = blockIdx.x * RF_TILE + px;
+  float acc[RF_MAXK][IC];
+#pragma unroll
+  for (int j = 0; j < RF_MAXK; ++j)
+#pragma unroll
+    for (int c = 0; c < IC; ++c) acc[j][c] = j < a.nk ? prm[a.boff[j] + c] : 0.f;
+  for (int dy = -halo; dy <= halo; ++dy) {
+    for (int dx = -halo; dx <= halo; ++dx) {
+      const float v = tile[(py + halo + dy) * TSP + px + halo + dx];
+      const int r = max(abs(dy), abs(dx));
+#pragma unroll
+      for (int j = 0; j < RF_MAXK; ++j) {
+        if (j < a.nk) {
+          const int k = a.ks[j], kh = k >> 1;
+          if (r <= kh) {
+            const float* wp = prm + a.woff[j] + (dy + kh) * k + (dx + kh);
+#pragma unroll
+            for (int c = 0; c < IC; ++c) acc[j][c] = fmaf(wp[c * k * k], v, acc[j][c]);
+          }
+        }
+      }
+    }
+  }
+  if (oy < H && ox < W) {
+    float out = prm[a.comb_b];
+#pragma unroll
+    for (int j = 0; j < RF_MAXK; ++j)
+      if (j < a.nk) {
+#pragma unroll
+        for (int c = 0; c < IC; ++c) out = fmaf(prm[a.comb_w + j * IC + c], act_apply<false>(acc[j][c], CVMI_ACT_GELU), out);
+      }
+    high[((size_t)n * H + oy) * W + ox] = out;
+  }
+}
+
+// ---- SAM2Transforms.__call__: /255, antialiased bilinear (torch _upsample_bilinear2d_aa), normalise -----------
+constexpr int AA_MAXTAPS = 24;
+__device__ __forceinline__ void aa_axis(int i, float scale, int in, int& xmin, int& xsize, float* wt) {
+  const float support = scale >= 1.f ? scale : 1.f;
+  const float invscale = scale >= 1.f ? 1.f / scale : 1.f;
+  const float center = scale * ((float)i + 0.5f);
+  xmin = max((int)(center - support + 0.5f), 0);
+  xsize = min((int)(center + support + 0.5f), in) - xmin;
+  if (xsize > AA_MAXTAPS) xsize = AA_MAXTAPS;
+  float total = 0.f;
+  for (int j = 0; j < xsize; ++j) {
+    float t = ((float)(j + xmin) - center + 0.5f) * invscale;
+    t = fabsf(t);
+    const float wv = t < 1.f ? 1.f - t : 0.f;
+    wt[j] = wv;
+    total += wv;
+  }
+  const float ws = total != 0.f ? 1.f / total : 0.f;
+  for (int j = 0; j < xsize; ++j) wt[j] *= ws;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void sam2_transform_kernel(const uint8_t* __restrict__ src, int H, int W, T* __restrict__ dst, int R, float sy, float sx) {
+  const int total = R * R;
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+    const int oy = idx / R, ox = idx - oy * R;
+    int ymin, ysize, xmin, xsize;
+    float wy[AA_MAXTAPS], wx[AA_MAXTAPS];
+    aa_axis(oy, sy, H, ymin, ysize, wy);
+    aa_axis(ox, sx, W, xmin, xsize, wx);
+    float acc[3] = {0.f, 0.f, 0.f};
+    for (int j = 0; j < ysize; ++j) {
+      float row[3] = {0.f, 0.f, 0.f};
+      const uint8_t* sp = src + ((size_t)(ymin + j) * W + xmin) * 3;
+      for (int i = 0; i < xsize; ++i) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) row[c] += wx[i] * ((float)sp[i * 3 + c] / 255.0f);
+      }
+#pragma unroll
+      for (int c = 0; c < 3; ++c) acc[c] += wy[j] * row[c];
+    }
+    const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) dst[(size_t)idx * 3 + c] = (T)((acc[c] - mean[c]) / stdv[c]);
+  }
+}
+
+inline int grid_for(long long total, int block = 256, int cap = 256 * 16) {
+  long long g = (total + block - 1) / block;
+  if (g > cap) g = cap;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+template <typename TI, typename TO>
+int launch_ln(const void* x, int x_ld, const float* gamma, const float* beta, void* y, int y_ld, long long rows, int C, float eps, int act,
+              hipStream_t stream) {
+  constexpr int VI = Elem<TI>::VEC;
+  const int nch = (C / VI + 63) / 64;
+  const dim3 g((unsigned)((rows + 3) / 4)), b(256);
+  if (nch <= 1) hipLaunchKernelGGL((layernorm_kernel<TI, TO, 1>), g, b, 0, stream, (const TI*)x, x_ld, gamma, beta, (TO*)y, y_ld, rows, C, eps, act);
+  else if (nch <= 2) hipLaunchKernelGGL((layernorm_kernel<TI, TO, 2>), g, b, 0, stream, (const TI*)x, x_ld, gamma, beta, (TO*)y, y_ld, rows, C, eps, act);
+  else if (nch <= 3) hipLaunchKernelGGL((layernorm_kernel<TI, TO, 3>), g, b, 0, stream, (const TI*)x, x_ld, gamma, beta, (TO*)y, y_ld, rows, C, eps, act);
+  else if (nch <= 5) hipLaunchKernelGGL((layernorm_kernel<TI, TO, 5>), g, b, 0, stream, (const TI*)x, x_ld, gamma, beta, (TO*)y, y_ld, rows, C, eps, act);
+  else if (nch <= 8) hipLaunchKernelGGL((layernorm_kernel<TI, TO, 8>), g, b, 0, stream, (const TI*)x, x_ld, gamma, beta, (TO*)y, y_ld, rows, C, eps, act);
+  else CVMI_FAIL("layernorm: C=%d too wide", C);
+  CVMI_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int cvmi_layernorm(const void* x, int x_ld, int x_dtype, const float* gamma, const float* beta, void* y, int y_ld, int y_dtype,
+                              long long rows, int C, float eps, int act, cvmi_stream_t stream_) {
+  CVMI_CHECK(x && gamma && beta && y && rows > 0 && C > 0, "layernorm: bad arguments");
+  const int vi = x_dtype == CVMI_F16 ? 8 : 4;
+  CVMI_CHECK((x_dtype == CVMI_F16 || x_dtype == CVMI_F32) && (y_dtype == CVMI_F16 || y_dtype == CVMI_F32), "layernorm: bad dtype");
+  CVMI_CHECK(C % vi == 0 && x_ld % vi == 0 && y_ld % vi == 0 && (((uintptr_t)x | (uintptr_t)y) & 15) == 0 && x_ld >= C && y_ld >= C, "layernorm: C=%d / ld not 16-byte aligned", C);
+  hipStream_t s = (hipStream_t)stream_;
+  if (x_dtype == CVMI_F32 && y_dtype == CVMI_F32) return launch_ln<float, float>(x, x_ld, gamma, beta, y, y_ld, rows, C, eps, act, s);
+  if (x_dtype == CVMI_F32 && y_dtype == CVMI_F16) return launch_ln<float, f16>(x, x_ld, gamma, beta, y, y_ld, rows, C, eps, act, s);
+  if (x_dtype == CVMI_F16 && y_dtype == CVMI_F16) return launch_ln<f16, f16>(x, x_ld, gamma, beta, y, y_ld, rows, C, eps, act, s);
+  return launch_ln<f16, float>(x, x_ld, gamma, beta, y, y_ld, rows, C, eps, act, s);
+}
+
+extern "C" int cvmi_maxpool2x2(const void* x, int x_ld, void* y, int y_ld, int B, int H, int W, int C, int dtype, cvmi_stream_t stream_) {
+  CVMI_CHECK(x && y && B > 0 && H > 0 && W > 0 && C > 0 && H % 2 == 0 && W % 2 == 0, "maxpool2x2: bad shape");
+  CVMI_CHECK(dtype == CVMI_F16 || dtype == CVMI_F32, "maxpool2x2: bad dtype");
+  const int vec = dtype == CVMI_F16 ? 8 : 4;
+  CVMI_CHECK(C % vec == 0 && x_ld % vec == 0 && y_ld % vec == 0 && (((uintptr_t)x | (uintptr_t)y) & 15) == 0, "maxpool2x2: not 16-byte aligned");
+  const long long total = (long long)B * (H / 2) * (W / 2) * (C / vec);
+  hipStream_t s = (hipStream_t)stream_;
+  if (dtype == CVMI_F16) hipLaunchKernelGGL(maxpool2_kernel<f16>, dim3(grid_for(total)), dim3(256), 0, s, (const char*)x, x_ld, (char*)y, y_ld, B, H, W, C);
+  else hipLaunchKernelGGL(maxpool2_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, (const char*)x, x_ld, (char*)y, y_ld, B, H, W, C);
+  CVMI_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int cvmi_cast(const void* x, int x_ld, int x_dtype, void* y, int y_ld, int y_dtype, long long rows, int C, cvmi_stream_t stream_) {
+  CVMI_CHECK(x && y && rows > 0 && C > 0 && x_ld >= C && y_ld >= C, "cast: bad arguments");
+  hipStream_t s = (hipStream_t)stream_;
+  const dim3 g(grid_for(rows * C)), b(256);
+  if (x_dtype == CVMI_F32 && y_dtype == CVMI_F16) hipLaunchKernelGGL((cast_kernel<float, f16>), g, b, 0, s, (const float*)x, x_ld, (f16*)y, y_ld, rows, C);
+  else if (x_dtype == CVMI_F16 && y_dtype == CVMI_F32) hipLaunchKernelGGL((cast_kernel<f16, float>), g, b, 0, s, (const f16*)x, x_ld, (float*)y, y_ld, rows, C);
+  else if (x_dtype == CVMI_F32 && y_dtype == CVMI_F32) hipLaunchKernelGGL((cast_kernel<float, float>), g, b, 0, s, (const float*)x, x_ld, (float*)y, y_ld, rows, C);
+  else if (x_dtype == CVMI_F16 && y_dtype == CVMI_F16) hipLaunchKernelGGL((cast_kernel<f16, f16>), g, b, 0, s, (const f16*)x, x_ld, (f16*)y, y_ld, rows, C);
+  else CVMI_FAIL("cast: bad dtypes");
+  CVMI_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int cvmi_hyper_masks(const float* hyper, int hyper_ld, const void* up, int up_ld, int up_dtype, int C, float* masks, int* areas, int B,
+                                int P, float delta, cvmi_stream_t stream_) {
+  CVMI_CHECK(hyper && up && masks && areas && B > 0 && P > 0 && C > 0 && C <= 64 && hyper_ld >= C && up_ld >= C, "hyper_masks: bad arguments");
+  CVMI_CHECK(up_dtype == CVMI_F16 || up_dtype == CVMI_F32, "hyper_masks: bad dtype");
+  hipStream_t s = (hipStream_t)stream_;
+  CVMI_HIP(hipMemsetAsync(areas, 0, sizeof(int) * 2 * B, s));
+  const dim3 g(grid_for(P, 256, 64), B), b(256);
+  if (up_dtype == CVMI_F16) hipLaunchKernelGGL(hyper_masks_kernel<f16>, g, b, 0, s, hyper, hyper_ld, (const f16*)up, up_ld, C, masks, areas, P, delta);
+  else hipLaunchKernelGGL(hyper_masks_kernel<float>, g, b, 0, s, hyper, hyper_ld, (const float*)up, up_ld, C, masks, areas, P, delta);
+  CVMI_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int cvmi_select_mask(const float* masks, const int* areas, const float* iou, int iou_ld, int dynamic, float thresh, float* low_res,
+                                float* iou_out, int* sel, int B, int P, cvmi_stream_t stream_) {
+  CVMI_CHECK(masks && areas && iou && low_res && iou_out && sel && B > 0 && P > 0 && iou_ld >= 4, "select_mask: bad arguments");
+  hipLaunchKernelGGL(select_mask_kernel, dim3(grid_for(P, 256, 64), B), dim3(256), 0, (hipStream_t)stream_, masks, areas, iou, iou_ld, dynamic, thresh,
+                     low_res, iou_out, sel, P);
+  CVMI_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int cvmi_bilinear_f32(const float* x, int N, int h, int w, float* y, int H, int W, uint8_t* mask_u8, float thresh, cvmi_stream_t stream_) {
+  CVMI_CHECK(x && y && N > 0 && h > 0 && w > 0 && H > 0 && W > 0, "bilinear: bad arguments");
+  hipLaunchKernelGGL(bilinear_kernel, dim3(grid_for((long long)H * W, 256, 1024), N), dim3(256), 0, (hipStream_t)stream_, x, h, w, y, H, W, mask_u8,
+                     thresh, (float)h / (float)H, (float)w / (float)W);
+  CVMI_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int cvmi_upsample_refine(const float* low, int N, int h, int w, float* high, int H, int W, const float* params, const int* ks, int nk,
+                                    int ic, cvmi_stream_t stream_) {
+  CVMI_CHECK(low && high && params && ks && N > 0 && h > 0 && w > 0 && H > 0 && W > 0, "upsample_refine: bad arguments");
+  CVMI_CHECK(nk >= 1 && nk <= RF_MAXK && ic == 4, "upsample_refine: supports 1..%d branches of 4 channels", RF_MAXK);
+  RefineArgs a;
+  int off = 0, halo = 0;
+  for (int j = 0; j < RF_MAXK; ++j) {
+    if (j < nk) {
+      CVMI_CHECK(ks[j] % 2 == 1 && ks[j] >= 1 && ks[j] <= 15, "upsample_refine: kernel sizes must be odd and <= 15");
+      a.ks[j] = ks[j]; a.woff[j] = off; off += ic * ks[j] * ks[j]; a.boff[j] = off; off += ic;
+      if (ks[j] / 2 > halo) halo = ks[j] / 2;
+    } else { a.ks[j] = 1; a.woff[j] = a.boff[j] = 0; }
+  }
+  a.nk = nk; a.ic = ic; a.comb_w = off; a.comb_b = off + nk * ic; a.halo = halo;
+  const int TS = RF_TILE + 2 * halo;
+  const size_t lds = (size_t)TS * (TS + 1) * sizeof(float);
+  const dim3 g((W + RF_TILE - 1) / RF_TILE, (H + RF_TILE - 1) / RF_TILE, N);
+  hipLaunchKernelGGL(upsample_refine_kernel<4>, g, dim3(256), lds, (hipStream_t)stream_, low, h, w, high, H, W, params, a, (float)h / (float)H,
+                     (float)w / (float)W);
+  CVMI_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int cvmi_sam2_transform(const uint8_t* src, int H, int W, void* dst, int R, int dst_dtype, cvmi_stream_t stream_) {
+  CVMI_CHECK(src && dst && H > 0 && W > 0 && R > 0, "sam2_transform: bad arguments");
+  CVMI_CHECK(dst_dtype == CVMI_F16 || dst_dtype == CVMI_F32, "sam2_transform: bad dtype");
+  const float sy = (float)H / (float)R, sx = (float)W / (float)R;
+  CVMI_CHECK(2.f * (sy > 1.f ? sy : 1.f) + 2.f <= AA_MAXTAPS && 2.f * (sx > 1.f ? sx : 1.f) + 2.f <= AA_MAXTAPS, "sam2_transform: down-scale factor too large");
+  hipStream_t s = (hipStream_t)stream_;
+  const dim3 g(grid_for((long long)R * R)), b(256);
+  if (dst_dtype == CVMI_F16) hipLaunchKernelGGL(sam2_transform_kernel<f16>, g, b, 0, s, src, H, W, (f16*)dst, R, sy, sx);
+  else hipLaunchKernelGGL(sam2_transform_kernel<float>, g, b, 0, s, src, H, W, (float*)dst, R, sy, sx);
+  CVMI_LAUNCH_CHECK();
+  return 0;
+}

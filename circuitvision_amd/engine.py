@@ -160,7 +160,7 @@ class Plan:
 
 # ---- op wrappers (each appends one launch to a plan) --------------------------------------------
 def op_conv(plan, label, pc, srcs, dst, stride=1, pad=None, act=_lib.ACT_NONE, res=None, out_hw=None,
-            scalar_gather=False, kind="conv"):
+            scalar_gather=False, kind="conv", res_mod=0, act_after_res=False, shuffle_cout=0):
     """srcs: [(View, up)] (1 or 2 channel-concatenated sources).  dst / res: View."""
     lib = _lib.load()
     (v0, up0) = srcs[0]
@@ -175,7 +175,10 @@ def op_conv(plan, label, pc, srcs, dst, stride=1, pad=None, act=_lib.ACT_NONE, r
     OW = (W + 2 * pad - pc.KW) // stride + 1
     if out_hw is not None:
         assert (OH, OW) == tuple(out_hw)
-    assert (dst.B, dst.H, dst.W) == (v0.B, OH, OW) and dst.c == pc.N, (label, (dst.B, dst.H, dst.W, dst.c), (v0.B, OH, OW, pc.N))
+    if shuffle_cout:
+        assert (dst.B, dst.H, dst.W) == (v0.B, 2 * OH, 2 * OW) and dst.c == shuffle_cout and pc.N == 4 * shuffle_cout, label
+    else:
+        assert (dst.B, dst.H, dst.W) == (v0.B, OH, OW) and dst.c == pc.N, (label, (dst.B, dst.H, dst.W, dst.c), (v0.B, OH, OW, pc.N))
     out_f32 = 1 if (dst.dtype == F32 and pc.dtype == F16) else 0
     d = ConvDesc(
         x0=v0.ptr, x1=(v1.ptr if v1 is not None else None), w=pc.w.data_ptr(), bias=pc.bias.data_ptr(),
@@ -183,7 +186,8 @@ def op_conv(plan, label, pc, srcs, dst, stride=1, pad=None, act=_lib.ACT_NONE, r
         x0_ld=v0.ld, x1_ld=(v1.ld if v1 is not None else 0), res_ld=(res.ld if res is not None else 0), y_ld=dst.ld,
         c0=v0.c, c1=(v1.c if v1 is not None else 0), up0=up0, up1=up1,
         B=v0.B, H=H, W=W, OH=OH, OW=OW, KH=pc.KH, KW=pc.KW, stride=stride, pad=pad,
-        N=pc.N, Kpad=pc.Kpad, act=act, dtype=pc.dtype, out_f32=out_f32, scalar_gather=1 if scalar_gather else 0)
+        N=pc.N, Kpad=pc.Kpad, act=act, dtype=pc.dtype, out_f32=out_f32, scalar_gather=1 if scalar_gather else 0,
+        res_mod=res_mod, act_after_res=1 if act_after_res else 0, shuffle_cout=shuffle_cout)
     plan.keep.append((d, pc, srcs, dst, res))
     sp = plan.sptr
     fn = lib.cvmi_conv2d
@@ -246,3 +250,79 @@ def make_attn_desc(**kw):
     for k, v in kw.items():
         setattr(d, k, v)
     return d
+
+
+# ---- SAM 2 path op wrappers ----------------------------------------------------------------------------
+class Rows:
+    """rows x C matrix view (ptr, ld, dtype) over any device tensor; used for token / pixel matrices."""
+
+    def __init__(self, t, rows, C, ld=None, offset=0, dtype=None):
+        self.t, self.rows, self.C = t, rows, C
+        self.ld = ld if ld is not None else C
+        self.offset = offset
+        self.dtype = dtype if dtype is not None else (F16 if t.dtype == torch.float16 else F32)
+
+    @property
+    def ptr(self):
+        return self.t.data_ptr() + self.offset * self.t.element_size()
+
+
+def op_layernorm(plan, label, src, gamma, beta, dst, eps=1e-6, act=_lib.ACT_NONE):
+    """src / dst: Rows (or View, treated as B*H*W rows)."""
+    lib = _lib.load()
+    src, dst = _as_rows(src), _as_rows(dst)
+    assert src.rows == dst.rows and src.C == dst.C == gamma.numel()
+    args = (src.ptr, src.ld, src.dtype, gamma.data_ptr(), beta.data_ptr(), dst.ptr, dst.ld, dst.dtype, src.rows, src.C, float(eps), act)
+    plan.keep.append((src, dst, gamma, beta))
+    sp, fn = plan.sptr, lib.cvmi_layernorm
+
+    def thunk():
+        _lib.check(fn(*args, sp), label)
+
+    plan.add(label, "layernorm", thunk, src.rows * src.C * (ESIZE[src.dtype] + ESIZE[dst.dtype]), 8 * src.rows * src.C)
+
+
+def _as_rows(v):
+    if isinstance(v, Rows):
+        return v
+    if isinstance(v, View):
+        return Rows(v.buf.t, v.B * v.H * v.W, v.c, ld=v.ld, offset=v.c0, dtype=v.dtype)
+    raise TypeError(type(v))
+
+
+def op_maxpool2(plan, label, src, dst):
+    lib = _lib.load()
+    assert src.c == dst.c and (dst.H, dst.W) == (src.H // 2, src.W // 2) and src.dtype == dst.dtype
+    args = (src.ptr, src.ld, dst.ptr, dst.ld, src.B, src.H, src.W, src.c, src.dtype)
+    plan.keep.append((src, dst))
+    sp, fn = plan.sptr, lib.cvmi_maxpool2x2
+
+    def thunk():
+        _lib.check(fn(*args, sp), label)
+
+    n = src.B * src.H * src.W * src.c
+    plan.add(label, "pool", thunk, n * ESIZE[src.dtype] * 5 // 4, 0)
+
+
+def op_cast(plan, label, src, dst):
+    lib = _lib.load()
+    src, dst = _as_rows(src), _as_rows(dst)
+    args = (src.ptr, src.ld, src.dtype, dst.ptr, dst.ld, dst.dtype, src.rows, src.C)
+    plan.keep.append((src, dst))
+    sp, fn = plan.sptr, lib.cvmi_cast
+
+    def thunk():
+        _lib.check(fn(*args, sp), label)
+
+    plan.add(label, "cast", thunk, src.rows * src.C * (ESIZE[src.dtype] + ESIZE[dst.dtype]), 0)
+
+
+def op_call(plan, label, kind, fn, args, keep=(), bytes_=0, flops=0):
+    """Generic: fn(*args, stream)."""
+    plan.keep.append(keep)
+    sp = plan.sptr
+
+    def thunk():
+        _lib.check(fn(*args, sp), label)
+
+    plan.add(label, kind, thunk, bytes_, flops)

@@ -1,0 +1,578 @@
+"""SAM 2.1 image path on the cvmi355 kernels: weight preparation (LoRA merge, constant folding),
+launch plan, and the reference's boundary objects.
+
+What it replaces:
+  * `get_modified_sam2(...)` -> model with `.load_state_dict`, `.eval`, `.sam2_model.image_size`,
+    `__call__(x[B,3,1024,1024]) -> (high_res[B,1,1024,1024], low_res[B,1,256,256], iou[B,1])`
+    (/root/reference/src/sam2_infer.py:277-410, :220-275; caller circuit_analyzer.py:203-242, :349-351)
+  * `SAM2Transforms(resolution, mask_threshold, max_hole_area, max_sprinkle_area)` with `__call__`
+    and `postprocess_masks` (sam2_infer.py:29-128; caller circuit_analyzer.py:245-250, :347, :354)
+  * `infer_masks(images)`: the batched entry point named by BASELINE.json's north_star.
+
+Weight preparation (host, fp32, once): LoRA adapters merged (W' = W + (alpha/r) B A, rows B12); the
+FPN lateral convs composed with conv_s0 / conv_s1 (no 256-channel 256^2 map is ever materialised);
+FPN level 2 = lateral(stage 3) + nearest-2x lateral(stage 4) as ONE two-source GEMM with the learned
+dense prompt added in its epilogue; every "+ positional encoding" of the two-way transformer folded
+into constant post-projection residuals; Hiera's bicubic position embedding precomputed.
+
+Numerics: the residual stream, LayerNorm statistics, softmax and all accumulators are fp32; in F16
+mode GEMM / attention operands are fp16.  F32 mode runs everything on exact-f32 MFMA (parity mode).
+"""
+import hashlib
+import math
+import threading
+
+import numpy as np
+import torch
+import torch.nn.functional as TF
+
+from . import _lib
+from ._lib import ACT_GELU, ACT_NONE, ACT_RELU, ACT_SIGMOID, F16, F32
+from .engine import (ESIZE, TORCH_DTYPE, Buf, PackedConv, Plan, Rows, make_attn_desc, op_attention, op_call, op_cast, op_conv,
+                     op_layernorm, op_maxpool2, require_gpu)
+
+HIERA_L = dict(embed_dim=144, num_heads=2, stages=(2, 6, 36, 4), global_att_blocks=(23, 33, 43), window_spec=(8, 4, 16, 8))
+HIERA_T = dict(embed_dim=96, num_heads=1, stages=(1, 2, 7, 2), global_att_blocks=(5, 7, 9), window_spec=(8, 4, 14, 7))
+
+# circuit_analyzer.py:156-199 -- the 36 LoRA-wrapped modules of the fine-tuned checkpoint
+LORA_TARGETS_REFERENCE = (
+    [f"sam_mask_decoder.transformer.layers.{l}.{a}.{p}" for l in (0, 1) for a in ("self_attn", "cross_attn_token_to_image")
+     for p in ("k_proj", "q_proj", "v_proj", "out_proj")]
+    + [f"sam_mask_decoder.transformer.layers.{l}.mlp.layers.{j}" for l in (0, 1) for j in (0, 1)]
+    + ["sam_mask_decoder.iou_prediction_head.layers.2", "sam_mask_decoder.conv_s0", "sam_mask_decoder.conv_s1",
+       "image_encoder.neck.convs.2.conv", "image_encoder.neck.convs.3.conv",
+       "image_encoder.trunk.blocks.44.attn.qkv", "image_encoder.trunk.blocks.44.mlp.layers.0", "image_encoder.trunk.blocks.44.proj",
+       "image_encoder.trunk.blocks.47.attn.qkv", "image_encoder.trunk.blocks.47.mlp.layers.0"]
+    + [f"sam_mask_decoder.transformer.layers.{l}.cross_attn_image_to_token.{p}" for l in (0, 1) for p in ("q_proj", "k_proj", "v_proj")])
+
+
+# ---- parameter sources ---------------------------------------------------------------------------------
+class SamSyntheticParams:
+    """Seeded synthetic weights in the fine-tuned checkpoint's own key format (PEFT names for LoRA
+    targets, wrapper parameters at the top level).  `state_dict()` loads strictly into the oracle."""
+
+    def __init__(self, seed=0, lora_targets=LORA_TARGETS_REFERENCE, r=4, alpha=16, std=0.02):
+        self.seed, self.targets, self.r, self.scaling, self.std, self.sd = seed, set(lora_targets), r, alpha / r, std, {}
+
+    def _t(self, name, shape, kind="w"):
+        if name in self.sd:
+            assert tuple(self.sd[name].shape) == tuple(shape), (name, self.sd[name].shape, shape)
+            return self.sd[name]
+        h = int.from_bytes(hashlib.sha256(f"{self.seed}:{name}".encode()).digest()[:8], "little") & 0x7FFFFFFFFFFFFFFF
+        g = torch.Generator().manual_seed(h)
+        if kind == "gamma":
+            t = torch.empty(shape).uniform_(0.8, 1.2, generator=g)
+        elif kind == "unit":
+            t = torch.empty(shape).normal_(0, 1.0, generator=g)
+        elif kind == "refine":
+            t = torch.empty(shape).normal_(0, 0.2, generator=g)
+        else:
+            t = torch.empty(shape).normal_(0, self.std, generator=g).clamp_(-2 * self.std, 2 * self.std)
+        self.sd[name] = t
+        return t
+
+    def weight(self, mod, shape):
+        """Merged weight of module `mod` (Linear [out,in] or Conv [out,in,kh,kw])."""
+        if mod in self.targets:
+            w = self._t(f"{mod}.base_layer.weight", shape)
+            a_shape = (self.r, shape[1]) + tuple(shape[2:])
+            b_shape = (shape[0], self.r) + (1,) * (len(shape) - 2)
+            A = self._t(f"{mod}.lora_A.default.weight", a_shape)
+            Bm = self._t(f"{mod}.lora_B.default.weight", b_shape)
+            delta = (Bm.reshape(shape[0], self.r) @ A.reshape(self.r, -1)).reshape(shape)
+            return w + self.scaling * delta
+        return self._t(f"{mod}.weight", shape)
+
+    def bias(self, mod, n):
+        return self._t(f"{mod}.base_layer.bias" if mod in self.targets else f"{mod}.bias", (n,))
+
+    def tensor(self, name, shape, kind="w"):
+        return self._t(name, shape, kind)
+
+    def state_dict(self):
+        return dict(self.sd)
+
+
+class SamStateDictParams:
+    """A real checkpoint: flat state_dict (optionally under 'state_dict'), PEFT key names with the
+    `sam2_model.base_model.model.` prefix (sam2_infer.py:396), wrapper parameters at the top level."""
+
+    PREFIXES = ("sam2_model.base_model.model.", "sam2_model.")
+
+    def __init__(self, sd, r=4, alpha=16):
+        self.scaling = alpha / r
+        self.sd = {}
+        for k, v in sd.items():
+            for p in self.PREFIXES:
+                if k.startswith(p):
+                    k = k[len(p):]
+                    break
+            self.sd[k] = v.detach().float().cpu()
+
+    def _get(self, name, shape):
+        t = self.sd[name]
+        if tuple(t.shape) != tuple(shape):
+            raise ValueError(f"{name}: checkpoint shape {tuple(t.shape)} != expected {tuple(shape)}")
+        return t
+
+    def weight(self, mod, shape):
+        if f"{mod}.base_layer.weight" in self.sd:
+            w = self._get(f"{mod}.base_layer.weight", shape)
+            A, Bm = self.sd[f"{mod}.lora_A.default.weight"], self.sd[f"{mod}.lora_B.default.weight"]
+            r = A.shape[0]
+            return w + self.scaling * (Bm.reshape(shape[0], r) @ A.reshape(r, -1)).reshape(shape)
+        return self._get(f"{mod}.weight", shape)
+
+    def bias(self, mod, n):
+        k = f"{mod}.base_layer.bias" if f"{mod}.base_layer.bias" in self.sd else f"{mod}.bias"
+        return self._get(k, (n,))
+
+    def tensor(self, name, shape, kind="w"):
+        return self._get(name, shape)
+
+
+# ---- prepared weights -----------------------------------------------------------------------------------------
+def _lin(w):
+    return w.reshape(w.shape[0], w.shape[1], 1, 1)
+
+
+class Sam2Weights:
+    def __init__(self, params, hiera=HIERA_L, image_size=1024, dtype=F16, device="cuda", use_refinement=True,
+                 refinement_kernels=(3, 5, 7, 11), embedding_r=4):
+        self.p, self.hiera, self.image_size, self.dtype, self.device = params, hiera, image_size, dtype, device
+        self.use_refinement, self.kernels = use_refinement, tuple(refinement_kernels)
+        self.pc, self.ln, self.const = {}, {}, {}
+        self.param_bytes = 0
+        self.flops_per_image = 0
+        self._trunk()
+        self._neck_and_prompts(embedding_r)
+        self._decoder()
+        self._refinement()
+
+    # -- helpers
+    def _pack(self, key, w4, b):
+        pc = PackedConv(w4, b, self.dtype, self.device)
+        self.pc[key] = pc
+        self.param_bytes += pc.param_bytes
+        return pc
+
+    def _linear(self, key, mod, cout, cin):
+        return self._pack(key, _lin(self.p.weight(mod, (cout, cin))), self.p.bias(mod, cout))
+
+    def _norm(self, key, mod, c):
+        self.ln[key] = (self.p.tensor(f"{mod}.weight", (c,), "gamma").float().to(self.device),
+                        self.p.tensor(f"{mod}.bias", (c,)).float().to(self.device))
+
+    def _trunk(self):
+        h = self.hiera
+        E, stages, ws = h["embed_dim"], h["stages"], h["window_spec"]
+        T = "image_encoder.trunk"
+        self._pack("patch_embed", self.p.weight(f"{T}.patch_embed.proj", (E, 3, 7, 7)), self.p.bias(f"{T}.patch_embed.proj", E))
+        g = self.image_size // 4
+        pos = TF.interpolate(self.p.tensor(f"{T}.pos_embed", (1, E, 7, 7)), size=(g, g), mode="bicubic")
+        win = self.p.tensor(f"{T}.pos_embed_window", (1, E, ws[0], ws[0]))
+        pos = pos + win.tile([1, 1, g // ws[0], g // ws[0]])
+        self.const["pos_embed"] = pos.permute(0, 2, 3, 1).reshape(g * g, E).contiguous().float().to(self.device)   # f32 residual stream
+        stage_ends = [sum(stages[:i]) - 1 for i in range(1, len(stages) + 1)]
+        q_pool_blocks = [x + 1 for x in stage_ends[:-1]][:3]
+        self.blocks, self.stage_ends = [], stage_ends
+        cur, dim, heads = 1, E, h["num_heads"]
+        for i in range(sum(stages)):
+            dim_out, window = dim, ws[cur - 1]
+            if i in h["global_att_blocks"]:
+                window = 0
+            if i - 1 in stage_ends:
+                dim_out, heads, cur = dim * 2, heads * 2, cur + 1
+            b = f"{T}.blocks.{i}"
+            self._norm(f"b{i}.norm1", f"{b}.norm1", dim)
+            self._linear(f"b{i}.qkv", f"{b}.attn.qkv", 3 * dim_out, dim)
+            self._linear(f"b{i}.proj", f"{b}.attn.proj", dim_out, dim_out)
+            self._norm(f"b{i}.norm2", f"{b}.norm2", dim_out)
+            self._linear(f"b{i}.fc1", f"{b}.mlp.layers.0", 4 * dim_out, dim_out)
+            self._linear(f"b{i}.fc2", f"{b}.mlp.layers.1", dim_out, 4 * dim_out)
+            if dim != dim_out:
+                self._linear(f"b{i}.dimproj", f"{b}.proj", dim_out, dim)
+            self.blocks.append(dict(dim=dim, dim_out=dim_out, heads=heads, window=window, q_pool=i in q_pool_blocks))
+            if window > 0 and i in q_pool_blocks and window % 2:
+                raise ValueError("q-pool block with odd window")
+            dim = dim_out
+        self.stage_dims = [E * 2 ** s for s in range(len(stages))]
+
+    def _neck_and_prompts(self, embedding_r):
+        N, D = "image_encoder.neck", "sam_mask_decoder"
+        c = self.stage_dims                                   # [144, 288, 576, 1152]
+        wn = [self.p.weight(f"{N}.convs.{j}.conv", (256, c[3 - j], 1, 1)).reshape(256, -1) for j in range(4)]
+        bn = [self.p.bias(f"{N}.convs.{j}.conv", 256) for j in range(4)]
+        ws0, bs0 = self.p.weight(f"{D}.conv_s0", (32, 256, 1, 1)).reshape(32, 256), self.p.bias(f"{D}.conv_s0", 32)
+        ws1, bs1 = self.p.weight(f"{D}.conv_s1", (64, 256, 1, 1)).reshape(64, 256), self.p.bias(f"{D}.conv_s1", 64)
+        # level 0 (256^2, 144 ch): conv_s0 o lateral ; level 1 (128^2, 288 ch): conv_s1 o lateral
+        self._pack("feat_s0", _lin(ws0 @ wn[3]), ws0 @ bn[3] + bs0)
+        self._pack("feat_s1", _lin(ws1 @ wn[2]), ws1 @ bn[2] + bs1)
+        # level 2 (64^2): lateral(stage 3, 576) + nearest2x(lateral(stage 4, 1152)) as one K-concatenated GEMM
+        self._pack("embed", _lin(torch.cat((wn[1], wn[0]), 1)), bn[1] + bn[0])
+        fs = self.image_size // 16
+        e1 = self.p.tensor("dense_embedding1", (1, 256, embedding_r), "unit")
+        e2 = self.p.tensor("dense_embedding2", (1, embedding_r, fs * fs), "unit")
+        dense = (e1 @ e2).view(256, fs * fs).t().contiguous()                       # [pixels, 256]  (sam2_infer.py:250)
+        self.const["dense"] = dense.float().to(self.device)
+        G = self.p.tensor("sam_prompt_encoder.pe_layer.positional_encoding_gaussian_matrix", (2, 128), "unit")
+        yy, xx = torch.meshgrid((torch.arange(fs, dtype=torch.float32) + 0.5) / fs, (torch.arange(fs, dtype=torch.float32) + 0.5) / fs, indexing="ij")
+        cpe = 2 * math.pi * ((2 * torch.stack((xx, yy), -1) - 1) @ G)
+        self.key_pe = torch.cat((torch.sin(cpe), torch.cos(cpe)), -1).reshape(fs * fs, 256)      # get_dense_pe(), [pixels, 256]
+        self.sparse = self.p.tensor("sparse_embedding", (1, 32, 256), "unit")[0]
+
+    def _attn(self, key, mod, inner, q_pe=None, k_pe=None):
+        """One Attention module.  q / k / v projections packed separately; constants (x + pe) W^T folded."""
+        d = {}
+        for nm in ("q_proj", "k_proj", "v_proj"):
+            d[nm] = (self.p.weight(f"{mod}.{nm}", (inner, 256)), self.p.bias(f"{mod}.{nm}", inner))
+        self._linear(f"{key}.out", f"{mod}.out_proj", 256, inner)
+        return d
+
+    def _decoder(self):
+        D = "sam_mask_decoder"
+        dev, od = self.device, TORCH_DTYPE[self.dtype]
+        tokens = torch.cat((self.p.tensor(f"{D}.obj_score_token.weight", (1, 256), "unit"), self.p.tensor(f"{D}.iou_token.weight", (1, 256), "unit"),
+                            self.p.tensor(f"{D}.mask_tokens.weight", (4, 256), "unit"), self.sparse), 0)          # [38, 256]
+        self.tokens = tokens
+        self.const["tokens"] = tokens.float().to(dev)
+        kpe = self.key_pe
+        self.n_tok = tokens.shape[0]
+
+        def cres(t):                       # constant residual in the GEMM's output dtype
+            return t.contiguous().to(od).to(dev)
+
+        for l in (0, 1):
+            L = f"{D}.transformer.layers.{l}"
+            # self attention: q, k (+ token pe unless layer 0), v from the same queries -> one GEMM of N = 768
+            sa = self._attn(f"l{l}.sa", f"{L}.self_attn", 256)
+            w = torch.cat([sa[n][0] for n in ("q_proj", "k_proj", "v_proj")], 0)
+            b = torch.cat([sa[n][1] for n in ("q_proj", "k_proj", "v_proj")], 0)
+            self._pack(f"l{l}.sa.qkv", _lin(w), b)
+            if l > 0:
+                pe = torch.cat((tokens @ sa["q_proj"][0].t(), tokens @ sa["k_proj"][0].t(), torch.zeros(self.n_tok, 256)), 1)
+                self.const[f"l{l}.sa.qkv_pe"] = cres(pe)
+            self._norm(f"l{l}.norm1", f"{L}.norm1", 256)
+            # token -> image cross attention (internal dim 128)
+            t2i = self._attn(f"l{l}.t2i", f"{L}.cross_attn_token_to_image", 128)
+            self._pack(f"l{l}.t2i.q", _lin(t2i["q_proj"][0]), t2i["q_proj"][1])
+            self.const[f"l{l}.t2i.q_pe"] = cres(tokens @ t2i["q_proj"][0].t())
+            self._pack(f"l{l}.t2i.kv", _lin(torch.cat((t2i["k_proj"][0], t2i["v_proj"][0]), 0)), torch.cat((t2i["k_proj"][1], t2i["v_proj"][1]), 0))
+            self.const[f"l{l}.t2i.kv_pe"] = cres(torch.cat((kpe @ t2i["k_proj"][0].t(), torch.zeros(kpe.shape[0], 128)), 1))
+            self._norm(f"l{l}.norm2", f"{L}.norm2", 256)
+            self._linear(f"l{l}.mlp1", f"{L}.mlp.layers.0", 2048, 256)
+            self._linear(f"l{l}.mlp2", f"{L}.mlp.layers.1", 256, 2048)
+            self._norm(f"l{l}.norm3", f"{L}.norm3", 256)
+            # image -> token cross attention: q from keys (+ key pe), k from queries (+ token pe), v from queries
+            i2t = self._attn(f"l{l}.i2t", f"{L}.cross_attn_image_to_token", 128)
+            self._pack(f"l{l}.i2t.q", _lin(i2t["q_proj"][0]), i2t["q_proj"][1])
+            self.const[f"l{l}.i2t.q_pe"] = cres(kpe @ i2t["q_proj"][0].t())
+            self._pack(f"l{l}.i2t.kv", _lin(torch.cat((i2t["k_proj"][0], i2t["v_proj"][0]), 0)), torch.cat((i2t["k_proj"][1], i2t["v_proj"][1]), 0))
+            self.const[f"l{l}.i2t.kv_pe"] = cres(torch.cat((tokens @ i2t["k_proj"][0].t(), torch.zeros(self.n_tok, 128)), 1))
+            self._norm(f"l{l}.norm4", f"{L}.norm4", 256)
+        F_ = f"{D}.transformer.final_attn_token_to_image"
+        fa = self._attn("final", F_, 128)
+        self._pack("final.q", _lin(fa["q_proj"][0]), fa["q_proj"][1])
+        self.const["final.q_pe"] = cres(tokens @ fa["q_proj"][0].t())
+        self._pack("final.kv", _lin(torch.cat((fa["k_proj"][0], fa["v_proj"][0]), 0)), torch.cat((fa["k_proj"][1], fa["v_proj"][1]), 0))
+        self.const["final.kv_pe"] = cres(torch.cat((kpe @ fa["k_proj"][0].t(), torch.zeros(kpe.shape[0], 128)), 1))
+        self._norm("norm_final", f"{D}.transformer.norm_final_attn", 256)
+        # upscaling: ConvTranspose2d(k=2, s=2) weights [Cin, Cout, 2, 2] -> GEMM rows n = (dy*2+dx)*Cout + co
+        for key, mod, cin, cout in (("up1", f"{D}.output_upscaling.0", 256, 64), ("up2", f"{D}.output_upscaling.3", 64, 32)):
+            w = self.p.weight(mod, (cin, cout, 2, 2))
+            b = self.p.bias(mod, cout)
+            self._pack(key, _lin(w.permute(2, 3, 1, 0).reshape(4 * cout, cin)), b.repeat(4))
+        self._norm("up_ln", f"{D}.output_upscaling.1", 64)
+        for i in range(4):
+            for j, (co, ci) in enumerate(((256, 256), (256, 256), (32, 256))):
+                self._linear(f"hyper{i}.{j}", f"{D}.output_hypernetworks_mlps.{i}.layers.{j}", co, ci)
+        for j, (co, ci) in enumerate(((256, 256), (256, 256), (4, 256))):
+            self._linear(f"iou.{j}", f"{D}.iou_prediction_head.layers.{j}", co, ci)
+        for j, (co, ci) in enumerate(((256, 256), (256, 256), (1, 256))):     # pred_obj_score_head: loaded (strictness), unused by the wrapper
+            self.p.weight(f"{D}.pred_obj_score_head.layers.{j}", (co, ci)); self.p.bias(f"{D}.pred_obj_score_head.layers.{j}", co)
+
+    def _refinement(self):
+        if not self.use_refinement:
+            self.refine_params = None
+            return
+        parts = []
+        for j, k in enumerate(self.kernels):
+            parts.append(self.p.tensor(f"refinement_layer.conv_branches.{j}.weight", (4, 1, k, k), "refine").reshape(-1))
+            parts.append(self.p.tensor(f"refinement_layer.conv_branches.{j}.bias", (4,), "refine"))
+        parts.append(self.p.tensor("refinement_layer.combiner_conv.weight", (1, 4 * len(self.kernels), 1, 1), "refine").reshape(-1))
+        parts.append(self.p.tensor("refinement_layer.combiner_conv.bias", (1,), "refine"))
+        self.refine_params = torch.cat([t.float() for t in parts]).to(self.device)
+
+
+class Sam2Plan:
+    """Launch plan for B images: x [B, R, R, 3] (NHWC, normalised) -> high_res, low_res, iou."""
+
+    def __init__(self, wt, B, stream, dynamic_multimask_via_stability=True):
+        self.wt, self.B, self.dt, self.dev = wt, B, wt.dtype, wt.device
+        self.plan = Plan(stream)
+        self.pool = {}
+        self.dynamic = dynamic_multimask_via_stability
+        self.act_bytes = 0
+        self._build()
+        torch.cuda.synchronize()
+
+    def buf(self, H, W, C, dtype=None, tag=None):
+        """Scratch buffers are shared between blocks of equal shape (launches are stream-ordered)."""
+        dtype = self.dt if dtype is None else dtype
+        key = (H, W, C, dtype, tag)
+        if tag is None or key not in self.pool:
+            b = Buf(self.B, H, W, C, dtype, self.dev)
+            self.act_bytes += b.nbytes
+            if tag is None:
+                return b
+            self.pool[key] = b
+        return self.pool[key]
+
+    def gemm(self, label, key, src, dst, act=ACT_NONE, res=None, kind="gemm", **kw):
+        srcs = src if isinstance(src, list) else [(src, 0)]
+        op_conv(self.plan, label, self.wt.pc[key], srcs, dst, act=act, res=res, kind=kind, **kw)
+
+    def _build(self):
+        wt, B = self.wt, self.B
+        R = wt.image_size
+        g = R // 4
+        self.x_in = Buf(B, R, R, 3, self.dt, self.dev, zero=True)
+        E = wt.hiera["embed_dim"]
+        x = self.buf(g, g, E, F32)
+        pos = wt.const["pos_embed"]
+        self.plan.keep.append(pos)
+        op_conv(self.plan, "patch_embed", wt.pc["patch_embed"], [(self.x_in.view(), 0)], x.view(), stride=4, pad=3,
+                res=_ConstView(pos, E), res_mod=g * g, scalar_gather=True, kind="stem")
+        H = W = g
+        stage_out = []
+        for i, blk in enumerate(wt.blocks):
+            x, H, W = self._block(i, blk, x, H, W)
+            if i in wt.stage_ends:
+                stage_out.append(x)
+        self.stage_out = stage_out
+        self._neck_decoder(stage_out)
+
+    # ---- one Hiera block ---------------------------------------------------------------------------------
+    def _block(self, i, blk, x, H, W):
+        wt, B = self.wt, self.B
+        dim, dout, heads, ws = blk["dim"], blk["dim_out"], blk["heads"], blk["window"]
+        hd = dout // heads
+        gam, bet = wt.ln[f"b{i}.norm1"]
+        xn = self.buf(H, W, dim, tag="xn")
+        op_layernorm(self.plan, f"b{i}.norm1", x.view(), gam, bet, xn.view(), 1e-6)
+        if blk["q_pool"] and (ws == 0 or H % ws or W % ws):
+            raise NotImplementedError("q-pool block needs a window that divides the grid")
+        if ws > 0 and (H % ws or W % ws):
+            raise NotImplementedError(f"block {i}: window {ws} does not divide the {H}x{W} grid (padded windows: Hiera-T) -- not on the GPU path yet")
+        if dim != dout:
+            pj = self.buf(H, W, dout, F32, tag="dimproj")
+            self.gemm(f"b{i}.dimproj", f"b{i}.dimproj", xn.view(), pj.view())
+            short = self.buf(H // 2, W // 2, dout, F32)
+            op_maxpool2(self.plan, f"b{i}.pool", pj.view(), short.view())
+        else:
+            short = x
+        qkv = self.buf(H, W, 3 * dout, tag="qkv")
+        self.gemm(f"b{i}.qkv", f"b{i}.qkv", xn.view(), qkv.view())
+        OH, OW = (H // 2, W // 2) if blk["q_pool"] else (H, W)
+        ao = self.buf(OH, OW, dout, tag="ao")
+        es = ESIZE[self.dt]
+        base = qkv.t.data_ptr()
+        C3 = 3 * dout
+        if ws > 0:
+            nwin = B * (H // ws) * (W // ws)
+            nq = (ws // 2) ** 2 if blk["q_pool"] else ws * ws
+            desc = make_attn_desc(q=base, k=base + dout * es, v=base + 2 * dout * es, o=ao.t.data_ptr(),
+                                  q_sb=0, q_sh=hd, q_st=C3, k_sb=0, k_sh=hd, k_st=C3, v_sb=0, v_sh=hd, v_st=C3,
+                                  o_sb=0, o_sh=hd, o_st=dout, B=nwin, heads=heads, Nq=nq, Nk=ws * ws, dqk=hd, dv=hd,
+                                  scale=hd ** -0.5, dtype=self.dt, win=ws, grid_h=H, grid_w=W, q_pool=1 if blk["q_pool"] else 0)
+            fl = 4 * nwin * heads * nq * ws * ws * hd
+        else:
+            N = H * W
+            desc = make_attn_desc(q=base, k=base + dout * es, v=base + 2 * dout * es, o=ao.t.data_ptr(),
+                                  q_sb=N * C3, q_sh=hd, q_st=C3, k_sb=N * C3, k_sh=hd, k_st=C3, v_sb=N * C3, v_sh=hd, v_st=C3,
+                                  o_sb=N * dout, o_sh=hd, o_st=dout, B=B, heads=heads, Nq=N, Nk=N, dqk=hd, dv=hd,
+                                  scale=hd ** -0.5, dtype=self.dt, win=0, grid_h=0, grid_w=0, q_pool=0)
+            fl = 4 * B * heads * N * N * hd
+        op_attention(self.plan, f"b{i}.attn", desc, (qkv, ao), bytes_=qkv.nbytes + ao.nbytes, flops=fl)
+        self.plan.ops[-1] = (self.plan.ops[-1][0], "attn_global" if ws == 0 else "attn_window") + self.plan.ops[-1][2:]
+        # x = shortcut + proj(attn)   (in place on the f32 residual stream)
+        self.gemm(f"b{i}.proj", f"b{i}.proj", ao.view(), short.view(), res=short.view())
+        x = short
+        gam, bet = wt.ln[f"b{i}.norm2"]
+        xn2 = self.buf(OH, OW, dout, tag="xn")
+        op_layernorm(self.plan, f"b{i}.norm2", x.view(), gam, bet, xn2.view(), 1e-6)
+        hid = self.buf(OH, OW, 4 * dout, tag="hid")
+        self.gemm(f"b{i}.fc1", f"b{i}.fc1", xn2.view(), hid.view(), act=ACT_GELU)
+        self.gemm(f"b{i}.fc2", f"b{i}.fc2", hid.view(), x.view(), res=x.view())
+        if i in self.wt.stage_ends and i != len(self.wt.blocks) - 1:
+            # the next block writes its own shortcut buffer (dim change) -> x stays intact as the stage output
+            pass
+        return x, OH, OW
+
+    # ---- neck + mask decoder + tail -------------------------------------------------------------------------
+    def _neck_decoder(self, st):
+        wt, B, dt = self.wt, self.B, self.dt
+        R = wt.image_size
+        f0, f1, fs = R // 4, R // 8, R // 16
+        # GEMM operands in compute dtype (stage outputs are f32 residual streams)
+        def cast(buf, tag):
+            if dt == F32:
+                return buf
+            o = self.buf(buf.H, buf.W, buf.C, dt)
+            op_cast(self.plan, f"cast.{tag}", buf.view(), o.view())
+            return o
+        s0, s1, s2, s3 = (cast(b, f"s{j}") for j, b in enumerate(st))
+        feat_s0 = self.buf(f0, f0, 32)
+        feat_s1 = self.buf(f1, f1, 64)
+        self.gemm("feat_s0", "feat_s0", s0.view(), feat_s0.view(), kind="neck")
+        self.gemm("feat_s1", "feat_s1", s1.view(), feat_s1.view(), kind="neck")
+        # src = FPN level 2 + learned dense prompt   (f32: it is the decoder's residual stream "keys")
+        keys = self.buf(fs, fs, 256, F32)
+        dense = wt.const["dense"]
+        self.gemm("embed", "embed", [(s2.view(), 0), (s3.view(), 1)], keys.view(), res=_ConstView(dense, 256), res_mod=fs * fs, kind="neck")
+        self.feat_s0, self.feat_s1, self.keys0 = feat_s0, feat_s1, keys
+        P, T = fs * fs, wt.n_tok
+        # token stream (f32).  Layer 0 reads the constant tokens (qn0) and REPLACES the stream, so it needs no init.
+        q = Buf(B, 1, T, 256, F32, self.dev, zero=True)
+        lib = _lib.load()
+        qn0 = Buf(B, 1, T, 256, dt, self.dev)
+        qn0.t.copy_(wt.const["tokens"].to(TORCH_DTYPE[dt]).view(1, 1, T, 256).expand(B, 1, T, 256))
+
+        def ln(label, key, src, dst):
+            gam, bet = wt.ln[key]
+            op_layernorm(self.plan, label, src.view(), gam, bet, dst.view(), 1e-5)
+
+        def attention(label, qb, q_off, kb, k_off, vb, v_off, ob, Nq, Nk, hd):
+            es = ESIZE[dt]
+            desc = make_attn_desc(q=qb.t.data_ptr() + q_off * es, k=kb.t.data_ptr() + k_off * es, v=vb.t.data_ptr() + v_off * es, o=ob.t.data_ptr(),
+                                  q_sb=Nq * qb.C, q_sh=hd, q_st=qb.C, k_sb=Nk * kb.C, k_sh=hd, k_st=kb.C, v_sb=Nk * vb.C, v_sh=hd, v_st=vb.C,
+                                  o_sb=Nq * ob.C, o_sh=hd, o_st=ob.C, B=B, heads=8, Nq=Nq, Nk=Nk, dqk=hd, dv=hd, scale=hd ** -0.5, dtype=dt,
+                                  win=0, grid_h=0, grid_w=0, q_pool=0)
+            op_attention(self.plan, label, desc, (qb, kb, vb, ob), flops=4 * B * 8 * Nq * Nk * hd)
+            self.plan.ops[-1] = (self.plan.ops[-1][0], "decoder") + self.plan.ops[-1][2:]
+
+        qn = self.buf(1, T, 256, tag="qn")           # compute-dtype copies of the f32 streams
+        kn = self.buf(fs, fs, 256, tag="kn")
+        G = lambda *a, **k: self.gemm(*a, kind="decoder", **k)
+        for l in (0, 1):
+            p = f"l{l}"
+            # --- self attention on the tokens
+            qkv = self.buf(1, T, 768, tag="sa_qkv")
+            if l == 0:
+                G(f"{p}.sa.qkv", f"{p}.sa.qkv", qn0.view(), qkv.view())
+            else:
+                op_cast(self.plan, f"{p}.sa.cast", q.view(), qn.view())
+                G(f"{p}.sa.qkv", f"{p}.sa.qkv", qn.view(), qkv.view(), res=_ConstView(wt.const[f"{p}.sa.qkv_pe"], 768), res_mod=T)
+            ao = self.buf(1, T, 256, tag="sa_ao")
+            attention(f"{p}.sa.attn", qkv, 0, qkv, 256, qkv, 512, ao, T, T, 32)
+            if l == 0:
+                G(f"{p}.sa.out", f"{p}.sa.out", ao.view(), q.view())                         # layer 0: queries REPLACED (skip_first_layer_pe)
+            else:
+                G(f"{p}.sa.out", f"{p}.sa.out", ao.view(), q.view(), res=q.view())
+            ln(f"{p}.norm1", f"{p}.norm1", q, q)
+            # --- tokens attend to the image
+            op_cast(self.plan, f"{p}.t2i.castq", q.view(), qn.view())
+            op_cast(self.plan, f"{p}.t2i.castk", keys.view(), kn.view())
+            tq = self.buf(1, T, 128, tag="t2i_q")
+            G(f"{p}.t2i.q", f"{p}.t2i.q", qn.view(), tq.view(), res=_ConstView(wt.const[f"{p}.t2i.q_pe"], 128), res_mod=T)
+            kv = self.buf(fs, fs, 256, tag="t2i_kv")
+            G(f"{p}.t2i.kv", f"{p}.t2i.kv", kn.view(), kv.view(), res=_ConstView(wt.const[f"{p}.t2i.kv_pe"], 256), res_mod=P)
+            ao2 = self.buf(1, T, 128, tag="t2i_ao")
+            attention(f"{p}.t2i.attn", tq, 0, kv, 0, kv, 128, ao2, T, P, 16)
+            G(f"{p}.t2i.out", f"{p}.t2i.out", ao2.view(), q.view(), res=q.view())
+            ln(f"{p}.norm2", f"{p}.norm2", q, q)
+            # --- MLP on the tokens
+            op_cast(self.plan, f"{p}.mlp.cast", q.view(), qn.view())
+            hid = self.buf(1, T, 2048, tag="mlp_hid")
+            G(f"{p}.mlp1", f"{p}.mlp1", qn.view(), hid.view(), act=ACT_RELU)
+            G(f"{p}.mlp2", f"{p}.mlp2", hid.view(), q.view(), res=q.view())
+            ln(f"{p}.norm3", f"{p}.norm3", q, q)
+            # --- image attends to the tokens
+            op_cast(self.plan, f"{p}.i2t.castq", q.view(), qn.view())
+            iq = self.buf(fs, fs, 128, tag="i2t_q")
+            G(f"{p}.i2t.q", f"{p}.i2t.q", kn.view(), iq.view(), res=_ConstView(wt.const[f"{p}.i2t.q_pe"], 128), res_mod=P)
+            ikv = self.buf(1, T, 256, tag="i2t_kv")
+            G(f"{p}.i2t.kv", f"{p}.i2t.kv", qn.view(), ikv.view(), res=_ConstView(wt.const[f"{p}.i2t.kv_pe"], 256), res_mod=T)
+            ao3 = self.buf(fs, fs, 128, tag="i2t_ao")
+            attention(f"{p}.i2t.attn", iq, 0, ikv, 0, ikv, 128, ao3, P, T, 16)
+            G(f"{p}.i2t.out", f"{p}.i2t.out", ao3.view(), keys.view(), res=keys.view())
+            ln(f"{p}.norm4", f"{p}.norm4", keys, keys)
+        # --- final token -> image attention
+        op_cast(self.plan, "final.castq", q.view(), qn.view())
+        op_cast(self.plan, "final.castk", keys.view(), kn.view())
+        tq = self.buf(1, T, 128, tag="t2i_q")
+        G("final.q", "final.q", qn.view(), tq.view(), res=_ConstView(wt.const["final.q_pe"], 128), res_mod=T)
+        kv = self.buf(fs, fs, 256, tag="t2i_kv")
+        G("final.kv", "final.kv", kn.view(), kv.view(), res=_ConstView(wt.const["final.kv_pe"], 256), res_mod=P)
+        ao2 = self.buf(1, T, 128, tag="t2i_ao")
+        attention("final.attn", tq, 0, kv, 0, kv, 128, ao2, T, P, 16)
+        G("final.out", "final.out", ao2.view(), q.view(), res=q.view())
+        ln("norm_final", "norm_final", q, q)
+        self.tokens_out, self.keys_out = q, keys
+        # --- upscaling: act1(ln1(dc1(src) + s1)) ; act2(dc2(.) + s0)
+        u1 = self.buf(f1, f1, 64)
+        G("up1", "up1", kn.view(), u1.view(), res=feat_s1.view(), shuffle_cout=64)
+        gam, bet = wt.ln["up_ln"]
+        op_layernorm(self.plan, "up_ln", u1.view(), gam, bet, u1.view(), 1e-6, act=ACT_GELU)
+        u2 = self.buf(f0, f0, 32)
+        G("up2", "up2", u1.view(), u2.view(), res=feat_s0.view(), shuffle_cout=32, act=ACT_GELU, act_after_res=True)
+        self.up = u2
+        # --- hypernetwork MLPs on the 4 mask tokens, IoU head on the iou token (rows strided by T*256)
+        op_cast(self.plan, "heads.cast", q.view(), qn.view())
+        hyper = Buf(B, 1, 4, 32, F32, self.dev)
+        for i in range(4):
+            src = _RowsView(qn.t, B, 256, ld=T * 256, offset=(2 + i) * 256, dtype=dt)
+            h1 = self.buf(1, 1, 256, tag="h1"); h2 = self.buf(1, 1, 256, tag="h2")
+            G(f"hyper{i}.0", f"hyper{i}.0", src, h1.view(), act=ACT_RELU)
+            G(f"hyper{i}.1", f"hyper{i}.1", h1.view(), h2.view(), act=ACT_RELU)
+            G(f"hyper{i}.2", f"hyper{i}.2", h2.view(), _RowsView(hyper.t, B, 32, ld=128, offset=i * 32, dtype=F32))
+        iou4 = Buf(B, 1, 1, 4, F32, self.dev)
+        src = _RowsView(qn.t, B, 256, ld=T * 256, offset=256, dtype=dt)
+        h1 = self.buf(1, 1, 256, tag="h1"); h2 = self.buf(1, 1, 256, tag="h2")
+        G("iou.0", "iou.0", src, h1.view(), act=ACT_RELU)
+        G("iou.1", "iou.1", h1.view(), h2.view(), act=ACT_RELU)
+        G("iou.2", "iou.2", h2.view(), iou4.view(), act=ACT_SIGMOID)
+        self.hyper, self.iou4 = hyper, iou4
+        # --- masks, dynamic multimask selection, upsample + refinement
+        P0 = f0 * f0
+        self.masks4 = torch.empty(B, 4, f0, f0, dtype=torch.float32, device=self.dev)
+        self.areas = torch.zeros(B, 2, dtype=torch.int32, device=self.dev)
+        self.low_res = torch.empty(B, 1, f0, f0, dtype=torch.float32, device=self.dev)
+        self.iou = torch.empty(B, 1, dtype=torch.float32, device=self.dev)
+        self.sel = torch.zeros(B, dtype=torch.int32, device=self.dev)
+        self.high_res = torch.empty(B, 1, R, R, dtype=torch.float32, device=self.dev)
+        op_call(self.plan, "hyper_masks", "tail", lib.cvmi_hyper_masks,
+                (hyper.t.data_ptr(), 32, u2.t.data_ptr(), 32, dt, 32, self.masks4.data_ptr(), self.areas.data_ptr(), B, P0, 0.05),
+                keep=(hyper, u2), bytes_=B * P0 * (32 * ESIZE[dt] + 16), flops=2 * B * P0 * 128)
+        op_call(self.plan, "select_mask", "tail", lib.cvmi_select_mask,
+                (self.masks4.data_ptr(), self.areas.data_ptr(), iou4.t.data_ptr(), 4, 1 if self.dynamic else 0, 0.98, self.low_res.data_ptr(),
+                 self.iou.data_ptr(), self.sel.data_ptr(), B, P0), bytes_=B * P0 * 8)
+        if wt.refine_params is not None:
+            import ctypes as C
+            ks = (C.c_int * len(wt.kernels))(*wt.kernels)
+            taps = sum(k * k for k in wt.kernels)
+            op_call(self.plan, "upsample_refine", "tail", lib.cvmi_upsample_refine,
+                    (self.low_res.data_ptr(), B, f0, f0, self.high_res.data_ptr(), R, R, wt.refine_params.data_ptr(), ks, len(wt.kernels), 4),
+                    keep=(ks,), bytes_=B * (P0 + R * R) * 4, flops=2 * B * R * R * 4 * taps)
+        else:
+            op_call(self.plan, "upsample", "tail", lib.cvmi_bilinear_f32,
+                    (self.low_res.data_ptr(), B, f0, f0, self.high_res.data_ptr(), R, R, None, 0.0), bytes_=B * (P0 + R * R) * 4)
+
+class _ConstView:
+    """Constant [rows, C] device tensor posing as a residual View (ptr, ld)."""
+
+    def __init__(self, t, C):
+        self.t, self.c = t, C
+
+    ptr = property(lambda s: s.t.data_ptr())
+    ld = property(lambda s: s.c)
+
+
+class _RowsView:
+    """Strided row matrix posing as a [B,1,1,C] conv source / destination."""
+
+    def __init__(self, t, rows, C, ld, offset, dtype):
+        self.t, self.B, self.H, self.W, self.c, self._ld, self.off, self.dtype = t, rows, 1, 1, C, ld, offset, dtype
+
+    ptr = property(lambda s: s.t.data_ptr() + s.off * s.t.element_size())
+    ld = property(lambda s: s._ld)

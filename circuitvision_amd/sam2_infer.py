@@ -1,0 +1,179 @@
+"""Drop-in for the names the reference imports from its `src/sam2_infer.py`
+(`from .sam2_infer import SAM2Transforms, get_modified_sam2, device`, circuit_analyzer.py:17-21),
+backed by the cvmi355 HIP kernels.  See SURVEY.md 8(b) for the exact surface the callers rely on.
+"""
+import os
+import threading
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import F16, F32
+from .engine import TORCH_DTYPE, require_gpu
+from .sam2 import HIERA_L, Sam2Plan, Sam2Weights, SamStateDictParams, SamSyntheticParams
+
+# the reference picks its device at import time (sam2_infer.py:19-25); on PyTorch-ROCm "cuda" is the MI355X
+device = torch.device("cuda") if torch.cuda.is_available() else torch.device("cpu")
+
+
+def _hiera_from_yaml(path):
+    """Trunk hyper-parameters from a sam2 Hydra YAML (models/configs/sam2.1_hiera_l.yaml:9-16, :89)."""
+    import yaml
+    with open(path) as f:
+        cfg = yaml.safe_load(f)
+    m = cfg["model"]
+    t = m["image_encoder"]["trunk"]
+    hiera = dict(embed_dim=t.get("embed_dim", 96), num_heads=t.get("num_heads", 1), stages=tuple(t.get("stages", (2, 3, 16, 3))),
+                 global_att_blocks=tuple(t.get("global_att_blocks", (12, 16, 20))), window_spec=tuple(t.get("window_spec", (8, 4, 14, 7))))
+    return hiera, int(m.get("image_size", 1024))
+
+
+class SAM2Model:
+    """What `get_modified_sam2(...)` returns: `.load_state_dict`, `.eval`, `.sam2_model.image_size`,
+    `__call__(x) -> (high_res, low_res, iou)` (sam2_infer.py:220-275), plus `infer_masks`."""
+
+    def __init__(self, hiera=HIERA_L, image_size=1024, dtype="f16", dev="cuda", use_refinement=True, refinement_kernels=(3, 5, 7, 11),
+                 embedding_r=4, lora_rank=4, lora_alpha=16, dynamic_multimask_via_stability=True):
+        require_gpu()
+        self.hiera, self.image_size = hiera, image_size
+        self.dtype = {"f16": F16, "fp16": F16, "f32": F32, "fp32": F32}[dtype] if isinstance(dtype, str) else dtype
+        self.dev = dev
+        self.cfg = dict(use_refinement=use_refinement, refinement_kernels=tuple(refinement_kernels), embedding_r=embedding_r)
+        self.lora = (lora_rank, lora_alpha)
+        self.dynamic = dynamic_multimask_via_stability
+        self.sam2_model = SimpleNamespace(image_size=image_size)          # circuit_analyzer.py:237-240 reads .sam2_model.image_size
+        self.weights, self.params = None, None
+        self.stream = torch.cuda.Stream(device=dev)
+        self._plans = {}
+        self._lock = threading.Lock()                                       # one analyzer is shared across sessions (app.py:134)
+        self.training = False
+
+    # -- nn.Module-like surface the reference touches
+    def load_params(self, params):
+        self.params = params
+        with torch.cuda.device(self.dev):
+            self.weights = Sam2Weights(params, self.hiera, self.image_size, self.dtype, self.dev, **self.cfg)
+        self._plans.clear()
+        return self
+
+    def load_state_dict(self, sd, strict=True):
+        if "state_dict" in sd and not torch.is_tensor(sd["state_dict"]):
+            sd = sd["state_dict"]
+        return self.load_params(SamStateDictParams(sd, *self.lora))
+
+    def eval(self):
+        self.training = False
+        return self
+
+    def to(self, *_a, **_k):
+        return self
+
+    def plan(self, B):
+        if self.weights is None:
+            raise RuntimeError("SAM2 weights not loaded (call load_state_dict first)")
+        if B not in self._plans:
+            with torch.cuda.device(self.dev):
+                self._plans[B] = Sam2Plan(self.weights, B, self.stream, self.dynamic)
+        return self._plans[B]
+
+    def __call__(self, images, points=None, point_labels=None, masks_prompt=None, multimask_output=False):
+        if not (torch.is_tensor(images) and images.dim() == 4 and images.shape[1] == 3 and images.shape[2] == images.shape[3] == self.image_size):
+            raise ValueError(f"expected a [B,3,{self.image_size},{self.image_size}] tensor")
+        if multimask_output:
+            raise NotImplementedError("the wrapper always runs multimask_output=False (sam2_infer.py:257)")
+        lib = _lib.load()
+        B = images.shape[0]
+        with self._lock, torch.cuda.device(self.dev):
+            p = self.plan(B)
+            x = images.to(self.dev)
+            if x.dtype not in (torch.float32, torch.float16):
+                x = x.float()
+            src_dt = F32 if x.dtype == torch.float32 else F16
+            torch.cuda.current_stream().synchronize()
+            sp = self.stream.cuda_stream
+            if x.permute(0, 2, 3, 1).is_contiguous():            # already channels-last memory (SAM2Transforms output)
+                _lib.check(lib.cvmi_cast(x.data_ptr(), 3, src_dt, p.x_in.t.data_ptr(), 3, self.dtype, B * self.image_size ** 2, 3, sp), "cast")
+            else:
+                x = x.contiguous()
+                _lib.check(lib.cvmi_nchw_to_nhwc(x.data_ptr(), src_dt, p.x_in.t.data_ptr(), self.dtype, 3, B, 3, self.image_size, self.image_size, sp), "nchw_to_nhwc")
+            p.plan.run()
+            self.stream.synchronize()
+            return p.high_res.clone(), p.low_res.clone(), p.iou.clone()
+
+    forward = __call__
+
+    def infer_masks(self, images, boxes=None):
+        """Batched segmentation entry point (north_star): images [B,3,R,R]; boxes=None == SAM2ImageWrapper.forward."""
+        if boxes is not None:
+            raise NotImplementedError("box prompts (BASELINE configs 4-5, upstream semantics) are not built yet")
+        return self(images)
+
+
+def get_modified_sam2(model_cfg_path, checkpoint_path, device="cuda", use_high_res_features=True, use_peft=True, lora_rank=12,
+                      lora_alpha=16, lora_dropout=0.2, lora_target_modules=None, use_wrapper=True, trainable_embedding_r=4,
+                      use_refinement_layer=False, refinement_kernels=(3, 5, 7, 11), kernel_channels=4, dtype="f16", **_loss_and_optimizer_kwargs):
+    """Same signature as sam2_infer.py:277-305 (loss / optimizer kwargs accepted and ignored).  `checkpoint_path`
+    may be 'synthetic[:seed]' for seeded random weights; a real base checkpoint ({'model': state_dict}) is accepted
+    but every tensor is expected to come from the fine-tuned state dict loaded afterwards (circuit_analyzer.py:227-233)."""
+    if not use_wrapper or not use_high_res_features:
+        raise NotImplementedError("only the reference configuration (use_wrapper=True, use_high_res_features=True) is built")
+    hiera, image_size = HIERA_L, 1024
+    if isinstance(model_cfg_path, str) and os.path.exists(model_cfg_path):
+        hiera, image_size = _hiera_from_yaml(model_cfg_path)
+    elif isinstance(model_cfg_path, str) and os.path.exists(model_cfg_path.lstrip("/")):
+        hiera, image_size = _hiera_from_yaml(model_cfg_path.lstrip("/"))          # the reference prepends "/" for Hydra (circuit_analyzer.py:204)
+    model = SAM2Model(hiera, image_size, dtype=dtype, dev=str(device), use_refinement=use_refinement_layer, refinement_kernels=refinement_kernels,
+                      embedding_r=trainable_embedding_r, lora_rank=lora_rank, lora_alpha=lora_alpha)
+    if isinstance(checkpoint_path, str) and checkpoint_path.startswith("synthetic"):
+        seed = int(checkpoint_path.split(":")[1]) if ":" in checkpoint_path else 0
+        targets = lora_target_modules if (use_peft and lora_target_modules is not None) else ()
+        model.load_params(SamSyntheticParams(seed=seed, lora_targets=targets, r=lora_rank, alpha=lora_alpha))
+    return model
+
+
+class SAM2Transforms:
+    """sam2_infer.py:29-128.  `__call__` returns an f32 [3,R,R] device tensor (channels-last memory, so the model
+    consumes it without a layout pass); `postprocess_masks` with the reference's settings (areas = 0) is the
+    bilinear resize to the original size (:127)."""
+
+    def __init__(self, resolution, mask_threshold, max_hole_area=0.0, max_sprinkle_area=0.0):
+        self.resolution, self.mask_threshold = resolution, mask_threshold
+        self.max_hole_area, self.max_sprinkle_area = max_hole_area, max_sprinkle_area
+        if max_hole_area > 0 or max_sprinkle_area > 0:
+            raise NotImplementedError("hole / sprinkle filtering (connected components) is disabled in the reference (circuit_analyzer.py:245-250)")
+        self.mean, self.std = [0.485, 0.456, 0.406], [0.229, 0.224, 0.225]
+
+    def __call__(self, x):
+        require_gpu()
+        img = np.ascontiguousarray(np.asarray(x))
+        if img.ndim != 3 or img.shape[2] != 3 or img.dtype != np.uint8:
+            raise TypeError("SAM2Transforms expects an RGB uint8 image (PIL or HxWx3 array)")
+        lib = _lib.load()
+        R = self.resolution
+        src = torch.from_numpy(img).cuda()
+        out = torch.empty(R, R, 3, dtype=torch.float32, device="cuda")
+        torch.cuda.current_stream().synchronize()
+        _lib.check(lib.cvmi_sam2_transform(src.data_ptr(), img.shape[0], img.shape[1], out.data_ptr(), R, F32, None), "sam2_transform")
+        torch.cuda.synchronize()
+        return out.permute(2, 0, 1)
+
+    def forward_batch(self, img_list):
+        return torch.stack([self(img) for img in img_list], dim=0)
+
+    def postprocess_masks(self, masks, orig_hw, return_u8=False):
+        require_gpu()
+        lib = _lib.load()
+        m = masks.float().contiguous()
+        if not m.is_cuda:
+            m = m.cuda()
+        B, C, h, w = m.shape
+        H, W = int(orig_hw[0]), int(orig_hw[1])
+        out = torch.empty(B, C, H, W, dtype=torch.float32, device=m.device)
+        u8 = torch.empty(B, C, H, W, dtype=torch.uint8, device=m.device) if return_u8 else None
+        torch.cuda.current_stream().synchronize()
+        _lib.check(lib.cvmi_bilinear_f32(m.data_ptr(), B * C, h, w, out.data_ptr(), H, W, u8.data_ptr() if return_u8 else None,
+                                         float(self.mask_threshold), None), "bilinear")
+        torch.cuda.synchronize()
+        return (out, u8) if return_u8 else out

@@ -76,6 +76,11 @@ typedef struct cvmi_conv_desc {
   int dtype;                        /* CVMI_F16 / CVMI_F32: type of x, w */
   int out_f32;                      /* 1: y and res are f32 even when dtype is F16 */
   int scalar_gather;                /* 1: per-element gather (channel count not vectorizable) */
+  int res_mod;                      /* > 0: residual row = m % res_mod (batch-broadcast constants) */
+  int act_after_res;                /* 1: y = act(conv + bias + res) instead of act(conv + bias) + res */
+  int shuffle_cout;                 /* > 0: ConvTranspose2d(k=2,s=2) as GEMM: N = 4*shuffle_cout, column
+                                       n = (dy*2+dx)*shuffle_cout + co is stored at output pixel
+                                       (2*oy+dy, 2*ox+dx), channel co of a [B,2*OH,2*OW,*] tensor (y, res) */
 } cvmi_conv_desc;
 int cvmi_conv2d(const cvmi_conv_desc* d, cvmi_stream_t stream);
 
@@ -138,6 +143,52 @@ int cvmi_nchw_to_nhwc(const void* src, int src_dtype, void* dst, int dst_dtype, 
 /* NHWC dtype -> NCHW f32 */
 int cvmi_nhwc_to_nchw_f32(const void* src, int src_dtype, int src_ld, float* dst, int B, int C,
                           int H, int W, cvmi_stream_t stream);
+
+/* ==== SAM 2.1 path (sam2_infer.py:220-275 and the un-vendored sam2 package behind it) ========= */
+
+/* LayerNorm over the channel axis of rows x C (nn.LayerNorm in Hiera / TwoWayTransformer, LayerNorm2d
+ * in the mask decoder's upscaling); optional activation after the affine.  x / y dtypes independent
+ * (fp16 mode keeps the residual stream in f32 and feeds fp16 to the GEMMs). gamma, beta: f32 [C]. */
+int cvmi_layernorm(const void* x, int x_ld, int x_dtype, const float* gamma, const float* beta,
+                   void* y, int y_ld, int y_dtype, long long rows, int C, float eps, int act,
+                   cvmi_stream_t stream);
+
+/* 2x2 / stride 2 max-pool, NHWC (Hiera shortcut path of the q-pooling blocks: do_pool(proj(x))). */
+int cvmi_maxpool2x2(const void* x, int x_ld, void* y, int y_ld, int B, int H, int W, int C, int dtype,
+                    cvmi_stream_t stream);
+
+/* rows x C copy with dtype conversion (f32 <-> f16). */
+int cvmi_cast(const void* x, int x_ld, int x_dtype, void* y, int y_ld, int y_dtype, long long rows, int C,
+              cvmi_stream_t stream);
+
+/* Mask decoder tail: masks[b,i,p] = sum_c hyper[b,i,c] * up[b,p,c] for the 4 mask tokens (c = 32),
+ * plus the stability counters of token 0 (area over +delta / -delta) for
+ * dynamic_multimask_via_stability.  hyper f32 [B,4,hyper_ld], up dtype [B,P,up_ld], masks f32 [B,4,P],
+ * areas i32 [B,2] (zeroed by this call). */
+int cvmi_hyper_masks(const float* hyper, int hyper_ld, const void* up, int up_ld, int up_dtype, int C,
+                     float* masks, int* areas, int B, int P, float delta, cvmi_stream_t stream);
+/* Select per image: token 0 when dynamic == 0 or stability >= thresh, else 1 + argmax(iou[1:4]).
+ * iou f32 [B, iou_ld] (4 values used).  Writes low_res f32 [B,P], iou_out f32 [B], sel i32 [B]. */
+int cvmi_select_mask(const float* masks, const int* areas, const float* iou, int iou_ld, int dynamic,
+                     float thresh, float* low_res, float* iou_out, int* sel, int B, int P,
+                     cvmi_stream_t stream);
+
+/* F.interpolate(bilinear, align_corners=False) of f32 planes [N,h,w] -> [N,H,W] (sam2_infer.py:263-268,
+ * postprocess_masks :127).  mask_u8 (optional): also writes (value > thresh) ? 255 : 0. */
+int cvmi_bilinear_f32(const float* x, int N, int h, int w, float* y, int H, int W, uint8_t* mask_u8,
+                      float thresh, cvmi_stream_t stream);
+
+/* Fused 'bilinear upsample to HxW' + MultiKernelRefinement (sam2_infer.py:130-189, :263-272):
+ * nk parallel convs (1 -> ic channels, odd kernels ks[], zero 'same' padding) + exact GELU + 1x1
+ * combiner.  The ic*nk x H x W intermediate never leaves LDS/registers.
+ * params f32: for each branch j: w[ic][ks_j][ks_j] then b[ic]; then combiner w[nk*ic], b[1]. */
+int cvmi_upsample_refine(const float* low, int N, int h, int w, float* high, int H, int W,
+                         const float* params, const int* ks, int nk, int ic, cvmi_stream_t stream);
+
+/* SAM2Transforms.__call__ (sam2_infer.py:49-51): u8 HWC -> /255 -> antialiased bilinear resize to
+ * R x R -> ImageNet normalise; written NHWC with 3 channels in dst_dtype. */
+int cvmi_sam2_transform(const uint8_t* src, int H, int W, void* dst, int R, int dst_dtype,
+                        cvmi_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,264 @@
+"""GPU parity of the SAM 2.1 path: helper kernels, conv-epilogue extensions, the refinement head and
+post-process against the REFERENCE's golden vectors, and the whole wrapper forward vs the CPU oracle."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from circuitvision_amd import _lib
+from circuitvision_amd._lib import ACT_GELU, ACT_NONE, F16, F32
+from circuitvision_amd.engine import Buf, PackedConv, Plan, TORCH_DTYPE, op_cast, op_conv, op_layernorm, op_maxpool2
+from helpers import TOL, from_view, quant, run, stream, to_buf
+from oracle import sam2_model as osam
+from test_oracle_sam2_cpu import MINI, mini_oracle, mini_targets
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.mark.parametrize("din,dout", [(F32, F32), (F32, F16), (F16, F16), (F16, F32)])
+@pytest.mark.parametrize("C_,act", [(144, ACT_NONE), (256, ACT_NONE), (1152, ACT_NONE), (64, ACT_GELU), (16, ACT_NONE)])
+def test_layernorm(din, dout, C_, act):
+    g = torch.Generator().manual_seed(C_)
+    x = quant(torch.randn(3, 5, 7, C_, generator=g) * 3 + 1, din)
+    gam, bet = torch.rand(C_, generator=g) + 0.5, torch.randn(C_, generator=g)
+    ref = F.layer_norm(x, (C_,), gam, bet, 1e-6)
+    if act == ACT_GELU:
+        ref = F.gelu(ref)
+    xb = Buf(3, 5, 7, C_, din); xb.t.copy_(x.to(TORCH_DTYPE[din]))
+    yb = Buf(3, 5, 7, C_, dout, zero=True)
+    plan = Plan(stream())
+    op_layernorm(plan, "ln", xb.view(), gam.cuda(), bet.cuda(), yb.view(), 1e-6, act)
+    run(plan)
+    tol = dict(rtol=1e-5, atol=1e-5) if dout == F32 else dict(rtol=2e-3, atol=2e-3)
+    torch.testing.assert_close(yb.t.float().cpu(), ref, **tol)
+
+
+@pytest.mark.parametrize("dtype", [F16, F32])
+def test_maxpool_and_cast(dtype):
+    g = torch.Generator().manual_seed(0)
+    x = quant(torch.randn(2, 24, 8, 12, generator=g), dtype)
+    xb = to_buf(x, dtype)
+    yb = Buf(2, 4, 6, 24, dtype, zero=True)
+    zb = Buf(2, 4, 6, 24, F16 if dtype == F32 else F32, zero=True)
+    plan = Plan(stream())
+    op_maxpool2(plan, "mp", xb.view(), yb.view())
+    op_cast(plan, "cast", yb.view(), zb.view())
+    run(plan)
+    ref = F.max_pool2d(x, 2, 2)
+    assert torch.equal(from_view(yb.view()), ref)
+    torch.testing.assert_close(from_view(zb.view()), ref, rtol=1e-3, atol=1e-3)
+
+
+@pytest.mark.parametrize("dtype", [F16, F32])
+def test_conv_transpose_shuffle_and_act_after_res(dtype):
+    """act2(ConvTranspose2d(k=2,s=2)(x) + skip): the mask decoder's second upscaling step."""
+    g = torch.Generator().manual_seed(4)
+    x = quant(torch.randn(2, 64, 6, 5, generator=g), dtype)
+    w = quant(torch.randn(64, 32, 2, 2, generator=g) / 8, dtype)
+    b = torch.randn(32, generator=g)
+    skip = quant(torch.randn(2, 32, 12, 10, generator=g), dtype)
+    ref = F.gelu(F.conv_transpose2d(x, w, b, stride=2) + skip)
+    pc = PackedConv(w.permute(2, 3, 1, 0).reshape(128, 64, 1, 1), b.repeat(4), dtype)
+    xb, sb = to_buf(x, dtype), to_buf(skip, dtype)
+    yb = Buf(2, 12, 10, 32, dtype, zero=True)
+    plan = Plan(stream())
+    op_conv(plan, "ct", pc, [(xb.view(), 0)], yb.view(), act=ACT_GELU, res=sb.view(), shuffle_cout=32, act_after_res=True)
+    run(plan)
+    torch.testing.assert_close(from_view(yb.view()), ref, **TOL[dtype])
+
+
+def test_conv_broadcast_residual():
+    """res_mod: one constant [pixels, C] residual shared by every image (position embeddings, dense prompt)."""
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(3, 16, 4, 4, generator=g)
+    w = torch.randn(24, 16, 1, 1, generator=g) / 4
+    const = torch.randn(16, 24, generator=g)                      # [pixels, C]
+    ref = F.conv2d(x, w) + const.t().reshape(1, 24, 4, 4)
+    from circuitvision_amd.sam2 import _ConstView
+    cd = const.cuda()
+    xb = to_buf(x, F32)
+    yb = Buf(3, 4, 4, 24, F32, zero=True)
+    plan = Plan(stream())
+    op_conv(plan, "c", PackedConv(w, None, F32), [(xb.view(), 0)], yb.view(), res=_ConstView(cd, 24), res_mod=16)
+    run(plan)
+    torch.testing.assert_close(from_view(yb.view()), ref, rtol=1e-4, atol=1e-4)
+
+
+def test_refinement_head_matches_reference_golden():
+    """GPU refinement == the REFERENCE's MultiKernelRefinement outputs (src/sam2_infer.py:130-189).
+    With H == h the fused kernel's bilinear stage is the identity, leaving the refinement alone."""
+    lib = _lib.load()
+    gld = np.load(os.path.join(GOLD, "refinement.npz"))
+    parts = []
+    for j in range(4):
+        parts += [gld[f"conv_branches__{j}__weight"].reshape(-1), gld[f"conv_branches__{j}__bias"]]
+    parts += [gld["combiner_conv__weight"].reshape(-1), gld["combiner_conv__bias"]]
+    prm = torch.from_numpy(np.concatenate(parts)).cuda()
+    assert prm.numel() == 849
+    ks = (C.c_int * 4)(3, 5, 7, 11)
+    for xk, yk in (("x1", "y1"), ("x2", "y2")):
+        x = torch.from_numpy(gld[xk]).cuda()
+        n, _, h, w = x.shape
+        y = torch.zeros_like(x)
+        torch.cuda.synchronize()
+        _lib.check(lib.cvmi_upsample_refine(x.data_ptr(), n, h, w, y.data_ptr(), h, w, prm.data_ptr(), ks, 4, 4, None), "refine")
+        torch.cuda.synchronize()
+        torch.testing.assert_close(y.cpu(), torch.from_numpy(gld[yk]), rtol=1e-4, atol=1e-4)
+
+
+def test_upsample_refine_fused_vs_oracle():
+    lib = _lib.load()
+    m = osam.randomize_(osam.MultiKernelRefinement((3, 5, 7, 11), 4), seed=3, std=0.3).eval()
+    parts = []
+    for b in m.conv_branches:
+        parts += [b.weight.detach().reshape(-1), b.bias.detach()]
+    parts += [m.combiner_conv.weight.detach().reshape(-1), m.combiner_conv.bias.detach()]
+    prm = torch.cat(parts).cuda()
+    low = torch.randn(2, 1, 40, 24, generator=torch.Generator().manual_seed(1)) * 4
+    with torch.no_grad():
+        ref = m(F.interpolate(low, size=(160, 96), mode="bilinear", align_corners=False))
+    out = torch.zeros(2, 1, 160, 96, device="cuda")
+    ks = (C.c_int * 4)(3, 5, 7, 11)
+    ld = low.cuda()
+    torch.cuda.synchronize()
+    _lib.check(lib.cvmi_upsample_refine(ld.data_ptr(), 2, 40, 24, out.data_ptr(), 160, 96, prm.data_ptr(), ks, 4, 4, None), "refine")
+    torch.cuda.synchronize()
+    torch.testing.assert_close(out.cpu(), ref, rtol=1e-4, atol=1e-4)
+
+
+def test_postprocess_matches_reference_golden():
+    """SAM2Transforms.postprocess_masks on the GPU == the REFERENCE's outputs (src/sam2_infer.py:88-128)."""
+    from circuitvision_amd.sam2_infer import SAM2Transforms
+    gld = np.load(os.path.join(GOLD, "postprocess.npz"))
+    tr = SAM2Transforms(1024, 0, 0, 0)
+    masks = torch.from_numpy(gld["masks"])
+    for k in gld.files:
+        if k.startswith("out_"):
+            h, w = map(int, k[4:].split("x"))
+            out, u8 = tr.postprocess_masks(masks, (h, w), return_u8=True)
+            ref = torch.from_numpy(gld[k])
+            torch.testing.assert_close(out.cpu(), ref, rtol=1e-5, atol=1e-5)
+            sure = ref.abs() > 1e-4
+            assert torch.equal((u8.cpu() > 0)[sure], (ref > 0.0)[sure])      # circuit_analyzer.py:356 threshold
+
+
+@pytest.mark.parametrize("hw", [(720, 1280), (1024, 1024), (300, 500), (2000, 1500)])
+def test_sam2_transform_vs_oracle(hw):
+    from circuitvision_amd.sam2_infer import SAM2Transforms
+    from synth import circuit_image
+    img = circuit_image(*hw, seed=hw[1])
+    ref = osam.sam2_transform(img, 256)
+    got = SAM2Transforms(256, 0, 0, 0)(img)
+    assert got.shape == (3, 256, 256)
+    torch.testing.assert_close(got.cpu(), ref, rtol=1e-4, atol=2e-5)
+
+
+def test_hyper_masks_and_dynamic_selection():
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(2)
+    B, P, Cc = 3, 1000, 32
+    up = torch.randn(B, P, Cc, generator=g)
+    hyper = torch.randn(B, 4, Cc, generator=g)
+    hyper[1, 0] *= 1e-3                              # image 1: token-0 logits ~ 0 -> unstable -> falls back to best multimask
+    iou = torch.rand(B, 4, generator=g)
+    masks_ref = hyper @ up.transpose(1, 2)           # [B,4,P]
+    dec = osam.MaskDecoder(256, 3, lora=False).eval()
+    m_ref, i_ref = dec._dynamic(masks_ref.view(B, 4, 1, P), iou)
+    upd, hd, ioud = up.cuda(), hyper.cuda(), iou.cuda()
+    masks = torch.zeros(B, 4, P, device="cuda"); areas = torch.zeros(B, 2, dtype=torch.int32, device="cuda")
+    low = torch.zeros(B, P, device="cuda"); iou_o = torch.zeros(B, device="cuda"); sel = torch.zeros(B, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    _lib.check(lib.cvmi_hyper_masks(hd.data_ptr(), Cc, upd.data_ptr(), Cc, F32, Cc, masks.data_ptr(), areas.data_ptr(), B, P, 0.05, None), "hm")
+    _lib.check(lib.cvmi_select_mask(masks.data_ptr(), areas.data_ptr(), ioud.data_ptr(), 4, 1, 0.98, low.data_ptr(), iou_o.data_ptr(), sel.data_ptr(), B, P, None), "sel")
+    torch.cuda.synchronize()
+    torch.testing.assert_close(masks.cpu(), masks_ref, rtol=1e-4, atol=1e-4)
+    assert sel.cpu().tolist()[1] != 0
+    torch.testing.assert_close(low.cpu(), m_ref.view(B, P), rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(iou_o.cpu(), i_ref.view(B))
+
+
+def _run_wrapper(hiera, targets, oracle_fn, image_size, dtype, B, seed=5):
+    from circuitvision_amd.sam2 import Sam2Plan, Sam2Weights, SamSyntheticParams
+    p = SamSyntheticParams(seed=seed, lora_targets=targets, std=0.05)
+    wt = Sam2Weights(p, hiera, image_size, dtype)
+    oracle = oracle_fn(p)
+    x = torch.randn(B, 3, image_size, image_size, generator=torch.Generator().manual_seed(0)).to(TORCH_DTYPE[dtype]).float()
+    with torch.no_grad():
+        hi, lo, iou, inter = oracle(x, return_intermediates=True)
+    sp = Sam2Plan(wt, B, torch.cuda.Stream())
+    sp.x_in.t.copy_(x.permute(0, 2, 3, 1).to(TORCH_DTYPE[dtype]))
+    torch.cuda.synchronize()
+    sp.plan.run_eager()
+    torch.cuda.synchronize()
+    return sp, (hi, lo, iou, inter)
+
+
+@pytest.mark.parametrize("dtype", [F32, F16])
+def test_sam2_wrapper_mini_matches_oracle(dtype):
+    """Whole SAM2ImageWrapper.forward (mini Hiera with q-pool, windowed + global blocks, LoRA everywhere)."""
+    sp, (hi, lo, iou, inter) = _run_wrapper(MINI, mini_targets(), lambda p: mini_oracle(p, 256), 256, dtype, B=2)
+    tol = dict(rtol=1e-3, atol=1e-3) if dtype == F32 else dict(rtol=3e-2, atol=3e-2)
+    for name, buf, ref in (("feat_s0", sp.feat_s0, inter["s0"]), ("feat_s1", sp.feat_s1, inter["s1"])):
+        torch.testing.assert_close(buf.t.float().permute(0, 3, 1, 2).cpu(), ref, **tol, msg=lambda m: f"{name}: {m}")
+    torch.testing.assert_close(sp.low_res.cpu(), lo, **tol)
+    torch.testing.assert_close(sp.iou.cpu(), iou, **tol)
+    torch.testing.assert_close(sp.high_res.cpu(), hi, **tol)
+
+
+def test_sam2_wrapper_hiera_l_f16_matches_oracle():
+    """BASELINE config 3 shape at B=1: SAM 2.1 Hiera-L, 1024^2, fp16 operands / fp32 residual stream.
+    Tolerances written here: mask logits within 5e-2 of the fp32 oracle (logit scale ~ +-10), binary masks IoU >= 0.99."""
+    from circuitvision_amd.sam2 import HIERA_L, LORA_TARGETS_REFERENCE
+
+    def make(p):
+        w = osam.SAM2ImageWrapper(osam.SAM2Core(osam.HIERA_L, lora=True)).eval()
+        w.load_state_dict({("sam2_model." + k if not (k.startswith("dense_") or k.startswith("sparse_") or k.startswith("refinement_")) else k): v
+                           for k, v in p.state_dict().items()}, strict=True)
+        return w
+    sp, (hi, lo, iou, inter) = _run_wrapper(HIERA_L, LORA_TARGETS_REFERENCE, make, 1024, F16, B=1)
+    got = sp.low_res.cpu()
+    scale = float(lo.abs().max())
+    err = float((got - lo).abs().max())
+    print(f"Hiera-L f16: low-res logit scale {scale:.3f}, max abs err {err:.4f}, iou err {float((sp.iou.cpu() - iou).abs().max()):.2e}")
+    assert err <= 5e-2 * max(1.0, scale)
+    a, b = sp.high_res.cpu() > 0, hi > 0
+    inter_, union = (a & b).sum().item(), (a | b).sum().item()
+    assert union == 0 or inter_ / union >= 0.99
+    torch.testing.assert_close(sp.iou.cpu(), iou, rtol=0, atol=2e-2)
+
+
+def test_boundary_get_modified_sam2_and_transforms():
+    """The reference's call sequence (circuit_analyzer.py:203-250, :343-356) against the oracle pipeline."""
+    from circuitvision_amd.sam2_infer import SAM2Model, SAM2Transforms, device
+    from circuitvision_amd.sam2 import SamSyntheticParams
+    from synth import circuit_image
+    assert device.type == "cuda"
+    model = SAM2Model(MINI, 256, dtype="f32", use_refinement=True)
+    p = SamSyntheticParams(seed=8, lora_targets=mini_targets(), std=0.05)
+    from circuitvision_amd.sam2 import Sam2Weights
+    Sam2Weights(p, MINI, 256, F32, device="cpu")                       # materialise the synthetic checkpoint
+    sd = {"sam2_model.base_model.model." + k if not (k.startswith("dense_") or k.startswith("sparse_") or k.startswith("refinement_")) else k: v
+          for k, v in p.state_dict().items()}
+    model.load_state_dict({"state_dict": sd})
+    model.eval()
+    assert model.sam2_model.image_size == 256
+    tr = SAM2Transforms(resolution=256, mask_threshold=0, max_hole_area=0, max_sprinkle_area=0)
+    img = circuit_image(200, 320, seed=4)
+    x = tr(img).unsqueeze(0).to(device)
+    with torch.no_grad():
+        hi, lo, iou = model(x)
+    final = tr.postprocess_masks(hi, img.shape[:2])
+    mask = (final.detach().cpu().squeeze() > 0.0).numpy().astype(np.uint8) * 255
+    oracle = mini_oracle(p, 256)
+    with torch.no_grad():
+        rhi, rlo, riou = oracle(osam.sam2_transform(img, 256)[None])
+        rfinal = osam.postprocess_masks(rhi, img.shape[:2])
+    torch.testing.assert_close(lo.cpu(), rlo, rtol=1e-3, atol=1e-3)
+    torch.testing.assert_close(final.cpu(), rfinal, rtol=1e-3, atol=1e-3)
+    rmask = (rfinal.squeeze() > 0.0).numpy().astype(np.uint8) * 255
+    assert (mask != rmask).mean() < 1e-3
+    assert mask.shape == img.shape[:2]
