@@ -34,8 +34,10 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--batch", type=int, default=32, help="images per GPU per step")
-    ap.add_argument("--scale", default="n")
+    ap.add_argument("--workload", default="yolo11n", choices=["yolo11n", "yolo11l", "sam2l"],
+                    help="yolo11n = BASELINE configs[1] (default, the bench line); sam2l = configs[2]")
+    ap.add_argument("--batch", type=int, default=None, help="images per GPU per step (default 32 YOLO / 16 SAM)")
+    ap.add_argument("--scale", default=None)
     ap.add_argument("--dtype", default="f16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile-pass", action="store_true")
@@ -62,8 +64,107 @@ def cpu_baseline(scale, nc, state_dict, seconds=12.0):
             "sample": f"{n} synthetic 640x640 images (batches of 4), YOLO11-{scale} fp32 oracle forward + NMS, {dt:.1f} s"}
 
 
+SAM_FLOP_PER_IMAGE = 1.83e12     # trunk linear 1606 G + attention 203 G + conv/neck/decoder/refine
+MFMA_PEAK_TFLOPS = 2500.0        # dense fp16/bf16 (MI355X_MICROARCH.md)
+
+
+def sam_cpu_baseline(state_dict, seconds=20.0):
+    import torch
+    from oracle import sam2_model as osam
+    w = osam.SAM2ImageWrapper(osam.SAM2Core(osam.HIERA_L, lora=True)).eval()
+    w.load_state_dict({("sam2_model." + k if not (k.startswith("dense_") or k.startswith("sparse_") or k.startswith("refinement_")) else k): v
+                       for k, v in state_dict.items()}, strict=True)
+    x = torch.randn(1, 3, 1024, 1024, generator=torch.Generator().manual_seed(0))
+    with torch.no_grad():
+        n, t0 = 0, time.perf_counter()
+        while n < 1 or time.perf_counter() - t0 < seconds:
+            w(x)
+            n += 1
+        dt = time.perf_counter() - t0
+    return {"value": round(n / dt, 4), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n} synthetic 1024x1024 images (batch 1), SAM2.1 Hiera-L fp32 oracle wrapper forward, {dt:.1f} s"}
+
+
+def run_sam(a):
+    """BASELINE configs[2]: SAM 2.1 Hiera-L, 1024x1024, batch 16 per GPU, learned-prompt wrapper forward."""
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0")); local_rank = int(os.environ.get("LOCAL_RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    from circuitvision_amd import _lib
+    from circuitvision_amd.distributed import broadcast_packed
+    from circuitvision_amd.sam2 import HIERA_L, LORA_TARGETS_REFERENCE, Sam2Plan, Sam2Weights, SamSyntheticParams
+    from synth import circuit_image
+    B = a.batch or 16
+    dtype = {"f16": _lib.F16, "f32": _lib.F32}[a.dtype]
+    params = SamSyntheticParams(seed=0, lora_targets=LORA_TARGETS_REFERENCE)
+    wt = Sam2Weights(params, HIERA_L, 1024, dtype, device=f"cuda:{local_rank}")
+    if world > 1:
+        broadcast_packed(wt.pc, src=0)
+    stream = torch.cuda.Stream()
+    sp = Sam2Plan(wt, B, stream)
+    lib = _lib.load()
+    for b in range(B):
+        img = torch.from_numpy(circuit_image(768, 1024, seed=20250704 + rank * B + b)).cuda()
+        _lib.check(lib.cvmi_sam2_transform(img.data_ptr(), 768, 1024, sp.x_in.t[b].data_ptr(), 1024, dtype, stream.cuda_stream), "transform")
+    stream.synchronize()
+    plan = sp.plan
+    plan.capture()
+    for _ in range(a.warmup):
+        plan.run()
+    stream.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        plan.run()
+    stream.synchronize(); torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX); dt = float(t.item()); dist.barrier()
+    roofline = breakdown = cpu = None
+    if rank == 0 and not a.no_profile_pass:
+        acc = {}
+        plan.timed_eager()
+        reps = 2
+        for _ in range(reps):
+            for label, kind, ms, b, f in plan.timed_eager():
+                k = acc.setdefault(kind, [0.0, 0, 0, 0]); k[0] += ms / reps; k[1] += 1; k[2] += b / reps; k[3] += f / reps
+        gemm_ms = acc["gemm"][0]; gemm_fl = acc["gemm"][3]
+        total_ms = sum(v[0] for v in acc.values())
+        ach = gemm_fl / (gemm_ms * 1e-3) / 1e12
+        roofline = {"bound": "mfma", "achieved": round(ach, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4),
+                    "traffic": None, "kernel": "igemm_kernel (Hiera linear layers) per step", "kernel_ms_per_step": round(gemm_ms, 3),
+                    "algorithmic_flops_per_step": int(gemm_fl), "whole_step_tflops": round(B * SAM_FLOP_PER_IMAGE / (total_ms * 1e-3) / 1e12, 1)}
+        breakdown = {k: {"ms": round(v[0], 3), "launches": v[1] // reps, "gflop": round(v[3] / 1e9, 1),
+                         "tflops": round(v[3] / max(v[0], 1e-9) / 1e9, 1)} for k, v in acc.items()}
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        cpu = sam_cpu_baseline(params.state_dict())
+    if rank == 0:
+        print(json.dumps({
+            "metric": "circuit images/sec (YOLOv11 640² + SAM2.1-L 1024²) at 1/2/4/8 MI355X", "value": round(world * B * a.steps / dt, 3),
+            "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+            "config": {"workload": f"SAM2.1 Hiera-L 1024x1024 batch={B}/GPU learned-prompt wrapper forward (BASELINE configs[2])",
+                       "images_per_step": world * B, "weights": "seeded random, LoRA merged"},
+            "roofline": roofline, "cpu_baseline": cpu, "breakdown": breakdown}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     a = parse()
+    if a.workload == "sam2l":
+        if a.steps == 50 and a.warmup == 10:
+            a.steps, a.warmup = 5, 2
+        return run_sam(a)
+    a.scale = a.scale or ("l" if a.workload == "yolo11l" else "n")
+    a.batch = a.batch or 32
     import torch
     import torch.distributed as dist
 
