@@ -190,13 +190,13 @@ def main():
     if world > 1:
         broadcast_packed(wt.packed, src=0)            # one-time RCCL broadcast of the packed weights
     stream = torch.cuda.Stream()
-    yp = Yolo11Plan(wt, a.batch, 640, 640, stream)
+    yp = Yolo11Plan(wt, a.batch, 640, 640, stream, keep_scores=False)
 
     # synthetic circuit images of this rank's shard, letterboxed on the GPU into the plan's input
     lib = _lib.load()
     for b in range(a.batch):
         img = torch.from_numpy(circuit_image(640, 640, seed=20250704 + rank * a.batch + b)).cuda()
-        _lib.check(lib.cvmi_letterbox(img.data_ptr(), 640, 640, yp.x_in.t[b].data_ptr(), 640, 640, 640, 640, 0, 0, dtype,
+        _lib.check(lib.cvmi_letterbox(img.data_ptr(), 640, 640, yp.x_in.t[b].data_ptr(), 640, 640, 640, 640, 0, 0, dtype, 1,
                                       stream.cuda_stream), "letterbox")
     stream.synchronize()
 

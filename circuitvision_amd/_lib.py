@@ -57,10 +57,11 @@ SIGNATURES = {
     "cvmi_sppf_pool": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp]),
     "cvmi_attention": (_i, [C.POINTER(AttnDesc), _vp]),
     "cvmi_detect_decode": (_i, [C.POINTER(_vp), C.POINTER(_i), C.POINTER(_vp), C.POINTER(_i), C.POINTER(_i),
-                                C.POINTER(_i), C.POINTER(_f), _i, _i, _i, _i, _vp, _vp]),
+                                C.POINTER(_i), C.POINTER(_f), _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp]),
+    "cvmi_yolo_nms_best": (_i, [_vp, _vp, _vp, _i, _i, _i, _f, _f, _i, _f, _vp, _vp, _vp, _vp, _vp]),
     "cvmi_yolo_nms_workspace": (C.c_size_t, [_i, _i]),
     "cvmi_yolo_nms": (_i, [_vp, _i, _i, _i, _f, _f, _i, _f, _vp, _vp, _vp, _vp, _vp]),
-    "cvmi_letterbox": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "cvmi_letterbox": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "cvmi_nchw_to_nhwc": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "cvmi_nhwc_to_nchw_f32": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _i, _vp]),
     "cvmi_layernorm": (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _i, C.c_longlong, _i, _f, _i, _vp]),

@@ -18,6 +18,7 @@
 // Pipeline: register-staged double buffer (global loads for tile t+1 are issued before the MFMAs
 // of tile t and written to the other LDS buffer after them; one barrier per K-tile).
 #include "common.hpp"
+#include <stdlib.h>
 
 namespace {
 
@@ -30,6 +31,7 @@ struct ConvKArgs {
   int M, N, K, Kpad;
   int act, scalar_gather;
   int res_mod, act_after_res, shuf_c;
+  int plain;
   int nb_n;
   FastDiv div_ctot, div_kw;
 };
@@ -90,9 +92,10 @@ __device__ __forceinline__ u32x4 gather_chunk(const ConvKArgs& p, int k, int b, 
   return v;
 }
 
-template <typename T, typename TO, int BM, int BN, int WM, int WN>
+template <typename T, typename TO, int BM, int BN, int WM, int WN, int BKB, bool PLAIN>
 __global__ __launch_bounds__(256) void igemm_kernel(const ConvKArgs p) {
-  constexpr int BKB = 64;                 // data bytes per LDS row per K-tile
+  // BKB = data bytes per LDS row per K-tile (64 or 128); PLAIN = 1x1 / stride 1 / one source: A is a plain
+  // row-major matrix, so the per-tile gather arithmetic collapses to "row pointer + k"
   constexpr int ES = sizeof(T);
   constexpr int VEC = 16 / ES;
   constexpr int BK = BKB / ES;
@@ -134,17 +137,38 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ConvKArgs p) {
     a_ix0[i] = ox * p.stride - p.pad;
   }
 
+  const char* a_ptr[A_IT];
+  const char* b_ptr[B_IT];
+#pragma unroll
+  for (int i = 0; i < A_IT; ++i) {
+    const int row = (tid + i * 256) / CH;
+    const int m = a_ok[i] ? m0 + row : 0;
+    a_ptr[i] = p.x0 + ((size_t)m * p.x0_ld + cchunk * VEC) * ES;
+  }
+#pragma unroll
+  for (int i = 0; i < B_IT; ++i) {
+    const int row = (tid + i * 256) / CH;
+    b_ptr[i] = p.w + ((size_t)(n0 + (row < BN ? row : 0)) * p.Kpad + cchunk * VEC) * ES;
+  }
+
   u32x4 a_reg[A_IT], b_reg[B_IT];
   auto load_tile = [&](int kt) {
     const int k = kt * BK + cchunk * VEC;
 #pragma unroll
-    for (int i = 0; i < A_IT; ++i)
-      a_reg[i] = gather_chunk<T>(p, k, a_b[i], a_iy0[i], a_ix0[i], a_ok[i]);
+    for (int i = 0; i < A_IT; ++i) {
+      if constexpr (PLAIN) {
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (a_ok[i] && k < p.K) v = *reinterpret_cast<const u32x4*>(a_ptr[i] + (size_t)kt * BKB);
+        a_reg[i] = v;
+      } else {
+        a_reg[i] = gather_chunk<T>(p, k, a_b[i], a_iy0[i], a_ix0[i], a_ok[i]);
+      }
+    }
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) {
       const int row = (tid + i * 256) / CH;
       if (BN * CH >= 256 * (i + 1) || row < BN)
-        b_reg[i] = *reinterpret_cast<const u32x4*>(p.w + ((size_t)(n0 + row) * p.Kpad + k) * ES);
+        b_reg[i] = *reinterpret_cast<const u32x4*>(b_ptr[i] + (size_t)kt * BKB);
     }
   };
   auto store_tile = [&](int buf) {
@@ -275,24 +299,36 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ConvKArgs p) {
   }
 }
 
-template <typename T, typename TO, int BM, int BN, int WM, int WN>
-int launch_cfg(ConvKArgs& a, hipStream_t stream) {
-  constexpr int ROWB = 64 + 16;
+template <typename T, typename TO, int BM, int BN, int WM, int WN, int BKB, bool PLAIN>
+int launch_cfg2(ConvKArgs& a, hipStream_t stream) {
+  constexpr int ROWB = BKB + 16;
   constexpr size_t stage = (size_t)2 * (BM + BN) * ROWB;
   constexpr size_t epi = (size_t)BM * (BN * sizeof(TO) + 16);
   constexpr size_t lds = stage > epi ? stage : epi;
   static bool attr_done = false;
   if (!attr_done && lds > 64 * 1024) {
-    CVMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<T, TO, BM, BN, WM, WN>),
+    CVMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<T, TO, BM, BN, WM, WN, BKB, PLAIN>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_done = true;
   }
   a.nb_n = cdiv(a.N, BN);
   const long long blocks = (long long)cdiv(a.M, BM) * a.nb_n;
   CVMI_CHECK(blocks > 0 && blocks < (1ll << 31), "conv2d: bad grid %lld", blocks);
-  hipLaunchKernelGGL((igemm_kernel<T, TO, BM, BN, WM, WN>), dim3((unsigned)blocks), dim3(256), lds, stream, a);
+  hipLaunchKernelGGL((igemm_kernel<T, TO, BM, BN, WM, WN, BKB, PLAIN>), dim3((unsigned)blocks), dim3(256), lds, stream, a);
   CVMI_LAUNCH_CHECK();
   return 0;
+}
+
+template <typename T, typename TO, int BM, int BN, int WM, int WN>
+int launch_cfg(ConvKArgs& a, hipStream_t stream) {
+  const bool plain = a.plain != 0;
+  // 128-byte K-tiles halve the barrier count; 64-byte tiles only when K is too short to fill one
+  static const int force_bkb = getenv("CVMI_BKB") ? atoi(getenv("CVMI_BKB")) : 0;      // tuning experiments only
+  bool wide = plain && a.N >= 128 && a.Kpad * (int)sizeof(T) >= 256 && (a.Kpad * (int)sizeof(T)) % 128 == 0;
+  if (force_bkb == 64) wide = false;
+  if (force_bkb == 128) wide = a.Kpad * (int)sizeof(T) >= 256 && (a.Kpad * (int)sizeof(T)) % 128 == 0;
+  if (wide) return plain ? launch_cfg2<T, TO, BM, BN, WM, WN, 128, true>(a, stream) : launch_cfg2<T, TO, BM, BN, WM, WN, 128, false>(a, stream);
+  return plain ? launch_cfg2<T, TO, BM, BN, WM, WN, 64, true>(a, stream) : launch_cfg2<T, TO, BM, BN, WM, WN, 64, false>(a, stream);
 }
 
 template <typename T, typename TO>
@@ -315,6 +351,8 @@ int launch_typed(ConvKArgs& a, hipStream_t stream) {
 }
 
 }  // namespace
+
+int cvmi_conv_tile_try(const cvmi_conv_desc* d, hipStream_t stream);   // conv_tile.hip
 
 extern "C" int cvmi_conv2d(const cvmi_conv_desc* d, cvmi_stream_t stream_) {
   CVMI_CHECK(d != nullptr, "conv2d: null descriptor");
@@ -356,6 +394,8 @@ extern "C" int cvmi_conv2d(const cvmi_conv_desc* d, cvmi_stream_t stream_) {
   a.M = (int)M; a.N = d->N; a.K = (int)K; a.Kpad = d->Kpad;
   a.act = d->act; a.scalar_gather = d->scalar_gather; a.nb_n = 1;
   a.res_mod = d->res_mod; a.act_after_res = d->act_after_res; a.shuf_c = d->shuffle_cout;
+  a.plain = (d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0 && d->c1 == 0 && d->up0 == 0 && !d->scalar_gather &&
+             d->OH == d->H && d->OW == d->W) ? 1 : 0;
   CVMI_CHECK(d->res_mod >= 0 && d->shuffle_cout >= 0, "conv2d: negative res_mod / shuffle_cout");
   if (d->shuffle_cout > 0) {
     CVMI_CHECK(d->N == 4 * d->shuffle_cout && d->shuffle_cout % ovec == 0 && d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0 &&
@@ -364,6 +404,11 @@ extern "C" int cvmi_conv2d(const cvmi_conv_desc* d, cvmi_stream_t stream_) {
   }
   a.div_ctot.init((unsigned)ctot); a.div_kw.init((unsigned)d->KW);
   hipStream_t stream = (hipStream_t)stream_;
+  static const bool no_tile = getenv("CVMI_NO_TILE") != nullptr;                 // tuning experiments only
+  if (!no_tile && (d->KH > 1) && d->y_ld >= d->N) {
+    const int rc = cvmi_conv_tile_try(d, stream);
+    if (rc >= 0) return rc;
+  }
   if (d->dtype == CVMI_F32) return launch_typed<float, float>(a, stream);
   if (d->out_f32) return launch_typed<f16, float>(a, stream);
   return launch_typed<f16, f16>(a, stream);

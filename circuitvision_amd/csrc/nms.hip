@@ -16,7 +16,26 @@ constexpr int NMS_MAX_A = 16384;
 
 struct Cand { float x1, y1, x2, y2, area; };   // offset boxes (class * max_wh added)
 
-__global__ __launch_bounds__(NMS_THREADS) void yolo_nms_kernel(const float* __restrict__ pred, int nc, int A, float conf_thres,
+// per-anchor best class (first maximum), coalesced over anchors; used when the decode kernel did not provide it
+__global__ __launch_bounds__(256) void best_class_kernel(const float* __restrict__ pred, int nc, int A, long long total, float* __restrict__ best_score,
+                                                        int* __restrict__ best_cls) {
+  for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
+    const int a = (int)(g % A);
+    const long long b = g / A;
+    const float* pb = pred + (size_t)b * (4 + nc) * A + a;
+    float best = pb[(size_t)4 * A];
+    int bc = 0;
+    for (int c = 1; c < nc; ++c) {
+      const float v = pb[(size_t)(4 + c) * A];
+      if (v > best) { best = v; bc = c; }
+    }
+    best_score[g] = best;
+    best_cls[g] = bc;
+  }
+}
+
+__global__ __launch_bounds__(NMS_THREADS) void yolo_nms_kernel(const float* __restrict__ pred, const float* __restrict__ best_score,
+                                                              const int* __restrict__ best_cls, int nc, int A, float conf_thres,
                                                               float iou_thres, int max_det, float max_wh, float* __restrict__ out_det,
                                                               int* __restrict__ out_idx, int* __restrict__ out_count,
                                                               char* __restrict__ workspace, int P) {
@@ -26,8 +45,9 @@ __global__ __launch_bounds__(NMS_THREADS) void yolo_nms_kernel(const float* __re
   int& s_count = *reinterpret_cast<int*>(supp + (P >> 6));                           // all LDS dynamic (16-B aligned base)
   const int b = blockIdx.x, tid = threadIdx.x;
   const float* pb = pred + (size_t)b * (4 + nc) * A;
-  int* cls_ws = reinterpret_cast<int*>(workspace + (size_t)b * ((size_t)A * (sizeof(int) + sizeof(Cand))));
-  Cand* cand = reinterpret_cast<Cand*>(cls_ws + A);
+  const int* cls_ws = best_cls + (size_t)b * A;
+  const float* sc_ws = best_score + (size_t)b * A;
+  Cand* cand = reinterpret_cast<Cand*>(workspace + (size_t)b * (size_t)A * sizeof(Cand));
 
   if (tid == 0) s_count = 0;
   for (int i = tid; i < P; i += NMS_THREADS) keys[i] = 0ull;
@@ -35,13 +55,7 @@ __global__ __launch_bounds__(NMS_THREADS) void yolo_nms_kernel(const float* __re
 
   // 1. candidates
   for (int a = tid; a < A; a += NMS_THREADS) {
-    float best = pb[(size_t)4 * A + a];
-    int bc = 0;
-    for (int c = 1; c < nc; ++c) {
-      const float v = pb[(size_t)(4 + c) * A + a];
-      if (v > best) { best = v; bc = c; }
-    }
-    cls_ws[a] = bc;
+    const float best = sc_ws[a];
     if (best > conf_thres) {
       const int slot = atomicAdd(&s_count, 1);
       keys[slot] = ((unsigned long long)__float_as_uint(best) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)a);
@@ -129,15 +143,11 @@ __global__ __launch_bounds__(NMS_THREADS) void yolo_nms_kernel(const float* __re
 
 extern "C" size_t cvmi_yolo_nms_workspace(int B, int A) {
   if (B <= 0 || A <= 0) return 0;
-  return (size_t)B * (size_t)A * (sizeof(int) + sizeof(Cand)) + 256;
+  return (size_t)B * (size_t)A * (sizeof(Cand) + sizeof(float) + sizeof(int)) + 256;
 }
 
-extern "C" int cvmi_yolo_nms(const float* pred, int B, int nc, int A, float conf_thres, float iou_thres, int max_det, float max_wh,
-                             float* out_det, int* out_idx, int* out_count, void* workspace, cvmi_stream_t stream_) {
-  CVMI_CHECK(pred && out_det && out_idx && out_count && workspace, "yolo_nms: null pointer");
-  CVMI_CHECK(B > 0 && nc > 0 && A > 0 && max_det > 0, "yolo_nms: bad shape");
-  CVMI_CHECK(A <= NMS_MAX_A, "yolo_nms: A=%d exceeds %d anchors", A, NMS_MAX_A);
-  CVMI_CHECK(conf_thres >= 0.f, "yolo_nms: conf_thres must be >= 0 (keys rely on non-negative scores)");
+static int nms_launch(const float* pred, const float* best_score, const int* best_cls, int B, int nc, int A, float conf_thres, float iou_thres,
+                      int max_det, float max_wh, float* out_det, int* out_idx, int* out_count, void* workspace, hipStream_t stream) {
   int P = 1024;
   while (P < A) P <<= 1;
   const size_t lds = (size_t)P * 8 + (size_t)(P / 64) * 8 + 16;
@@ -147,9 +157,37 @@ extern "C" int cvmi_yolo_nms(const float* pred, int B, int nc, int A, float conf
                                  NMS_MAX_A * 8 + (NMS_MAX_A / 64) * 8 + 16));
     attr_done = true;
   }
-  hipStream_t stream = (hipStream_t)stream_;
-  hipLaunchKernelGGL(yolo_nms_kernel, dim3(B), dim3(NMS_THREADS), lds, stream, pred, nc, A, conf_thres, iou_thres, max_det, max_wh, out_det,
-                     out_idx, out_count, (char*)workspace, P);
+  hipLaunchKernelGGL(yolo_nms_kernel, dim3(B), dim3(NMS_THREADS), lds, stream, pred, best_score, best_cls, nc, A, conf_thres, iou_thres, max_det,
+                     max_wh, out_det, out_idx, out_count, (char*)workspace, P);
   CVMI_LAUNCH_CHECK();
   return 0;
+}
+
+extern "C" int cvmi_yolo_nms(const float* pred, int B, int nc, int A, float conf_thres, float iou_thres, int max_det, float max_wh,
+                             float* out_det, int* out_idx, int* out_count, void* workspace, cvmi_stream_t stream_) {
+  CVMI_CHECK(pred && out_det && out_idx && out_count && workspace, "yolo_nms: null pointer");
+  CVMI_CHECK(B > 0 && nc > 0 && A > 0 && max_det > 0, "yolo_nms: bad shape");
+  CVMI_CHECK(A <= NMS_MAX_A, "yolo_nms: A=%d exceeds %d anchors", A, NMS_MAX_A);
+  CVMI_CHECK(conf_thres >= 0.f, "yolo_nms: conf_thres must be >= 0 (keys rely on non-negative scores)");
+  hipStream_t stream = (hipStream_t)stream_;
+  char* ws = (char*)workspace;
+  float* bs = reinterpret_cast<float*>(ws + (size_t)B * A * sizeof(Cand));
+  int* bc = reinterpret_cast<int*>(bs + (size_t)B * A);
+  const long long total = (long long)B * A;
+  long long g = (total + 255) / 256;
+  if (g > 4096) g = 4096;
+  hipLaunchKernelGGL(best_class_kernel, dim3((unsigned)g), dim3(256), 0, stream, pred, nc, A, total, bs, bc);
+  CVMI_LAUNCH_CHECK();
+  return nms_launch(pred, bs, bc, B, nc, A, conf_thres, iou_thres, max_det, max_wh, out_det, out_idx, out_count, workspace, stream);
+}
+
+extern "C" int cvmi_yolo_nms_best(const float* pred, const float* best_score, const int* best_cls, int B, int nc, int A, float conf_thres,
+                                  float iou_thres, int max_det, float max_wh, float* out_det, int* out_idx, int* out_count, void* workspace,
+                                  cvmi_stream_t stream_) {
+  CVMI_CHECK(pred && best_score && best_cls && out_det && out_idx && out_count && workspace, "yolo_nms_best: null pointer");
+  CVMI_CHECK(B > 0 && nc > 0 && A > 0 && max_det > 0, "yolo_nms_best: bad shape");
+  CVMI_CHECK(A <= NMS_MAX_A, "yolo_nms_best: A=%d exceeds %d anchors", A, NMS_MAX_A);
+  CVMI_CHECK(conf_thres >= 0.f, "yolo_nms_best: conf_thres must be >= 0");
+  return nms_launch(pred, best_score, best_cls, B, nc, A, conf_thres, iou_thres, max_det, max_wh, out_det, out_idx, out_count, workspace,
+                    (hipStream_t)stream_);
 }

@@ -96,6 +96,64 @@ __global__ __launch_bounds__(256) void sppf_pool_kernel(char* __restrict__ buf, 
   }
 }
 
+
+// SPPF v2: one workgroup per (image, 16-byte channel chunk); the HxW plane of that chunk lives in LDS as f32 and
+// the three chained 5x5 max-pools run as separable 5-tap passes (row then column): ~30 LDS reads per pixel per
+// stage instead of 169 global reads per pixel.
+template <typename T>
+__global__ __launch_bounds__(256) void sppf_pool_lds_kernel(char* __restrict__ buf, int ld, int H, int W, int C) {
+  constexpr int VEC = Elem<T>::VEC;
+  extern __shared__ __attribute__((aligned(16))) float pl[];      // planes A, R: [H*W][VEC] each
+  const int nch = C / VEC;
+  const int b = blockIdx.x / nch, ch = blockIdx.x % nch;
+  const int HW = H * W;
+  float* A = pl;
+  float* R = pl + (size_t)HW * VEC;
+  char* base = buf + ((size_t)b * HW * ld + ch * VEC) * sizeof(T);
+  for (int p = threadIdx.x; p < HW; p += 256) {
+    float v[VEC];
+    unpack16<T>(*reinterpret_cast<const u32x4*>(base + (size_t)p * ld * sizeof(T)), v);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) A[p * VEC + e] = v[e];
+  }
+  __syncthreads();
+  for (int stage = 1; stage <= 3; ++stage) {
+    for (int p = threadIdx.x; p < HW; p += 256) {             // row pass: A -> R
+      const int y = p / W, x = p - y * W;
+      float m[VEC];
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) m[e] = -INFINITY;
+      for (int dx = -2; dx <= 2; ++dx) {
+        const int xx = x + dx;
+        if ((unsigned)xx < (unsigned)W) {
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) m[e] = fmaxf(m[e], A[(y * W + xx) * VEC + e]);
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) R[p * VEC + e] = m[e];
+    }
+    __syncthreads();
+    for (int p = threadIdx.x; p < HW; p += 256) {             // column pass: R -> A (next stage's input) + store
+      const int y = p / W, x = p - y * W;
+      float m[VEC];
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) m[e] = -INFINITY;
+      for (int dy = -2; dy <= 2; ++dy) {
+        const int yy = y + dy;
+        if ((unsigned)yy < (unsigned)H) {
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) m[e] = fmaxf(m[e], R[(yy * W + x) * VEC + e]);
+        }
+      }
+      *reinterpret_cast<u32x4*>(base + ((size_t)p * ld + (size_t)stage * C) * sizeof(T)) = pack16<T>(m);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) A[p * VEC + e] = m[e];    // A was fully consumed by the row pass (barrier above)
+    }
+    __syncthreads();
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 struct DetectArgs {
   const char* box[3]; const char* cls[3];
@@ -104,47 +162,116 @@ struct DetectArgs {
   int nlevels, B, nc, A;
 };
 
+// Decode v2: one workgroup = 64 consecutive anchors of the flat (image, anchor) space.
+//  * box: 4 lanes per anchor (one per side) read 32 contiguous bytes each -> coalesced; softmax-expectation per
+//    lane, the 4 distances are exchanged with 2 shuffles
+//  * cls: 16-byte chunks read contiguously, sigmoid, transposed through LDS so that the [B,4+nc,A] writes are
+//    64 consecutive anchors per class row; the per-anchor best class (first maximum) falls out of the same tile
+//    and feeds the NMS kernel directly (best_score / best_cls), so NMS never re-reads the class rows.
 template <typename T>
-__global__ __launch_bounds__(256) void detect_decode_kernel(const DetectArgs d, float* __restrict__ pred) {
+__global__ __launch_bounds__(256) void detect_decode_kernel(const DetectArgs d, float* __restrict__ pred, float* __restrict__ best_score,
+                                                           int* __restrict__ best_cls, int write_cls) {
   constexpr bool FAST = FastMath<T>::value;
+  constexpr int VEC = Elem<T>::VEC;
+  extern __shared__ __attribute__((aligned(16))) float tile[];          // [64][ncp + 1]
+  const int ncp = (d.nc + VEC - 1) / VEC * VEC;
+  const int TS = ncp + 1;
   const long long total = (long long)d.B * d.A;
-  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
-    const int a = (int)(idx % d.A);
-    const int b = (int)(idx / d.A);
-    int l = 0;
-    if (d.nlevels > 1 && a >= d.a0[1]) l = 1;
-    if (d.nlevels > 2 && a >= d.a0[2]) l = 2;
-    const int al = a - d.a0[l];
-    const int w = d.ws[l], h = d.hs[l];
-    const int ay = al / w, ax = al - ay * w;
-    const size_t pix = (size_t)b * h * w + al;
-    const T* bp = reinterpret_cast<const T*>(d.box[l]) + pix * d.box_ld[l];
-    float dist[4];
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
+  const long long g0 = (long long)blockIdx.x * 64;
+  const int tid = threadIdx.x;
+  // ---- boxes: thread = (anchor tid/4, side tid%4)
+  {
+    const long long g = g0 + (tid >> 2);
+    const int side = tid & 3;
+    float dist = 0.f;
+    int a = 0, b = 0, l = 0, ax = 0, ay = 0;
+    const bool ok = g < total;
+    if (ok) {
+      a = (int)(g % d.A); b = (int)(g / d.A);
+      if (d.nlevels > 1 && a >= d.a0[1]) l = 1;
+      if (d.nlevels > 2 && a >= d.a0[2]) l = 2;
+      const int al = a - d.a0[l];
+      ay = al / d.ws[l]; ax = al - ay * d.ws[l];
+      const T* bp = reinterpret_cast<const T*>(d.box[l]) + ((size_t)b * d.hs[l] * d.ws[l] + al) * d.box_ld[l] + side * 16;
       float v[16];
-      float mx = -INFINITY;
+      if constexpr (VEC == 8) {
+        unpack16<T>(*reinterpret_cast<const u32x4*>(bp), v);
+        unpack16<T>(*reinterpret_cast<const u32x4*>(bp + 8), v + 8);
+      } else {
 #pragma unroll
-      for (int i = 0; i < 16; ++i) { v[i] = (float)bp[s * 16 + i]; mx = fmaxf(mx, v[i]); }
-      float sum = 0.f, ws = 0.f;
+        for (int i = 0; i < 4; ++i) unpack16<T>(*reinterpret_cast<const u32x4*>(bp + 4 * i), v + 4 * i);
+      }
+      float mx = v[0];
+#pragma unroll
+      for (int i = 1; i < 16; ++i) mx = fmaxf(mx, v[i]);
+      float sum = 0.f, wsum = 0.f;
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const float e = FAST ? __expf(v[i] - mx) : expf(v[i] - mx);
         sum += e;
-        ws += e * (float)i;
+        wsum += e * (float)i;
       }
-      dist[s] = ws / sum;
+      dist = wsum / sum;
     }
-    const float cxa = (float)ax + 0.5f, cya = (float)ay + 0.5f;
-    const float x1 = cxa - dist[0], y1 = cya - dist[1], x2 = cxa + dist[2], y2 = cya + dist[3];
-    const float st = d.strides[l];
-    float* o = pred + (size_t)b * (4 + d.nc) * d.A + a;
-    o[0] = (x1 + x2) / 2.f * st;
-    o[(size_t)d.A] = (y1 + y2) / 2.f * st;
-    o[(size_t)2 * d.A] = (x2 - x1) * st;
-    o[(size_t)3 * d.A] = (y2 - y1) * st;
-    const T* cp = reinterpret_cast<const T*>(d.cls[l]) + pix * d.cls_ld[l];
-    for (int c = 0; c < d.nc; ++c) o[(size_t)(4 + c) * d.A] = act_apply<FAST>((float)cp[c], CVMI_ACT_SIGMOID);
+    const int lane4 = (threadIdx.x & 63) & ~3;
+    float dd[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) dd[j] = __shfl(dist, lane4 + j);       // the 4 sides of this anchor
+    if (ok) {
+      const float cxa = (float)ax + 0.5f, cya = (float)ay + 0.5f;
+      const float x1 = cxa - dd[0], y1 = cya - dd[1], x2 = cxa + dd[2], y2 = cya + dd[3];
+      const float st = d.strides[l];
+      float o;
+      if (side == 0) o = (x1 + x2) / 2.f * st;
+      else if (side == 1) o = (y1 + y2) / 2.f * st;
+      else if (side == 2) o = (x2 - x1) * st;
+      else o = (y2 - y1) * st;
+      pred[(size_t)b * (4 + d.nc) * d.A + (size_t)side * d.A + a] = o;
+    }
+  }
+  // ---- classes: chunk j = tid + 256*i -> (anchor j / nchunk, chunk j % nchunk)
+  const int nchunk = ncp / VEC;
+  for (int j = tid; j < 64 * nchunk; j += 256) {
+    const int al64 = j / nchunk, c0 = (j - al64 * nchunk) * VEC;
+    const long long g = g0 + al64;
+    float v[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) v[e] = 0.f;
+    if (g < total) {
+      const int a = (int)(g % d.A), b = (int)(g / d.A);
+      int l = 0;
+      if (d.nlevels > 1 && a >= d.a0[1]) l = 1;
+      if (d.nlevels > 2 && a >= d.a0[2]) l = 2;
+      const int al = a - d.a0[l];
+      const T* cp = reinterpret_cast<const T*>(d.cls[l]) + ((size_t)b * d.hs[l] * d.ws[l] + al) * d.cls_ld[l] + c0;
+      unpack16<T>(*reinterpret_cast<const u32x4*>(cp), v);
+    }
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) tile[al64 * TS + c0 + e] = act_apply<FAST>(v[e], CVMI_ACT_SIGMOID);
+  }
+  __syncthreads();
+  if (tid < 64 && best_score) {
+    const long long g = g0 + tid;
+    if (g < total) {
+      float best = tile[tid * TS];
+      int bc = 0;
+      for (int c = 1; c < d.nc; ++c) {
+        const float v = tile[tid * TS + c];
+        if (v > best) { best = v; bc = c; }
+      }
+      best_score[g] = best;
+      best_cls[g] = bc;
+    }
+  }
+  if (write_cls) {
+    for (int j = tid; j < 64 * d.nc; j += 256) {
+      const int c = j >> 6, al64 = j & 63;
+      const long long g = g0 + al64;
+      if (g < total) {
+        const int a = (int)(g % d.A), b = (int)(g / d.A);
+        pred[(size_t)b * (4 + d.nc) * d.A + (size_t)(4 + c) * d.A + a] = tile[al64 * TS + c];
+      }
+    }
   }
 }
 
@@ -164,9 +291,12 @@ __device__ __forceinline__ void lb_axis(int d, int dst, int src, int& s0, int& s
   s1 = s + 1 < src ? s + 1 : src - 1;
 }
 
+// s2d = 1: the output is written space-to-depth(2) with 16 channels per 2x2 block,
+// dst[(y/2, x/2)][((y&1)*2 + (x&1))*3 + c] (channels 12..15 zero), so that the stride-2 3x3 stem conv becomes a
+// stride-1 2x2 conv with 16-byte-aligned channel vectors (see Yolo11Weights.stem).
 template <typename T>
 __global__ __launch_bounds__(256) void letterbox_kernel(const uint8_t* __restrict__ src, int H, int W, T* __restrict__ dst, int out_h,
-                                                       int out_w, int new_h, int new_w, int top, int left) {
+                                                       int out_w, int new_h, int new_w, int top, int left, int s2d) {
   const int total = out_h * out_w;
   for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
     const int ox = idx % out_w, oy = idx / out_w;
@@ -190,6 +320,10 @@ __global__ __launch_bounds__(256) void letterbox_kernel(const uint8_t* __restric
       }
     }
     T* o = dst + (size_t)idx * 3;
+    if (s2d) {
+      o = dst + ((size_t)(oy >> 1) * (out_w >> 1) + (ox >> 1)) * 16 + ((oy & 1) * 2 + (ox & 1)) * 3;
+      if ((oy & 1) && (ox & 1)) { o[3] = (T)0.f; o[4] = (T)0.f; o[5] = (T)0.f; o[6] = (T)0.f; }     // channels 12..15
+    }
     o[0] = (T)((float)v[2] / 255.0f);   // reversed channel order (ultralytics im[..., ::-1])
     o[1] = (T)((float)v[1] / 255.0f);
     o[2] = (T)((float)v[0] / 255.0f);
@@ -258,7 +392,12 @@ extern "C" int cvmi_sppf_pool(void* buf, int ld, int B, int H, int W, int C, int
   CVMI_CHECK(((uintptr_t)buf & 15) == 0, "sppf_pool: pointer not 16-byte aligned");
   hipStream_t stream = (hipStream_t)stream_;
   const long long total = (long long)B * H * W * (C / vec);
-  if (dtype == CVMI_F16)
+  const size_t lds = (size_t)2 * H * W * vec * sizeof(float);
+  if (lds <= 64 * 1024) {
+    const unsigned blocks = (unsigned)(B * (C / vec));
+    if (dtype == CVMI_F16) hipLaunchKernelGGL(sppf_pool_lds_kernel<f16>, dim3(blocks), dim3(256), lds, stream, (char*)buf, ld, H, W, C);
+    else hipLaunchKernelGGL(sppf_pool_lds_kernel<float>, dim3(blocks), dim3(256), lds, stream, (char*)buf, ld, H, W, C);
+  } else if (dtype == CVMI_F16)
     hipLaunchKernelGGL(sppf_pool_kernel<f16>, dim3(grid_for(total)), dim3(256), 0, stream, (char*)buf, ld, B, H, W, C);
   else
     hipLaunchKernelGGL(sppf_pool_kernel<float>, dim3(grid_for(total)), dim3(256), 0, stream, (char*)buf, ld, B, H, W, C);
@@ -268,15 +407,19 @@ extern "C" int cvmi_sppf_pool(void* buf, int ld, int B, int H, int W, int C, int
 
 extern "C" int cvmi_detect_decode(const void* const* box, const int* box_ld, const void* const* cls, const int* cls_ld, const int* hs,
                                   const int* ws, const float* strides, int nlevels, int B, int nc, int dtype, float* pred,
-                                  cvmi_stream_t stream_) {
+                                  float* best_score, int* best_cls, int write_cls, cvmi_stream_t stream_) {
   CVMI_CHECK(box && cls && box_ld && cls_ld && hs && ws && strides && pred, "detect_decode: null pointer");
-  CVMI_CHECK(nlevels >= 1 && nlevels <= 3 && B > 0 && nc > 0, "detect_decode: bad shape");
+  CVMI_CHECK(nlevels >= 1 && nlevels <= 3 && B > 0 && nc > 0 && nc <= 1024, "detect_decode: bad shape");
   CVMI_CHECK(dtype == CVMI_F16 || dtype == CVMI_F32, "detect_decode: bad dtype");
+  CVMI_CHECK((best_score == nullptr) == (best_cls == nullptr), "detect_decode: best_score / best_cls go together");
+  const int vec = dtype == CVMI_F16 ? 8 : 4;
+  const int ncp = (nc + vec - 1) / vec * vec;
   DetectArgs d;
   int A = 0;
   for (int l = 0; l < 3; ++l) {
     if (l < nlevels) {
-      CVMI_CHECK(box[l] && cls[l] && hs[l] > 0 && ws[l] > 0 && box_ld[l] >= 64 && cls_ld[l] >= nc, "detect_decode: bad level %d", l);
+      CVMI_CHECK(box[l] && cls[l] && hs[l] > 0 && ws[l] > 0 && box_ld[l] >= 64 && cls_ld[l] >= ncp, "detect_decode: level %d: ld must cover 64 box / %d class channels", l, ncp);
+      CVMI_CHECK(box_ld[l] % vec == 0 && cls_ld[l] % vec == 0 && (((uintptr_t)box[l] | (uintptr_t)cls[l]) & 15) == 0, "detect_decode: level %d not 16-byte aligned", l);
       d.box[l] = (const char*)box[l]; d.cls[l] = (const char*)cls[l];
       d.box_ld[l] = box_ld[l]; d.cls_ld[l] = cls_ld[l]; d.hs[l] = hs[l]; d.ws[l] = ws[l]; d.strides[l] = strides[l];
       d.a0[l] = A;
@@ -288,16 +431,20 @@ extern "C" int cvmi_detect_decode(const void* const* box, const int* box_ld, con
   d.nlevels = nlevels; d.B = B; d.nc = nc; d.A = A;
   hipStream_t stream = (hipStream_t)stream_;
   const long long total = (long long)B * A;
+  const unsigned blocks = (unsigned)((total + 63) / 64);
+  const size_t lds = (size_t)64 * (ncp + 1) * sizeof(float);
+  CVMI_CHECK(lds <= 64 * 1024, "detect_decode: nc too large for the LDS tile");
   if (dtype == CVMI_F16)
-    hipLaunchKernelGGL(detect_decode_kernel<f16>, dim3(grid_for(total)), dim3(256), 0, stream, d, pred);
+    hipLaunchKernelGGL(detect_decode_kernel<f16>, dim3(blocks), dim3(256), lds, stream, d, pred, best_score, best_cls, write_cls);
   else
-    hipLaunchKernelGGL(detect_decode_kernel<float>, dim3(grid_for(total)), dim3(256), 0, stream, d, pred);
+    hipLaunchKernelGGL(detect_decode_kernel<float>, dim3(blocks), dim3(256), lds, stream, d, pred, best_score, best_cls, write_cls);
   CVMI_LAUNCH_CHECK();
   return 0;
 }
 
 extern "C" int cvmi_letterbox(const uint8_t* src, int H, int W, void* dst, int out_h, int out_w, int new_h, int new_w, int top, int left,
-                              int dtype, cvmi_stream_t stream_) {
+                              int dtype, int s2d, cvmi_stream_t stream_) {
+  CVMI_CHECK(!s2d || (out_h % 2 == 0 && out_w % 2 == 0), "letterbox: space-to-depth output needs even out_h, out_w");
   CVMI_CHECK(src && dst, "letterbox: null pointer");
   CVMI_CHECK(H > 0 && W > 0 && out_h > 0 && out_w > 0 && new_h > 0 && new_w > 0 && top >= 0 && left >= 0 && top + new_h <= out_h &&
                  left + new_w <= out_w, "letterbox: bad geometry");
@@ -305,9 +452,9 @@ extern "C" int cvmi_letterbox(const uint8_t* src, int H, int W, void* dst, int o
   hipStream_t stream = (hipStream_t)stream_;
   const long long total = (long long)out_h * out_w;
   if (dtype == CVMI_F16)
-    hipLaunchKernelGGL(letterbox_kernel<f16>, dim3(grid_for(total)), dim3(256), 0, stream, src, H, W, (f16*)dst, out_h, out_w, new_h, new_w, top, left);
+    hipLaunchKernelGGL(letterbox_kernel<f16>, dim3(grid_for(total)), dim3(256), 0, stream, src, H, W, (f16*)dst, out_h, out_w, new_h, new_w, top, left, s2d);
   else
-    hipLaunchKernelGGL(letterbox_kernel<float>, dim3(grid_for(total)), dim3(256), 0, stream, src, H, W, (float*)dst, out_h, out_w, new_h, new_w, top, left);
+    hipLaunchKernelGGL(letterbox_kernel<float>, dim3(grid_for(total)), dim3(256), 0, stream, src, H, W, (float*)dst, out_h, out_w, new_h, new_w, top, left, s2d);
   CVMI_LAUNCH_CHECK();
   return 0;
 }

@@ -70,8 +70,10 @@ class YOLO:
     """`YOLO(path)`; path is a checkpoint (torch-saved dict with 'state_dict' (ultralytics keys),
     'names', 'scale') or 'synthetic:<scale>:<nc>[:seed]' for seeded random weights."""
 
-    def __init__(self, path, dtype="f16", device="cuda", imgsz=640):
+    def __init__(self, path, dtype="f16", device="cuda", imgsz=640, keep_scores=False):
+        """keep_scores=True also materialises ultralytics' full [B, 4+nc, A] prediction tensor (tests / debugging)."""
         require_gpu()
+        self.keep_scores = keep_scores
         self.dtype = {"f16": F16, "fp16": F16, "f32": F32, "fp32": F32}[dtype] if isinstance(dtype, str) else dtype
         self.device = device
         self.imgsz = imgsz
@@ -101,7 +103,7 @@ class YOLO:
         key = (B, H, W, conf, iou, max_det)
         if key not in self._plans:
             with torch.cuda.device(self.device):
-                self._plans[key] = Yolo11Plan(self.weights, B, H, W, self.stream, conf, iou, max_det)
+                self._plans[key] = Yolo11Plan(self.weights, B, H, W, self.stream, conf, iou, max_det, keep_scores=self.keep_scores)
         return self._plans[key]
 
     # ---- reference entry point -----------------------------------------------------------------
@@ -126,7 +128,7 @@ class YOLO:
                     src = torch.from_numpy(np.ascontiguousarray(im)).to(self.device, non_blocking=False)
                     srcs.append(src)
                     dst = p.x_in.t[b]
-                    _lib.check(lib.cvmi_letterbox(src.data_ptr(), h0, w0, dst.data_ptr(), H, W, nh, nw, top, left, self.dtype, sp), "letterbox")
+                    _lib.check(lib.cvmi_letterbox(src.data_ptr(), h0, w0, dst.data_ptr(), H, W, nh, nw, top, left, self.dtype, 1, sp), "letterbox")
                 p.plan.run()
                 self.stream.synchronize()
                 counts = p.det_count.cpu().tolist()

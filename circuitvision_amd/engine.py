@@ -72,7 +72,7 @@ class PackedConv:
         N, Cin, KH, KW = weight.shape
         K = Cin * KH * KW
         Npad = (N + 127) // 128 * 128
-        Kpad = (K + 31) // 32 * 32
+        Kpad = (K + 63) // 64 * 64
         w = torch.zeros(Npad, Kpad, dtype=torch.float32)
         w[:N, :K] = weight.permute(0, 2, 3, 1).reshape(N, K)
         b = torch.zeros(Npad, dtype=torch.float32)
@@ -173,8 +173,9 @@ def op_conv(plan, label, pc, srcs, dst, stride=1, pad=None, act=_lib.ACT_NONE, r
     pad = pc.KH // 2 if pad is None else pad
     OH = (H + 2 * pad - pc.KH) // stride + 1
     OW = (W + 2 * pad - pc.KW) // stride + 1
-    if out_hw is not None:
-        assert (OH, OW) == tuple(out_hw)
+    if out_hw is not None:                     # explicit output size (asymmetric padding: fewer rows/cols than the formula)
+        assert out_hw[0] <= OH and out_hw[1] <= OW
+        OH, OW = out_hw
     if shuffle_cout:
         assert (dst.B, dst.H, dst.W) == (v0.B, 2 * OH, 2 * OW) and dst.c == shuffle_cout and pc.N == 4 * shuffle_cout, label
     else:

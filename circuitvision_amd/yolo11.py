@@ -20,7 +20,7 @@ import torch
 
 from . import _lib
 from ._lib import ACT_NONE, ACT_SILU, F16, F32
-from .engine import ESIZE, Buf, PackedConv, PackedDW, Plan, op_attention, op_conv, op_dwconv, op_sppf_pool, make_attn_desc
+from .engine import ESIZE, Buf, PackedConv, PackedDW, Plan, op_attention, op_call, op_conv, op_dwconv, op_sppf_pool, make_attn_desc
 
 SCALES = {"n": (0.50, 0.25, 1024), "s": (0.50, 0.50, 1024), "m": (0.50, 1.00, 512),
           "l": (1.00, 1.00, 512), "x": (1.00, 1.50, 512)}
@@ -158,9 +158,22 @@ class Yolo11Weights:
                 self.bottleneck(f"{name}.m.{i}", c, 0.5)
         self.conv(f"{name}.cv2", (2 + n) * c, c2, 1)
 
+    def stem(self, name, c2):
+        """Layer 0 (3x3, stride 2, 3 channels) re-expressed on the space-to-depth(2) input the letterbox kernel writes:
+        a 2x2 / stride-1 conv over 16 channels (12 real), taps (ty, tx) = block offsets (-1, 0).  Window row ky sits in
+        block row ty with sub-row sy: ky=0 -> (0,1), ky=1 -> (1,0), ky=2 -> (1,1); same for columns."""
+        w, b = self._fold(name, 3, c2, 3)
+        w2 = torch.zeros(c2, 16, 2, 2)
+        m = {0: (0, 1), 1: (1, 0), 2: (1, 1)}
+        for ky in range(3):
+            for kx in range(3):
+                (ty, sy), (tx, sx) = m[ky], m[kx]
+                w2[:, (sy * 2 + sx) * 3:(sy * 2 + sx) * 3 + 3, ty, tx] = w[:, :, ky, kx]
+        self._add(name, PackedConv(w2, b, self.dtype, self.device))
+
     def _walk(self):
         ch, rep, ca = self.ch, self.rep, self.c3k_all
-        self.conv("model.0", 3, ch(64), 3)
+        self.stem("model.0", ch(64))
         self.conv("model.1", ch(64), ch(128), 3)
         self.c3k2("model.2", ch(128), ch(256), rep(2), ca, 0.25)
         self.conv("model.3", ch(256), ch(256), 3)
@@ -215,7 +228,10 @@ class Yolo11Plan:
     """Launch plan of the full forward for one (B, H, W): input NHWC [B,H,W,3] -> pred f32 [B,4+nc,A]
     -> NMS outputs."""
 
-    def __init__(self, weights, B, H, W, stream, conf=0.25, iou=0.7, max_det=300, with_nms=True):
+    def __init__(self, weights, B, H, W, stream, conf=0.25, iou=0.7, max_det=300, with_nms=True, keep_scores=True):
+        """keep_scores=False: the decode kernel skips the class-score rows of `pred` (NMS takes the per-anchor
+        best class straight from the decode kernel); the detections are identical."""
+        self.keep_scores = keep_scores
         assert H % 32 == 0 and W % 32 == 0, "network input must be a multiple of stride 32"
         self.wt, self.B, self.H, self.W = weights, B, H, W
         self.dt, self.dev = weights.dtype, weights.device
@@ -270,9 +286,9 @@ class Yolo11Plan:
     def _build(self, with_nms):
         wt, ch, rep, ca = self.wt, self.wt.ch, self.wt.rep, self.wt.c3k_all
         B, H, W = self.B, self.H, self.W
-        self.x_in = Buf(B, H, W, 3, self.dt, self.dev, zero=True)
+        self.x_in = Buf(B, H // 2, W // 2, 16, self.dt, self.dev, zero=True)       # space-to-depth(2) image, see Yolo11Weights.stem
         x = self.buf(H // 2, W // 2, ch(64)).view()
-        self.cv("model.0", self.x_in.view(), x, 3, 2, scalar=True, kind="stem")
+        op_conv(self.plan, "model.0", wt.packed["model.0"], [(self.x_in.view(), 0)], x, stride=1, pad=1, act=ACT_SILU, out_hw=(H // 2, W // 2), kind="stem")
         y = self.buf(H // 4, W // 4, ch(128)).view()
         self.cv("model.1", x, y, 3, 2)
         x = self.c3k2("model.2", [(y, 0)], ch(256), rep(2), ca, 0.25)
@@ -381,24 +397,41 @@ class Yolo11Plan:
         strides = (C.c_float * nl)(*[float(self.H // f.H) for f in feats])
         self.plan.keep.append((box_p, cls_p, box_ld, cls_ld, hs, ws, strides))
         sp, dt, pred_ptr, Bn = self.plan.sptr, self.dt, self.pred.data_ptr(), self.B
+        self.best_score = torch.zeros(Bn * A, dtype=torch.float32, device=self.dev)
+        self.best_cls = torch.zeros(Bn * A, dtype=torch.int32, device=self.dev)
+        bs_ptr, bc_ptr, wcls = self.best_score.data_ptr(), self.best_cls.data_ptr(), 1 if self.keep_scores else 0
+        if not self.keep_scores:
+            self.pred.zero_()
 
         def decode():
-            _lib.check(lib.cvmi_detect_decode(box_p, box_ld, cls_p, cls_ld, hs, ws, strides, nl, Bn, nc, dt, pred_ptr, sp), "detect_decode")
+            _lib.check(lib.cvmi_detect_decode(box_p, box_ld, cls_p, cls_ld, hs, ws, strides, nl, Bn, nc, dt, pred_ptr, bs_ptr, bc_ptr, wcls, sp), "detect_decode")
 
         es = ESIZE[self.dt]
-        self.plan.add("model.23.decode", "decode", decode, Bn * A * ((64 + nc) * es + (4 + nc) * 4), 0)
+        self.plan.add("model.23.decode", "decode", decode, Bn * A * ((64 + nc) * es + (4 + (nc if wcls else 2)) * 4), 0)
         if with_nms:
             self.det = torch.zeros(Bn, self.max_det, 6, dtype=torch.float32, device=self.dev)
             self.det_idx = torch.zeros(Bn, self.max_det, dtype=torch.int32, device=self.dev)
             self.det_count = torch.zeros(Bn, dtype=torch.int32, device=self.dev)
             self.nms_ws = torch.empty(lib.cvmi_yolo_nms_workspace(Bn, A), dtype=torch.uint8, device=self.dev)
-            a = (pred_ptr, Bn, nc, A, float(self.conf), float(self.iou), int(self.max_det), 7680.0, self.det.data_ptr(),
+            a = (pred_ptr, bs_ptr, bc_ptr, Bn, nc, A, float(self.conf), float(self.iou), int(self.max_det), 7680.0, self.det.data_ptr(),
                  self.det_idx.data_ptr(), self.det_count.data_ptr(), self.nms_ws.data_ptr())
 
             def nms():
-                _lib.check(lib.cvmi_yolo_nms(*a, sp), "yolo_nms")
+                _lib.check(lib.cvmi_yolo_nms_best(*a, sp), "yolo_nms")
 
-            self.plan.add("nms", "nms", nms, Bn * A * (4 + nc) * 4, 0)
+            self.plan.add("nms", "nms", nms, Bn * A * 6 * 4, 0)
+
+    def set_input_nchw(self, x):
+        """x: [B,3,H,W] float tensor (already letterboxed, RGB-flipped, /255) -> the plan's space-to-depth input."""
+        B, _, H, W = x.shape
+        t = x.to(self.dev).reshape(B, 3, H // 2, 2, W // 2, 2).permute(0, 2, 4, 3, 5, 1).reshape(B, H // 2, W // 2, 12)
+        self.x_in.t.zero_()
+        self.x_in.t[..., :12] = t.to(self.x_in.t.dtype)
+
+    def input_nchw(self):
+        B, H2, W2, _ = self.x_in.t.shape
+        t = self.x_in.t[..., :12].float().reshape(B, H2, W2, 2, 2, 3).permute(0, 5, 1, 3, 2, 4).reshape(B, 3, H2 * 2, W2 * 2)
+        return t
 
     # -- accounting for the roofline line (SURVEY.md 8(d): layer-granular minimum traffic)
     def conv_stack_bytes(self):

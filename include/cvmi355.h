@@ -113,11 +113,14 @@ typedef struct cvmi_attn_desc {
 int cvmi_attention(const cvmi_attn_desc* d, cvmi_stream_t stream);
 
 /* ---- YOLO Detect decode: DFL expectation + dist2bbox + stride scale + class sigmoid -----------
- * box[l]: [B,Hl,Wl,64] (ld box_ld), cls[l]: [B,Hl,Wl,nc] (ld cls_ld) for l = 0..2.
- * pred: f32 [B, 4+nc, A], A = sum Hl*Wl (ultralytics layout: xywh then class scores). */
+ * box[l]: [B,Hl,Wl,64] (ld box_ld), cls[l]: [B,Hl,Wl,>=roundup(nc,16B)] (ld cls_ld) for l = 0..2.
+ * pred: f32 [B, 4+nc, A], A = sum Hl*Wl (ultralytics layout: xywh rows, then class-score rows).
+ * best_score f32 [B*A] / best_cls i32 [B*A] (optional, both or neither): per-anchor best class
+ * (first maximum) for cvmi_yolo_nms_best.  write_cls = 0 skips the class-score rows of pred. */
 int cvmi_detect_decode(const void* const* box, const int* box_ld, const void* const* cls,
                        const int* cls_ld, const int* hs, const int* ws, const float* strides,
-                       int nlevels, int B, int nc, int dtype, float* pred, cvmi_stream_t stream);
+                       int nlevels, int B, int nc, int dtype, float* pred, float* best_score,
+                       int* best_cls, int write_cls, cvmi_stream_t stream);
 
 /* ---- ultralytics-semantics NMS on the decoded predictions -------------------------------------
  * pred f32 [B, 4+nc, A].  Candidates: max class score > conf_thres; sorted by score desc (ties:
@@ -129,12 +132,19 @@ size_t cvmi_yolo_nms_workspace(int B, int A);
 int cvmi_yolo_nms(const float* pred, int B, int nc, int A, float conf_thres, float iou_thres,
                   int max_det, float max_wh, float* out_det, int* out_idx, int* out_count,
                   void* workspace, cvmi_stream_t stream);
+/* same, with the per-anchor best class supplied by cvmi_detect_decode (only the 4 box rows of pred are read) */
+int cvmi_yolo_nms_best(const float* pred, const float* best_score, const int* best_cls, int B, int nc,
+                       int A, float conf_thres, float iou_thres, int max_det, float max_wh,
+                       float* out_det, int* out_idx, int* out_count, void* workspace,
+                       cvmi_stream_t stream);
 
 /* ---- letterbox pre-processing (ultralytics LetterBox + BGR flip + /255) -----------------------
- * src u8 [H,W,3] -> dst [1? no: one image] NHWC dtype [out_h,out_w,3] at dst; resized region
- * new_w x new_h placed at (left, top); pad value 114.  8-bit fixed-point bilinear as OpenCV. */
+ * src u8 [H,W,3] -> one letterboxed image at dst: the resized region new_w x new_h is placed at
+ * (left, top) of an out_h x out_w canvas, pad value 114; 8-bit fixed-point bilinear as OpenCV.
+ * s2d = 0: dst is NHWC [out_h, out_w, 3].  s2d = 1: dst is space-to-depth(2) [out_h/2, out_w/2, 16],
+ * channel ((y&1)*2 + (x&1))*3 + c, channels 12..15 zero -- the layout the YOLO stem conv reads. */
 int cvmi_letterbox(const uint8_t* src, int H, int W, void* dst, int out_h, int out_w, int new_h,
-                   int new_w, int top, int left, int dtype, cvmi_stream_t stream);
+                   int new_w, int top, int left, int dtype, int s2d, cvmi_stream_t stream);
 
 /* ---- dtype conversion / layout helpers -------------------------------------------------------- */
 /* NCHW (f32 or f16) -> NHWC dtype */

@@ -66,7 +66,8 @@ def test_product_synthetic_checkpoint_loads_strictly_into_oracle():
         wt = Yolo11Weights(scale, 62, p, F32, device="cpu")
         m = YOLO11(scale, 62)
         m.load_state_dict(p.state_dict(), strict=True)
-        n_packed = sum(pc.param_bytes for pc in wt.packed.values()) // 4
+        stem = wt.packed["model.0"]                      # stored space-to-depth: 16x2x2 taps of which 27 are real
+        n_packed = sum(pc.param_bytes for pc in wt.packed.values()) // 4 - stem.N * (64 - 27)
         n_conv = sum(v.numel() for k, v in p.state_dict().items() if k.endswith("conv.weight") or re.search(r"cv[23]\.\d\.2\.weight$", k))
         assert n_packed == n_conv - 16        # everything but the DFL's constant arange(16) conv
 

@@ -88,8 +88,17 @@ def test_detect_decode(dtype):
     ws = (C.c_int * nl)(20, 10, 5)
     st = (C.c_float * nl)(8.0, 16.0, 32.0)
     torch.cuda.synchronize()
-    _lib.check(lib.cvmi_detect_decode(box_p, ld64, cls_p, ld64, hs, ws, st, nl, B, nc, dtype, pred.data_ptr(), None), "decode")
+    bs = torch.zeros(B * A, device="cuda")
+    bc = torch.zeros(B * A, dtype=torch.int32, device="cuda")
+    _lib.check(lib.cvmi_detect_decode(box_p, ld64, cls_p, ld64, hs, ws, st, nl, B, nc, dtype, pred.data_ptr(), bs.data_ptr(), bc.data_ptr(), 1, None), "decode")
     torch.cuda.synchronize()
+    got = pred.cpu()
+    m, am = got[:, 4:].max(1)
+    assert torch.equal(bs.cpu().view(B, A), m) and torch.equal(bc.cpu().view(B, A).long(), am)     # best class == first maximum
+    pred2 = torch.zeros_like(pred)
+    _lib.check(lib.cvmi_detect_decode(box_p, ld64, cls_p, ld64, hs, ws, st, nl, B, nc, dtype, pred2.data_ptr(), None, None, 0, None), "decode")
+    torch.cuda.synchronize()
+    assert torch.equal(pred2[:, :4], pred[:, :4]) and float(pred2[:, 4:].abs().max()) == 0.0
     tol = dict(rtol=2e-3, atol=2e-3) if dtype == F16 else dict(rtol=1e-5, atol=1e-5)
     torch.testing.assert_close(pred.cpu(), ref, **tol)
 
@@ -105,9 +114,15 @@ def test_letterbox_bit_exact(hw):
     src = torch.from_numpy(img).cuda()
     dst = torch.zeros(H, W, 3, device="cuda")
     torch.cuda.synchronize()
-    _lib.check(lib.cvmi_letterbox(src.data_ptr(), hw[0], hw[1], dst.data_ptr(), H, W, nh, nw, top, left, F32, None), "letterbox")
+    _lib.check(lib.cvmi_letterbox(src.data_ptr(), hw[0], hw[1], dst.data_ptr(), H, W, nh, nw, top, left, F32, 0, None), "letterbox")
     torch.cuda.synchronize()
     assert torch.equal(dst.cpu().permute(2, 0, 1), torch.from_numpy(ref))
+    # space-to-depth form (what the stem conv reads): same pixels, channel = ((y&1)*2 + (x&1))*3 + c
+    s2d = torch.full((H // 2, W // 2, 16), 7.0, device="cuda")
+    _lib.check(lib.cvmi_letterbox(src.data_ptr(), hw[0], hw[1], s2d.data_ptr(), H, W, nh, nw, top, left, F32, 1, None), "letterbox")
+    torch.cuda.synchronize()
+    back = s2d[..., :12].reshape(H // 2, W // 2, 2, 2, 3).permute(0, 2, 1, 3, 4).reshape(H, W, 3)
+    assert torch.equal(back, dst) and float(s2d[..., 12:].abs().max()) == 0.0
 
 
 def _oracle_from(params, scale, nc):
@@ -128,7 +143,7 @@ def test_yolo11_forward_matches_oracle(dtype, scale):
     with torch.no_grad():
         ref, raw, feats = oracle(x, return_feats=True)
     plan = Yolo11Plan(wt, B, H, W, torch.cuda.Stream())
-    plan.x_in.t.copy_(x.permute(0, 2, 3, 1).to(TORCH_DTYPE[dtype]))
+    plan.set_input_nchw(x)
     torch.cuda.synchronize()
     plan.plan.run_eager()
     torch.cuda.synchronize()
