@@ -59,16 +59,39 @@ template <> struct Elem<float> {
   __device__ static __forceinline__ float from_f(float v) { return v; }
 };
 
+// exact-GELU with erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, far below fp16 resolution): ~15 instructions
+// instead of libm erff's ~45; used only where the result is stored as fp16.
+__device__ __forceinline__ float gelu_fast(float v) {
+  const float x = fabsf(v) * 0.70710678118654752440f;
+  const float t = __frcp_rn(fmaf(0.3275911f, x, 1.0f));
+  float poly = fmaf(1.061405429f, t, -1.453152027f);
+  poly = fmaf(poly, t, 1.421413741f);
+  poly = fmaf(poly, t, -0.284496736f);
+  poly = fmaf(poly, t, 0.254829592f);
+  const float erfa = 1.0f - poly * t * __expf(-x * x);
+  return 0.5f * v * (1.0f + copysignf(erfa, v));
+}
+
 // FAST = true: v_exp/v_rcp based (fp16 storage mode); false: precise libm (f32 parity mode)
 template <bool FAST> __device__ __forceinline__ float act_apply(float v, int act) {
   switch (act) {
     case CVMI_ACT_SILU:
       return FAST ? v * __frcp_rn(1.0f + __expf(-v)) : v / (1.0f + expf(-v));
     case CVMI_ACT_RELU: return v > 0.f ? v : 0.f;
-    case CVMI_ACT_GELU: return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+    case CVMI_ACT_GELU: return FAST ? gelu_fast(v) : 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
     case CVMI_ACT_SIGMOID:
       return FAST ? __frcp_rn(1.0f + __expf(-v)) : 1.0f / (1.0f + expf(-v));
     default: return v;
+  }
+}
+// run `body(fn)` with fn = the activation selected ONCE (p.act is uniform): no per-element switch in hot loops
+template <bool FAST, typename Body> __device__ __forceinline__ void with_act(int act, Body&& body) {
+  switch (act) {
+    case CVMI_ACT_SILU: body([](float v) { return act_apply<FAST>(v, CVMI_ACT_SILU); }); break;
+    case CVMI_ACT_RELU: body([](float v) { return act_apply<FAST>(v, CVMI_ACT_RELU); }); break;
+    case CVMI_ACT_GELU: body([](float v) { return act_apply<FAST>(v, CVMI_ACT_GELU); }); break;
+    case CVMI_ACT_SIGMOID: body([](float v) { return act_apply<FAST>(v, CVMI_ACT_SIGMOID); }); break;
+    default: body([](float v) { return v; }); break;
   }
 }
 template <typename T> struct FastMath { static constexpr bool value = true; };

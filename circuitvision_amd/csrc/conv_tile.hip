@@ -36,7 +36,7 @@ template <> struct MmaT<float> {
 };
 
 template <typename T, int KS, int S, int CC, int BN, int WM, int WN>
-__global__ __launch_bounds__(256) void conv_tile_kernel(const TileArgs p) {
+__global__ __launch_bounds__(256, 3) void conv_tile_kernel(const TileArgs p) {
   constexpr int ES = sizeof(T);
   constexpr int VEC = 16 / ES;
   constexpr int PH = (TH - 1) * S + KS, PW = (TW - 1) * S + KS;
@@ -97,37 +97,38 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const TileArgs p) {
     //      the chunk is issued before the first LDS write, so the staging costs ONE memory round trip
     constexpr int NP = (PH * PW * CCH + 255) / 256, NW = (BN * WCH + 255) / 256;
     u32x4 pv[NP], wv_[NW];
+    bool pok[NP], wok[NW];                              // masks applied at LDS-write time (loads stay back to back)
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
       const int id = tid + i * 256;
       const int pp = id / CCH, ch = id - pp * CCH;
       const int pr = pp / PW, pc = pp - pr * PW;
       const int iy = iy0 + pr, ix = ix0 + pc;
-      u32x4 v = {0u, 0u, 0u, 0u};
-      if (id < PH * PW * CCH && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
-        v = *reinterpret_cast<const u32x4*>(p.x + ((((size_t)b * p.H + iy) * p.W + ix) * p.x_ld + c0 + ch * VEC) * ES);
-      pv[i] = v;
+      const bool ok = id < PH * PW * CCH && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+      const int iyc = ok ? iy : 0, ixc = ok ? ix : 0;                  // branch-free: clamped address + select
+      pv[i] = *reinterpret_cast<const u32x4*>(p.x + ((((size_t)b * p.H + iyc) * p.W + ixc) * p.x_ld + c0 + (ok ? ch * VEC : 0)) * ES);
+      pok[i] = ok;
     }
 #pragma unroll
     for (int i = 0; i < NW; ++i) {
       const int id = tid + i * 256;
       const int n = id / WCH, r = id - n * WCH;
       const int tap = r / CCH, ch = r - tap * CCH;
-      u32x4 v = {0u, 0u, 0u, 0u};
-      if (id < BN * WCH && tap < NTAP) v = *reinterpret_cast<const u32x4*>(p.w + ((size_t)(n0 + n) * p.Kpad + tap * p.Cin + c0 + ch * VEC) * ES);
-      wv_[i] = v;
+      const bool ok = id < BN * WCH && tap < NTAP;
+      wv_[i] = *reinterpret_cast<const u32x4*>(p.w + ((size_t)(n0 + (ok ? n : 0)) * p.Kpad + (ok ? tap * p.Cin + c0 + ch * VEC : 0)) * ES);
+      wok[i] = ok;
     }
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
       const int id = tid + i * 256;
       const int pp = id / CCH, ch = id - pp * CCH;
-      if (id < PH * PW * CCH) *reinterpret_cast<u32x4*>(patch + pp * PSTR + ch * 16) = pv[i];
+      if (id < PH * PW * CCH) *reinterpret_cast<u32x4*>(patch + pp * PSTR + ch * 16) = pok[i] ? pv[i] : u32x4{0u, 0u, 0u, 0u};
     }
 #pragma unroll
     for (int i = 0; i < NW; ++i) {
       const int id = tid + i * 256;
       const int n = id / WCH, r = id - n * WCH;
-      if (id < BN * WCH) *reinterpret_cast<u32x4*>(wslab + n * WROW + r * 16) = wv_[i];
+      if (id < BN * WCH) *reinterpret_cast<u32x4*>(wslab + n * WROW + r * 16) = wok[i] ? wv_[i] : u32x4{0u, 0u, 0u, 0u};
     }
     __syncthreads();
     // ---- MFMA over taps x channel steps ---------------------------------------------------------------
@@ -171,29 +172,31 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const TileArgs p) {
   // ---- epilogue: bias + act -> LDS [128][BN] -> 16-byte channel-contiguous stores (+ residual) ----------
   char* const Ct = smem;
   constexpr bool FAST = FastMath<T>::value;
+  with_act<FAST>(p.act, [&](auto actf) {
 #pragma unroll
-  for (int i = 0; i < TN; ++i) {
+    for (int i = 0; i < TN; ++i) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int nl = wn * WTN + i * 32 + 8 * q + 4 * lh;
-      const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + n0 + nl);
+      for (int q = 0; q < 4; ++q) {
+        const int nl = wn * WTN + i * 32 + 8 * q + 4 * lh;
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + n0 + nl);
 #pragma unroll
-      for (int j = 0; j < TM; ++j) {
-        const int ml = wm * WTM + j * 32 + lr;
-        float v[4];
+        for (int j = 0; j < TM; ++j) {
+          const int ml = wm * WTM + j * 32 + lr;
+          float v[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = act_apply<FAST>(acc[i][j][4 * q + e] + bv[e], p.act);
-        char* dst = Ct + ml * CROWB + nl * ES;
-        if constexpr (ES == 2) {
-          f16x4 hv = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
-          *reinterpret_cast<f16x4*>(dst) = hv;
-        } else {
-          f32x4 fv = {v[0], v[1], v[2], v[3]};
-          *reinterpret_cast<f32x4*>(dst) = fv;
+          for (int e = 0; e < 4; ++e) v[e] = actf(acc[i][j][4 * q + e] + bv[e]);
+          char* dst = Ct + ml * CROWB + nl * ES;
+          if constexpr (ES == 2) {
+            f16x4 hv = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
+            *reinterpret_cast<f16x4*>(dst) = hv;
+          } else {
+            f32x4 fv = {v[0], v[1], v[2], v[3]};
+            *reinterpret_cast<f32x4*>(dst) = fv;
+          }
         }
       }
     }
-  }
+  });
   __syncthreads();
   constexpr int NCH = BN / VEC;
   for (int idx = tid; idx < BMT * NCH; idx += 256) {

@@ -19,6 +19,7 @@
 // of tile t and written to the other LDS buffer after them; one barrier per K-tile).
 #include "common.hpp"
 #include <stdlib.h>
+#include <string.h>
 
 namespace {
 
@@ -50,50 +51,60 @@ template <> struct Mma<float> {
   }
 };
 
+// Returns the RAW 16 bytes at a clamped (always valid) address and sets `ok`; the caller zeroes !ok chunks when it
+// writes the tile to LDS, i.e. after the MFMAs of the current tile -- a select next to the load would make the
+// compiler wait for the load before the compute it is supposed to overlap.
 template <typename T>
-__device__ __forceinline__ u32x4 gather_chunk(const ConvKArgs& p, int k, int b, int iy0, int ix0, bool row_ok) {
+__device__ __forceinline__ u32x4 gather_chunk(const ConvKArgs& p, int k, int b, int iy0, int ix0, bool row_ok, bool& ok_out) {
   u32x4 v = {0u, 0u, 0u, 0u};
+  ok_out = true;
   constexpr int VEC = Elem<T>::VEC;
   if (!p.scalar_gather) {
+    // branch-free: out-of-range chunks read a clamped (valid) address and are zeroed by a select, so that the
+    // loads of a K-tile issue back to back (an exec-masked branch per load makes hipcc serialise them with waits)
     const unsigned tap = p.div_ctot.div((unsigned)k);
     int ci = k - (int)tap * p.ctot;
     const unsigned ky = p.div_kw.div(tap);
     const int kx = (int)tap - (int)ky * p.KW;
     const int iy = iy0 + (int)ky, ix = ix0 + kx;
-    if (row_ok && k < p.K && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) {
-      const char* base; int ld, up;
-      if (ci < p.c0) { base = p.x0; ld = p.x0_ld; up = p.up0; }
-      else { base = p.x1; ld = p.x1_ld; up = p.up1; ci -= p.c0; }
-      const size_t pix = ((size_t)b * (p.H >> up) + (iy >> up)) * (size_t)(p.W >> up) + (ix >> up);
-      v = *reinterpret_cast<const u32x4*>(base + (pix * ld + ci) * sizeof(T));
-    }
+    const bool ok = row_ok && k < p.K && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+    const bool s0 = ci < p.c0;
+    const char* base = s0 ? p.x0 : p.x1;
+    const int ld = s0 ? p.x0_ld : p.x1_ld, up = s0 ? p.up0 : p.up1;
+    ci = s0 ? ci : ci - p.c0;
+    const int iyc = ok ? iy : 0, ixc = ok ? ix : 0, cic = ok ? ci : 0;
+    const size_t pix = ((size_t)b * (p.H >> up) + (iyc >> up)) * (size_t)(p.W >> up) + (ixc >> up);
+    v = *reinterpret_cast<const u32x4*>(base + (pix * ld + cic) * sizeof(T));
+    ok_out = ok;
   } else {
-    T tmp[VEC];
+    // per-element gather (3-channel stems): values are inserted into the vector directly (no local array -> no scratch)
+    using VT = T __attribute__((ext_vector_type(16 / sizeof(T))));
+    VT tv;
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
       const int ke = k + e;
-      T val = (T)0;
       const unsigned tap = p.div_ctot.div((unsigned)ke);
       int ci = ke - (int)tap * p.ctot;
       const unsigned ky = p.div_kw.div(tap);
       const int kx = (int)tap - (int)ky * p.KW;
       const int iy = iy0 + (int)ky, ix = ix0 + kx;
-      if (row_ok && ke < p.K && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) {
-        const char* base; int ld, up;
-        if (ci < p.c0) { base = p.x0; ld = p.x0_ld; up = p.up0; }
-        else { base = p.x1; ld = p.x1_ld; up = p.up1; ci -= p.c0; }
-        const size_t pix = ((size_t)b * (p.H >> up) + (iy >> up)) * (size_t)(p.W >> up) + (ix >> up);
-        val = *reinterpret_cast<const T*>(base + (pix * ld + ci) * sizeof(T));
-      }
-      tmp[e] = val;
+      const bool ok = row_ok && ke < p.K && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+      const bool s0 = ci < p.c0;
+      const char* base = s0 ? p.x0 : p.x1;
+      const int ld = s0 ? p.x0_ld : p.x1_ld, up = s0 ? p.up0 : p.up1;
+      ci = s0 ? ci : ci - p.c0;
+      const int iyc = ok ? iy : 0, ixc = ok ? ix : 0, cic = ok ? ci : 0;
+      const size_t pix = ((size_t)b * (p.H >> up) + (iyc >> up)) * (size_t)(p.W >> up) + (ixc >> up);
+      const T val = *reinterpret_cast<const T*>(base + (pix * ld + cic) * sizeof(T));
+      tv[e] = ok ? val : (T)0;
     }
-    v = *reinterpret_cast<const u32x4*>(tmp);
+    v = __builtin_bit_cast(u32x4, tv);
   }
   return v;
 }
 
 template <typename T, typename TO, int BM, int BN, int WM, int WN, int BKB, bool PLAIN>
-__global__ __launch_bounds__(256) void igemm_kernel(const ConvKArgs p) {
+__global__ __launch_bounds__(256, (BM * BN >= 128 * 128 ? 2 : 3)) void igemm_kernel(const ConvKArgs p) {
   // BKB = data bytes per LDS row per K-tile (64 or 128); PLAIN = 1x1 / stride 1 / one source: A is a plain
   // row-major matrix, so the per-tile gather arithmetic collapses to "row pointer + k"
   constexpr int ES = sizeof(T);
@@ -115,7 +126,15 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ConvKArgs p) {
   char* const Bs = smem + 2 * BM * ROWB;          // weights [2][BN][ROWB]
 
   const int tid = threadIdx.x;
-  const int bn = blockIdx.x % p.nb_n, bm = blockIdx.x / p.nb_n;
+  // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (private L2 each), so give every XCD a
+  // CONTIGUOUS run of tiles -- the nb_n column tiles that share one pixel/row tile then hit the same L2 instead of
+  // each XCD fetching that A tile again from the Infinity Cache (bijective for any grid size; speed only).
+  int wg = blockIdx.x;
+  {
+    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = wg & 7, j = wg >> 3;
+    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+  }
+  const int bn = wg % p.nb_n, bm = wg / p.nb_n;
   const int m0 = bm * BM, n0 = bn * BN;
 
   // ---- per-thread staging slots ---------------------------------------------------------------
@@ -151,38 +170,36 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ConvKArgs p) {
     b_ptr[i] = p.w + ((size_t)(n0 + (row < BN ? row : 0)) * p.Kpad + cchunk * VEC) * ES;
   }
 
-  u32x4 a_reg[A_IT], b_reg[B_IT];
-  auto load_tile = [&](int kt) {
+  struct Stage { u32x4 a[A_IT]; u32x4 b[B_IT]; bool m[A_IT]; };
+  auto load_tile = [&](Stage& st, int kt) {
     const int k = kt * BK + cchunk * VEC;
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
       if constexpr (PLAIN) {
-        u32x4 v = {0u, 0u, 0u, 0u};
-        if (a_ok[i] && k < p.K) v = *reinterpret_cast<const u32x4*>(a_ptr[i] + (size_t)kt * BKB);
-        a_reg[i] = v;
+        const bool ok = a_ok[i] && k < p.K;                       // branch-free (see gather_chunk)
+        st.a[i] = *reinterpret_cast<const u32x4*>(a_ptr[i] + (ok ? (size_t)kt * BKB : (size_t)0) - (ok ? 0 : cchunk * 16));
+        st.m[i] = ok;
       } else {
-        a_reg[i] = gather_chunk<T>(p, k, a_b[i], a_iy0[i], a_ix0[i], a_ok[i]);
+        st.a[i] = gather_chunk<T>(p, k, a_b[i], a_iy0[i], a_ix0[i], a_ok[i], st.m[i]);
       }
     }
 #pragma unroll
-    for (int i = 0; i < B_IT; ++i) {
-      const int row = (tid + i * 256) / CH;
-      if (BN * CH >= 256 * (i + 1) || row < BN)
-        b_reg[i] = *reinterpret_cast<const u32x4*>(b_ptr[i] + (size_t)kt * BKB);
-    }
+    for (int i = 0; i < B_IT; ++i) st.b[i] = *reinterpret_cast<const u32x4*>(b_ptr[i] + (size_t)kt * BKB);   // rows clamped: always valid
   };
-  auto store_tile = [&](int buf) {
+  auto store_tile = [&](const Stage& st, int buf) {
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
       const int row = (tid + i * 256) / CH;
+      u32x4 v = st.a[i];
+      if (!st.m[i]) v = u32x4{0u, 0u, 0u, 0u};
       if (BM * CH >= 256 * (i + 1) || row < BM)
-        *reinterpret_cast<u32x4*>(As + (buf * BM + row) * ROWB + cchunk * 16) = a_reg[i];
+        *reinterpret_cast<u32x4*>(As + (buf * BM + row) * ROWB + cchunk * 16) = v;
     }
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) {
       const int row = (tid + i * 256) / CH;
       if (BN * CH >= 256 * (i + 1) || row < BN)
-        *reinterpret_cast<u32x4*>(Bs + (buf * BN + row) * ROWB + cchunk * 16) = b_reg[i];
+        *reinterpret_cast<u32x4*>(Bs + (buf * BN + row) * ROWB + cchunk * 16) = st.b[i];
     }
   };
 
@@ -198,60 +215,66 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ConvKArgs p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int nk = p.Kpad / BK;
-  load_tile(0);
-  store_tile(0);
-  __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
-    const int buf = kt & 1;
-    if (kt + 1 < nk) load_tile(kt + 1);
+  auto compute = [&](int buf) {
     const char* Ab = As + (buf * BM + wm * WTM + lr) * ROWB + lh * 16;
     const char* Bb = Bs + (buf * BN + wn * WTN + lr) * ROWB + lh * 16;
 #pragma unroll
-    for (int s = 0; s < BKB / 32; ++s) {
+    for (int s2 = 0; s2 < BKB / 32; ++s2) {
       u32x4 wf[TN], xf[TM];
 #pragma unroll
-      for (int i = 0; i < TN; ++i) wf[i] = *reinterpret_cast<const u32x4*>(Bb + i * 32 * ROWB + s * 32);
+      for (int i = 0; i < TN; ++i) wf[i] = *reinterpret_cast<const u32x4*>(Bb + i * 32 * ROWB + s2 * 32);
 #pragma unroll
-      for (int j = 0; j < TM; ++j) xf[j] = *reinterpret_cast<const u32x4*>(Ab + j * 32 * ROWB + s * 32);
+      for (int j = 0; j < TM; ++j) xf[j] = *reinterpret_cast<const u32x4*>(Ab + j * 32 * ROWB + s2 * 32);
 #pragma unroll
       for (int i = 0; i < TN; ++i)
 #pragma unroll
         for (int j = 0; j < TM; ++j) Mma<T>::run(wf[i], xf[j], acc[i][j]);
     }
-    if (kt + 1 < nk) store_tile(buf ^ 1);
+  };
+
+  // register-staged double buffer: tile t+1 is loaded while tile t is computed, then written to the other LDS buffer
+  // (a second register stage was measured: no gain at equal occupancy, and its registers cost a wave per SIMD)
+  const int nk = p.Kpad / BK;
+  Stage st;
+  load_tile(st, 0);
+  store_tile(st, 0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) load_tile(st, kt + 1);
+    compute(buf);
+    if (kt + 1 < nk) store_tile(st, buf ^ 1);
     __syncthreads();
   }
 
   // ---- epilogue: bias + act in registers -> LDS tile [BM][BN] (TO) -> coalesced 16-byte stores --
   char* const Ct = smem;
   constexpr bool FAST = FastMath<T>::value;
+  with_act<FAST>(p.act_after_res ? CVMI_ACT_NONE : p.act, [&](auto actf) {
 #pragma unroll
-  for (int i = 0; i < TN; ++i) {
+    for (int i = 0; i < TN; ++i) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int nl = wn * WTN + i * 32 + 8 * q + 4 * lh;      // 4 consecutive channels
-      const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + n0 + nl);
+      for (int q = 0; q < 4; ++q) {
+        const int nl = wn * WTN + i * 32 + 8 * q + 4 * lh;      // 4 consecutive channels
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + n0 + nl);
 #pragma unroll
-      for (int j = 0; j < TM; ++j) {
-        const int ml = wm * WTM + j * 32 + lr;
-        float v[4];
+        for (int j = 0; j < TM; ++j) {
+          const int ml = wm * WTM + j * 32 + lr;
+          float v[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          v[e] = acc[i][j][4 * q + e] + bv[e];
-          if (!p.act_after_res) v[e] = act_apply<FAST>(v[e], p.act);
-        }
-        char* dst = Ct + ml * CROWB + nl * OES;
-        if constexpr (OES == 2) {
-          f16x4 hv = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
-          *reinterpret_cast<f16x4*>(dst) = hv;
-        } else {
-          f32x4 fv = {v[0], v[1], v[2], v[3]};
-          *reinterpret_cast<f32x4*>(dst) = fv;
+          for (int e = 0; e < 4; ++e) v[e] = actf(acc[i][j][4 * q + e] + bv[e]);
+          char* dst = Ct + ml * CROWB + nl * OES;
+          if constexpr (OES == 2) {
+            f16x4 hv = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
+            *reinterpret_cast<f16x4*>(dst) = hv;
+          } else {
+            f32x4 fv = {v[0], v[1], v[2], v[3]};
+            *reinterpret_cast<f32x4*>(dst) = fv;
+          }
         }
       }
     }
-  }
+  });
   __syncthreads();
   constexpr int NCH = BN / OVEC;                  // 16-byte chunks per output row
   for (int idx = tid; idx < BM * NCH; idx += 256) {
@@ -288,12 +311,16 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ConvKArgs p) {
       }
       *reinterpret_cast<u32x4*>(yp) = cv;
     } else {                                       // ragged channel tail: element-wise
-      const TO* cs = reinterpret_cast<const TO*>(&cv);
-      for (int e = 0; e < p.N - n; ++e) {
-        float a = (float)cs[e];
-        if (p.res) a += (float)reinterpret_cast<const TO*>(p.res + (rpix * p.res_ld + nn) * OES)[e];
-        if (p.act_after_res) a = act_apply<FAST>(a, p.act);
-        reinterpret_cast<TO*>(yp)[e] = (TO)a;
+      float a[OVEC];
+      unpack16<TO>(cv, a);
+#pragma unroll
+      for (int e = 0; e < OVEC; ++e) {
+        if (n + e < p.N) {
+          float av = a[e];
+          if (p.res) av += (float)reinterpret_cast<const TO*>(p.res + (rpix * p.res_ld + nn) * OES)[e];
+          if (p.act_after_res) av = act_apply<FAST>(av, p.act);
+          reinterpret_cast<TO*>(yp)[e] = (TO)av;
+        }
       }
     }
   }
@@ -324,7 +351,10 @@ int launch_cfg(ConvKArgs& a, hipStream_t stream) {
   const bool plain = a.plain != 0;
   // 128-byte K-tiles halve the barrier count; 64-byte tiles only when K is too short to fill one
   static const int force_bkb = getenv("CVMI_BKB") ? atoi(getenv("CVMI_BKB")) : 0;      // tuning experiments only
-  bool wide = plain && a.N >= 128 && a.Kpad * (int)sizeof(T) >= 256 && (a.Kpad * (int)sizeof(T)) % 128 == 0;
+  // measured (tools/gemm_bench.py): 128-byte tiles pay for deep K (>= 2 KB per row: fewer barriers) and for rows
+  // that are exactly one tile; in between, 64-byte tiles win through higher occupancy (40 KB vs 74 KB of LDS)
+  const int kbytes = a.Kpad * (int)sizeof(T);
+  bool wide = plain && kbytes % 128 == 0 && (kbytes >= 2048 || kbytes == 128);
   if (force_bkb == 64) wide = false;
   if (force_bkb == 128) wide = a.Kpad * (int)sizeof(T) >= 256 && (a.Kpad * (int)sizeof(T)) % 128 == 0;
   if (wide) return plain ? launch_cfg2<T, TO, BM, BN, WM, WN, 128, true>(a, stream) : launch_cfg2<T, TO, BM, BN, WM, WN, 128, false>(a, stream);
@@ -335,6 +365,16 @@ template <typename T, typename TO>
 int launch_typed(ConvKArgs& a, hipStream_t stream) {
   const long long M = a.M;
   const int N = a.N;
+  static const char* force_tile = getenv("CVMI_TILE");                         // tuning experiments only: "BMxBN"
+  if (force_tile) {
+    const int bm = atoi(force_tile), bnn = atoi(strchr(force_tile, 'x') + 1);
+    if (bm == 256 && bnn == 32) return launch_cfg<T, TO, 256, 32, 4, 1>(a, stream);
+    if (bm == 128 && bnn == 32) return launch_cfg<T, TO, 128, 32, 4, 1>(a, stream);
+    if (bm == 128 && bnn == 64) return launch_cfg<T, TO, 128, 64, 2, 2>(a, stream);
+    if (bm == 64 && bnn == 64) return launch_cfg<T, TO, 64, 64, 2, 2>(a, stream);
+    if (bm == 128 && bnn == 128) return launch_cfg<T, TO, 128, 128, 2, 2>(a, stream);
+    if (bm == 64 && bnn == 128) return launch_cfg<T, TO, 64, 128, 2, 2>(a, stream);
+  }
   // Tile choice: BN covers Cout where it can (each gathered pixel row is then read once); BM
   // shrinks when the grid would not fill 256 CUs x 2.
   if (N <= 32) {
@@ -345,6 +385,7 @@ int launch_typed(ConvKArgs& a, hipStream_t stream) {
     if (M >= 128 * 512) return launch_cfg<T, TO, 128, 64, 2, 2>(a, stream);
     return launch_cfg<T, TO, 64, 64, 2, 2>(a, stream);
   }
+  if (sizeof(TO) == 4 && sizeof(T) == 2 && N <= 192) return launch_cfg<T, TO, 128, 64, 2, 2>(a, stream);   // f32 out: 67 KB epilogue tile at BN=128
   const long long blocks128 = (long long)cdiv(M, 128) * cdiv(N, 128);
   if (blocks128 >= 512) return launch_cfg<T, TO, 128, 128, 2, 2>(a, stream);
   return launch_cfg<T, TO, 64, 128, 2, 2>(a, stream);
