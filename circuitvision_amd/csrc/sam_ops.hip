@@ -11,47 +11,65 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
-// ---- LayerNorm: one wave per row, row held in registers (C <= 64 * VEC * MAXCH) ---------------------
-template <typename TI, typename TO, int MAXCH>
+// ---- LayerNorm: a row is shared by G lanes (G = 4..64, chosen so that C/VEC chunks fill G * NCH slots tightly),
+//      64/G rows per wave; the row stays in registers between the mean and the variance pass.
+template <typename TI, typename TO, int NCH>
 __global__ __launch_bounds__(256) void layernorm_kernel(const TI* __restrict__ x, int x_ld, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, TO* __restrict__ y, int y_ld, long long rows, int C,
-                                                       float eps, int act) {
+                                                       float eps, int act, int G) {
   constexpr int VI = Elem<TI>::VEC;
   const int lane = threadIdx.x & 63;
-  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= rows) return;
+  const int rpw = 64 / G;
+  const long long row_raw = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * rpw + lane / G;
+  const bool row_ok = row_raw < rows;
+  const long long row = row_ok ? row_raw : rows - 1;
+  const int g = lane % G;
   const TI* xr = x + row * x_ld;
-  float v[MAXCH][VI];
+  float v[NCH][VI];
   float s = 0.f;
 #pragma unroll
-  for (int i = 0; i < MAXCH; ++i) {
-    const int c = (i * 64 + lane) * VI;
+  for (int i = 0; i < NCH; ++i) {
+    const int c = (i * G + g) * VI;
     if (c < C) {
       unpack16<TI>(*reinterpret_cast<const u32x4*>(xr + c), v[i]);
 #pragma unroll
       for (int e = 0; e < VI; ++e) s += v[i][e];
     }
   }
-  const float mean = wave_sum(s) / (float)C;
+  for (int off = G >> 1; off > 0; off >>= 1) s += __shfl_xor(s, off);
+  const float mean = s / (float)C;
   float q = 0.f;
 #pragma unroll
-  for (int i = 0; i < MAXCH; ++i) {
-    const int c = (i * 64 + lane) * VI;
+  for (int i = 0; i < NCH; ++i) {
+    const int c = (i * G + g) * VI;
     if (c < C) {
 #pragma unroll
       for (int e = 0; e < VI; ++e) { const float d = v[i][e] - mean; q += d * d; }
     }
   }
-  const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)C + eps);
+  for (int off = G >> 1; off > 0; off >>= 1) q += __shfl_xor(q, off);
+  const float rstd = 1.0f / sqrtf(q / (float)C + eps);
+  if (!row_ok) return;
   TO* yr = y + row * y_ld;
 #pragma unroll
-  for (int i = 0; i < MAXCH; ++i) {
-    const int c = (i * 64 + lane) * VI;
+  for (int i = 0; i < NCH; ++i) {
+    const int c = (i * G + g) * VI;
     if (c < C) {
       struct alignas(sizeof(TO) * VI) Pack { TO v[VI]; } pk;
+      float gm[VI], bt[VI];
+      if constexpr (VI == 4) {
+        *reinterpret_cast<f32x4*>(gm) = *reinterpret_cast<const f32x4*>(gamma + c);
+        *reinterpret_cast<f32x4*>(bt) = *reinterpret_cast<const f32x4*>(beta + c);
+      } else {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          *reinterpret_cast<f32x4*>(gm + 4 * h) = *reinterpret_cast<const f32x4*>(gamma + c + 4 * h);
+          *reinterpret_cast<f32x4*>(bt + 4 * h) = *reinterpret_cast<const f32x4*>(beta + c + 4 * h);
+        }
+      }
 #pragma unroll
       for (int e = 0; e < VI; ++e) {
-        float o = (v[i][e] - mean) * rstd * gamma[c + e] + beta[c + e];
+        const float o = (v[i][e] - mean) * rstd * gm[e] + bt[e];
         pk.v[e] = (TO)act_apply<false>(o, act);
       }
       *reinterpret_cast<Pack*>(yr + c) = pk;
@@ -242,6 +260,98 @@ __global__ __launch_bounds__(256) void upsample_refine_kernel(const float* __res
   }
 }
 
+// Fast path for the reference's head (kernels 3,5,7,11 x 4 channels, sam2_infer.py:211-216): a workgroup owns a
+// 16 x 64 output tile, a thread a 1 x 4 strip; weights are re-laid out [tap][channel] in LDS so one broadcast
+// ds_read_b128 feeds 16 FMAs; the 11 rows of the window are walked once and shared by the four branches.
+constexpr int RF_HALO = 5, RF_TW = 64, RF_TH = 16, RF_TS = RF_TW + 2 * RF_HALO + 2;     // 76: row stride (floats)
+
+template <int K>
+__device__ __forceinline__ void refine_branch_row(const float* __restrict__ r, const float* __restrict__ wrow, float (&acc)[4][4]) {
+  constexpr int kh = K / 2;
+#pragma unroll
+  for (int dx = 0; dx < K; ++dx) {
+    const f32x4 w = *reinterpret_cast<const f32x4*>(wrow + dx * 4);
+#pragma unroll
+    for (int px = 0; px < 4; ++px) {
+      const float v = r[px + dx + (RF_HALO - kh)];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) acc[c][px] = fmaf(w[c], v, acc[c][px]);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void upsample_refine_fast_kernel(const float* __restrict__ low, int h, int w, float* __restrict__ high, int H, int W,
+                                                                  const float* __restrict__ prm, float sy, float sx) {
+  constexpr int KS[4] = {3, 5, 7, 11};
+  constexpr int WOFF[4] = {0, 3 * 3 * 4 + 4, 3 * 3 * 4 + 4 + 5 * 5 * 4 + 4, 3 * 3 * 4 + 4 + 5 * 5 * 4 + 4 + 7 * 7 * 4 + 4};   // offsets in prm (w then b)
+  constexpr int NW = 9 * 4 + 25 * 4 + 49 * 4 + 121 * 4;                                                               // 816 weights
+  __shared__ __attribute__((aligned(16))) float wl[NW];                       // [branch][tap][channel]
+  __shared__ __attribute__((aligned(16))) float tile[(RF_TH + 2 * RF_HALO) * RF_TS];
+  const int n = blockIdx.z, tid = threadIdx.x;
+  {
+    int o = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int kk = KS[j] * KS[j];
+      for (int i = tid; i < kk * 4; i += 256) wl[o + i] = prm[WOFF[j] + (i & 3) * kk + (i >> 2)];
+      o += kk * 4;
+    }
+  }
+  const int ty0 = blockIdx.y * RF_TH - RF_HALO, tx0 = blockIdx.x * RF_TW - RF_HALO;
+  const float* pl = low + (size_t)n * h * w;
+  constexpr int TSW = RF_TW + 2 * RF_HALO;
+  for (int i = tid; i < (RF_TH + 2 * RF_HALO) * TSW; i += 256) {
+    const int ly = i / TSW, lx = i - ly * TSW;
+    const int gy = ty0 + ly, gx = tx0 + lx;
+    float v = 0.f;
+    if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
+      int y0, y1, x0, x1; float fy, fx;
+      bil_axis(gy, sy, h, y0, y1, fy);
+      bil_axis(gx, sx, w, x0, x1, fx);
+      v = bil_sample(pl, w, y0, y1, fy, x0, x1, fx);
+    }
+    tile[ly * RF_TS + lx] = v;
+  }
+  __syncthreads();
+  const int py = tid >> 4, px0 = (tid & 15) * 4;
+  float acc[4][4][4];                                   // [branch][channel][pixel]
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc[j][c][q] = prm[WOFF[j] + KS[j] * KS[j] * 4 + c];
+  for (int dy = -RF_HALO; dy <= RF_HALO; ++dy) {
+    float r[4 + 2 * RF_HALO];
+    const float* tr = tile + (py + RF_HALO + dy) * RF_TS + px0;
+#pragma unroll
+    for (int i = 0; i < 4 + 2 * RF_HALO; ++i) r[i] = tr[i];
+    const int ady = dy < 0 ? -dy : dy;
+    refine_branch_row<11>(r, wl + (9 + 25 + 49) * 4 + (dy + 5) * 11 * 4, acc[3]);
+    if (ady <= 3) refine_branch_row<7>(r, wl + (9 + 25) * 4 + (dy + 3) * 7 * 4, acc[2]);
+    if (ady <= 2) refine_branch_row<5>(r, wl + 9 * 4 + (dy + 2) * 5 * 4, acc[1]);
+    if (ady <= 1) refine_branch_row<3>(r, wl + (dy + 1) * 3 * 4, acc[0]);
+  }
+  const int oy = blockIdx.y * RF_TH + py, ox = blockIdx.x * RF_TW + px0;
+  if (oy >= H) return;
+  constexpr int CW = WOFF[3] + 121 * 4 + 4;             // combiner weights, then bias
+  float out[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) out[q] = prm[CW + 16];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float cw = prm[CW + j * 4 + c];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) out[q] = fmaf(cw, act_apply<false>(acc[j][c][q], CVMI_ACT_GELU), out[q]);
+    }
+  float* op = high + ((size_t)n * H + oy) * W + ox;
+  if (ox + 4 <= W && (W & 3) == 0) *reinterpret_cast<f32x4*>(op) = f32x4{out[0], out[1], out[2], out[3]};
+  else
+    for (int q = 0; q < 4; ++q) if (ox + q < W) op[q] = out[q];
+}
+
 // ---- SAM2Transforms.__call__: /255, antialiased bilinear (torch _upsample_bilinear2d_aa), normalise -----------
 constexpr int AA_MAXTAPS = 24;
 __device__ __forceinline__ void aa_axis(int i, float scale, int in, int& xmin, int& xsize, float* wt) {
@@ -300,14 +410,30 @@ template <typename TI, typename TO>
 int launch_ln(const void* x, int x_ld, const float* gamma, const float* beta, void* y, int y_ld, long long rows, int C, float eps, int act,
               hipStream_t stream) {
   constexpr int VI = Elem<TI>::VEC;
-  const int nch = (C / VI + 63) / 64;
-  const dim3 g((unsigned)((rows + 3) / 4)), b(256);
-  if (nch <= 1) hipLaunchKernelGGL((layernorm_kernel<TI, TO, 1>), g, b, 0, stream, (const TI*)x, x_ld, gamma, beta, (TO*)y, y_ld, rows, C, eps, act);
-  else if (nch <= 2) hipLaunchKernelGGL((layernorm_kernel<TI, TO, 2>), g, b, 0, stream, (const TI*)x, x_ld, gamma, beta, (TO*)y, y_ld, rows, C, eps, act);
-  else if (nch <= 3) hipLaunchKernelGGL((layernorm_kernel<TI, TO, 3>), g, b, 0, stream, (const TI*)x, x_ld, gamma, beta, (TO*)y, y_ld, rows, C, eps, act);
-  else if (nch <= 5) hipLaunchKernelGGL((layernorm_kernel<TI, TO, 5>), g, b, 0, stream, (const TI*)x, x_ld, gamma, beta, (TO*)y, y_ld, rows, C, eps, act);
-  else if (nch <= 8) hipLaunchKernelGGL((layernorm_kernel<TI, TO, 8>), g, b, 0, stream, (const TI*)x, x_ld, gamma, beta, (TO*)y, y_ld, rows, C, eps, act);
-  else CVMI_FAIL("layernorm: C=%d too wide", C);
+  const int chunks = C / VI;
+  // lanes per row: the tightest fit of `chunks` into G * NCH slots with NCH in {1,2,3,5,8}
+  int bestG = 64, bestN = 8, bestWaste = 1 << 30;
+  const int ncand[5] = {1, 2, 3, 5, 8};
+  for (int G = 4; G <= 64; G <<= 1)
+    for (int k = 0; k < 5; ++k) {
+      const int n = ncand[k];
+      if (G * n < chunks) continue;
+      const int waste = G * n - chunks;
+      if (waste < bestWaste || (waste == bestWaste && n < bestN)) { bestWaste = waste; bestG = G; bestN = n; }
+      break;
+    }
+  CVMI_CHECK(bestG * bestN >= chunks, "layernorm: C=%d too wide", C);
+  const int rpw = 64 / bestG;
+  const dim3 g((unsigned)((rows + 4 * rpw - 1) / (4 * rpw))), b(256);
+#define CVMI_LN(N) hipLaunchKernelGGL((layernorm_kernel<TI, TO, N>), g, b, 0, stream, (const TI*)x, x_ld, gamma, beta, (TO*)y, y_ld, rows, C, eps, act, bestG)
+  switch (bestN) {
+    case 1: CVMI_LN(1); break;
+    case 2: CVMI_LN(2); break;
+    case 3: CVMI_LN(3); break;
+    case 5: CVMI_LN(5); break;
+    default: CVMI_LN(8); break;
+  }
+#undef CVMI_LN
   CVMI_LAUNCH_CHECK();
   return 0;
 }
@@ -319,7 +445,7 @@ extern "C" int cvmi_layernorm(const void* x, int x_ld, int x_dtype, const float*
   CVMI_CHECK(x && gamma && beta && y && rows > 0 && C > 0, "layernorm: bad arguments");
   const int vi = x_dtype == CVMI_F16 ? 8 : 4;
   CVMI_CHECK((x_dtype == CVMI_F16 || x_dtype == CVMI_F32) && (y_dtype == CVMI_F16 || y_dtype == CVMI_F32), "layernorm: bad dtype");
-  CVMI_CHECK(C % vi == 0 && x_ld % vi == 0 && y_ld % vi == 0 && (((uintptr_t)x | (uintptr_t)y) & 15) == 0 && x_ld >= C && y_ld >= C, "layernorm: C=%d / ld not 16-byte aligned", C);
+  CVMI_CHECK(C % vi == 0 && x_ld % vi == 0 && y_ld % vi == 0 && (((uintptr_t)x | (uintptr_t)y | (uintptr_t)gamma | (uintptr_t)beta) & 15) == 0 && x_ld >= C && y_ld >= C, "layernorm: C=%d / ld not 16-byte aligned", C);
   hipStream_t s = (hipStream_t)stream_;
   if (x_dtype == CVMI_F32 && y_dtype == CVMI_F32) return launch_ln<float, float>(x, x_ld, gamma, beta, y, y_ld, rows, C, eps, act, s);
   if (x_dtype == CVMI_F32 && y_dtype == CVMI_F16) return launch_ln<float, f16>(x, x_ld, gamma, beta, y, y_ld, rows, C, eps, act, s);
@@ -397,6 +523,13 @@ extern "C" int cvmi_upsample_refine(const float* low, int N, int h, int w, float
     } else { a.ks[j] = 1; a.woff[j] = a.boff[j] = 0; }
   }
   a.nk = nk; a.ic = ic; a.comb_w = off; a.comb_b = off + nk * ic; a.halo = halo;
+  if (nk == 4 && ks[0] == 3 && ks[1] == 5 && ks[2] == 7 && ks[3] == 11 && ic == 4 && ((uintptr_t)high & 15) == 0) {   // the reference's head
+    const dim3 gf((W + RF_TW - 1) / RF_TW, (H + RF_TH - 1) / RF_TH, N);
+    hipLaunchKernelGGL(upsample_refine_fast_kernel, gf, dim3(256), 0, (hipStream_t)stream_, low, h, w, high, H, W, params, (float)h / (float)H,
+                       (float)w / (float)W);
+    CVMI_LAUNCH_CHECK();
+    return 0;
+  }
   const int TS = RF_TILE + 2 * halo;
   const size_t lds = (size_t)TS * (TS + 1) * sizeof(float);
   const dim3 g((W + RF_TILE - 1) / RF_TILE, (H + RF_TILE - 1) / RF_TILE, N);
