@@ -104,7 +104,7 @@ __device__ __forceinline__ u32x4 gather_chunk(const ConvKArgs& p, int k, int b, 
 }
 
 template <typename T, typename TO, int BM, int BN, int WM, int WN, int BKB, bool PLAIN>
-__global__ __launch_bounds__(256, (BM * BN >= 128 * 128 ? 2 : 3)) void igemm_kernel(const ConvKArgs p) {
+__global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8 ? 4 : (BM * BN >= 128 * 128 ? 2 : 3))) void igemm_kernel(const ConvKArgs p) {
   // BKB = data bytes per LDS row per K-tile (64 or 128); PLAIN = 1x1 / stride 1 / one source: A is a plain
   // row-major matrix, so the per-tile gather arithmetic collapses to "row pointer + k"
   constexpr int ES = sizeof(T);
@@ -112,11 +112,12 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128 ? 2 : 3)) void igemm_ker
   constexpr int BK = BKB / ES;
   constexpr int CH = BKB / 16;            // 16-byte chunks per row
   constexpr int ROWB = BKB + 16;
-  constexpr int A_IT = (BM * CH + 255) / 256;
-  constexpr int B_IT = (BN * CH + 255) / 256;
+  constexpr int NT = WM * WN * 64;          // threads per workgroup (4 or 8 waves)
+  constexpr int A_IT = (BM * CH + NT - 1) / NT;
+  constexpr int B_IT = (BN * CH + NT - 1) / NT;
   constexpr int WTM = BM / WM, WTN = BN / WN;
   constexpr int TM = WTM / 32, TN = WTN / 32;
-  static_assert(WM * WN == 4 && TM >= 1 && TN >= 1, "4 waves, 32x32 tiles");
+  static_assert((WM * WN == 4 || WM * WN == 8) && TM >= 1 && TN >= 1 && NT % CH == 0, "4 or 8 waves, 32x32 tiles");
   constexpr int OES = sizeof(TO);
   constexpr int OVEC = 16 / OES;
   constexpr int CROWB = BN * OES + 16;    // epilogue tile row stride (bytes)
@@ -144,7 +145,7 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128 ? 2 : 3)) void igemm_ker
   const int ohow = p.OH * p.OW;
 #pragma unroll
   for (int i = 0; i < A_IT; ++i) {
-    const int row = (tid + i * 256) / CH;
+    const int row = (tid + i * NT) / CH;
     const int m = m0 + row;
     a_ok[i] = (row < BM) && (m < p.M);
     const int mm = a_ok[i] ? m : 0;
@@ -160,13 +161,13 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128 ? 2 : 3)) void igemm_ker
   const char* b_ptr[B_IT];
 #pragma unroll
   for (int i = 0; i < A_IT; ++i) {
-    const int row = (tid + i * 256) / CH;
+    const int row = (tid + i * NT) / CH;
     const int m = a_ok[i] ? m0 + row : 0;
     a_ptr[i] = p.x0 + ((size_t)m * p.x0_ld + cchunk * VEC) * ES;
   }
 #pragma unroll
   for (int i = 0; i < B_IT; ++i) {
-    const int row = (tid + i * 256) / CH;
+    const int row = (tid + i * NT) / CH;
     b_ptr[i] = p.w + ((size_t)(n0 + (row < BN ? row : 0)) * p.Kpad + cchunk * VEC) * ES;
   }
 
@@ -189,16 +190,16 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128 ? 2 : 3)) void igemm_ker
   auto store_tile = [&](const Stage& st, int buf) {
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
-      const int row = (tid + i * 256) / CH;
+      const int row = (tid + i * NT) / CH;
       u32x4 v = st.a[i];
       if (!st.m[i]) v = u32x4{0u, 0u, 0u, 0u};
-      if (BM * CH >= 256 * (i + 1) || row < BM)
+      if (BM * CH >= NT * (i + 1) || row < BM)
         *reinterpret_cast<u32x4*>(As + (buf * BM + row) * ROWB + cchunk * 16) = v;
     }
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) {
-      const int row = (tid + i * 256) / CH;
-      if (BN * CH >= 256 * (i + 1) || row < BN)
+      const int row = (tid + i * NT) / CH;
+      if (BN * CH >= NT * (i + 1) || row < BN)
         *reinterpret_cast<u32x4*>(Bs + (buf * BN + row) * ROWB + cchunk * 16) = st.b[i];
     }
   };
@@ -277,7 +278,7 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128 ? 2 : 3)) void igemm_ker
   });
   __syncthreads();
   constexpr int NCH = BN / OVEC;                  // 16-byte chunks per output row
-  for (int idx = tid; idx < BM * NCH; idx += 256) {
+  for (int idx = tid; idx < BM * NCH; idx += NT) {
     const int row = idx / NCH, ch = idx - row * NCH;
     const int m = m0 + row, n = n0 + ch * OVEC;
     if (m >= p.M || n >= p.N) continue;
@@ -341,7 +342,7 @@ int launch_cfg2(ConvKArgs& a, hipStream_t stream) {
   a.nb_n = cdiv(a.N, BN);
   const long long blocks = (long long)cdiv(a.M, BM) * a.nb_n;
   CVMI_CHECK(blocks > 0 && blocks < (1ll << 31), "conv2d: bad grid %lld", blocks);
-  hipLaunchKernelGGL((igemm_kernel<T, TO, BM, BN, WM, WN, BKB, PLAIN>), dim3((unsigned)blocks), dim3(256), lds, stream, a);
+  hipLaunchKernelGGL((igemm_kernel<T, TO, BM, BN, WM, WN, BKB, PLAIN>), dim3((unsigned)blocks), dim3(WM * WN * 64), lds, stream, a);
   CVMI_LAUNCH_CHECK();
   return 0;
 }
@@ -374,6 +375,7 @@ int launch_typed(ConvKArgs& a, hipStream_t stream) {
     if (bm == 64 && bnn == 64) return launch_cfg<T, TO, 64, 64, 2, 2>(a, stream);
     if (bm == 128 && bnn == 128) return launch_cfg<T, TO, 128, 128, 2, 2>(a, stream);
     if (bm == 64 && bnn == 128) return launch_cfg<T, TO, 64, 128, 2, 2>(a, stream);
+    if (bm == 256 && bnn == 128) return launch_cfg<T, TO, 256, 128, 4, 2>(a, stream);
   }
   // Tile choice: BN covers Cout where it can (each gathered pixel row is then read once); BM
   // shrinks when the grid would not fill 256 CUs x 2.

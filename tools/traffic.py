@@ -1,0 +1,22 @@
+#!/usr/bin/env python3
+"""HBM traffic per step from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of tools/one_step.py.
+gfx950 corrections (MI355X_MICROARCH.md, HBM): FETCH_SIZE counts 64 B per 128-B request for wide coalesced reads ->
+doubled; WRITE_SIZE is exact for 16-byte-per-lane stores.  Both counters are in KiB."""
+import csv, glob, json, re, sys
+
+def total(d, counter, pat):
+    f = glob.glob(f"{d}/**/*counter_collection.csv", recursive=True)[0]
+    s = 0.0
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] == counter and re.search(pat, r["Kernel_Name"]):
+            s += float(r["Counter_Value"])
+    return s
+
+fetch_dir, write_dir, steps, out = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
+pat = sys.argv[5] if len(sys.argv) > 5 else r"igemm_kernel|conv_tile_kernel|dwconv3x3|sppf_pool|attn_f16"
+fetch = total(fetch_dir, "FETCH_SIZE", pat) * 1024 * 2 / steps
+write = total(write_dir, "WRITE_SIZE", pat) * 1024 / steps
+res = {"hbm_bytes_per_step": int(fetch + write), "fetch_bytes_per_step_corrected_x2": int(fetch), "write_bytes_per_step": int(write),
+       "kernels": pat, "steps_profiled": steps, "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; FETCH_SIZE doubled (gfx950)"}
+json.dump(res, open(out, "w"), indent=1)
+print(res)
