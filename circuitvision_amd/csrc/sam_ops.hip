@@ -16,7 +16,9 @@ __device__ __forceinline__ float wave_sum(float v) {
 template <typename TI, typename TO, int NCH>
 __global__ __launch_bounds__(256) void layernorm_kernel(const TI* __restrict__ x, int x_ld, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, TO* __restrict__ y, int y_ld, long long rows, int C,
-                                                       float eps, int act, int G) {
+                                                       float eps, int act, int G, int pw, int pwp, int phw, int phpwp) {
+  // pw > 0: rows are pixels of [*, H, W] images (phw = H*W, pw = W) and are written into a zero-padded
+  // [*, Hp, Wp] grid (phpwp = Hp*Wp, pwp = Wp) -- Hiera's pad-to-window-multiple, applied after the norm
   constexpr int VI = Elem<TI>::VEC;
   const int lane = threadIdx.x & 63;
   const int rpw = 64 / G;
@@ -50,7 +52,13 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const TI* __restrict__ x
   for (int off = G >> 1; off > 0; off >>= 1) q += __shfl_xor(q, off);
   const float rstd = 1.0f / sqrtf(q / (float)C + eps);
   if (!row_ok) return;
-  TO* yr = y + row * y_ld;
+  long long orow = row;
+  if (pw > 0) {
+    const long long img = row / phw;
+    const int rem = (int)(row - img * phw);
+    orow = img * phpwp + (long long)(rem / pw) * pwp + rem % pw;
+  }
+  TO* yr = y + orow * y_ld;
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
     const int c = (i * G + g) * VI;
@@ -408,7 +416,7 @@ inline int grid_for(long long total, int block = 256, int cap = 256 * 16) {
 
 template <typename TI, typename TO>
 int launch_ln(const void* x, int x_ld, const float* gamma, const float* beta, void* y, int y_ld, long long rows, int C, float eps, int act,
-              hipStream_t stream) {
+              int pw, int pwp, int phw, int phpwp, hipStream_t stream) {
   constexpr int VI = Elem<TI>::VEC;
   const int chunks = C / VI;
   // lanes per row: the tightest fit of `chunks` into G * NCH slots with NCH in {1,2,3,5,8}
@@ -425,7 +433,7 @@ int launch_ln(const void* x, int x_ld, const float* gamma, const float* beta, vo
   CVMI_CHECK(bestG * bestN >= chunks, "layernorm: C=%d too wide", C);
   const int rpw = 64 / bestG;
   const dim3 g((unsigned)((rows + 4 * rpw - 1) / (4 * rpw))), b(256);
-#define CVMI_LN(N) hipLaunchKernelGGL((layernorm_kernel<TI, TO, N>), g, b, 0, stream, (const TI*)x, x_ld, gamma, beta, (TO*)y, y_ld, rows, C, eps, act, bestG)
+#define CVMI_LN(N) hipLaunchKernelGGL((layernorm_kernel<TI, TO, N>), g, b, 0, stream, (const TI*)x, x_ld, gamma, beta, (TO*)y, y_ld, rows, C, eps, act, bestG, pw, pwp, phw, phpwp)
   switch (bestN) {
     case 1: CVMI_LN(1); break;
     case 2: CVMI_LN(2); break;
@@ -441,16 +449,21 @@ int launch_ln(const void* x, int x_ld, const float* gamma, const float* beta, vo
 }  // namespace
 
 extern "C" int cvmi_layernorm(const void* x, int x_ld, int x_dtype, const float* gamma, const float* beta, void* y, int y_ld, int y_dtype,
-                              long long rows, int C, float eps, int act, cvmi_stream_t stream_) {
+                              long long rows, int C, float eps, int act, int pad_h, int pad_w, int pad_hp, int pad_wp, cvmi_stream_t stream_) {
   CVMI_CHECK(x && gamma && beta && y && rows > 0 && C > 0, "layernorm: bad arguments");
   const int vi = x_dtype == CVMI_F16 ? 8 : 4;
   CVMI_CHECK((x_dtype == CVMI_F16 || x_dtype == CVMI_F32) && (y_dtype == CVMI_F16 || y_dtype == CVMI_F32), "layernorm: bad dtype");
   CVMI_CHECK(C % vi == 0 && x_ld % vi == 0 && y_ld % vi == 0 && (((uintptr_t)x | (uintptr_t)y | (uintptr_t)gamma | (uintptr_t)beta) & 15) == 0 && x_ld >= C && y_ld >= C, "layernorm: C=%d / ld not 16-byte aligned", C);
+  int pw = 0, pwp = 0, phw = 0, phpwp = 0;
+  if (pad_w > 0) {
+    CVMI_CHECK(pad_h > 0 && pad_hp >= pad_h && pad_wp >= pad_w && rows % ((long long)pad_h * pad_w) == 0, "layernorm: bad padding geometry");
+    pw = pad_w; pwp = pad_wp; phw = pad_h * pad_w; phpwp = pad_hp * pad_wp;
+  }
   hipStream_t s = (hipStream_t)stream_;
-  if (x_dtype == CVMI_F32 && y_dtype == CVMI_F32) return launch_ln<float, float>(x, x_ld, gamma, beta, y, y_ld, rows, C, eps, act, s);
-  if (x_dtype == CVMI_F32 && y_dtype == CVMI_F16) return launch_ln<float, f16>(x, x_ld, gamma, beta, y, y_ld, rows, C, eps, act, s);
-  if (x_dtype == CVMI_F16 && y_dtype == CVMI_F16) return launch_ln<f16, f16>(x, x_ld, gamma, beta, y, y_ld, rows, C, eps, act, s);
-  return launch_ln<f16, float>(x, x_ld, gamma, beta, y, y_ld, rows, C, eps, act, s);
+  if (x_dtype == CVMI_F32 && y_dtype == CVMI_F32) return launch_ln<float, float>(x, x_ld, gamma, beta, y, y_ld, rows, C, eps, act, pw, pwp, phw, phpwp, s);
+  if (x_dtype == CVMI_F32 && y_dtype == CVMI_F16) return launch_ln<float, f16>(x, x_ld, gamma, beta, y, y_ld, rows, C, eps, act, pw, pwp, phw, phpwp, s);
+  if (x_dtype == CVMI_F16 && y_dtype == CVMI_F16) return launch_ln<f16, f16>(x, x_ld, gamma, beta, y, y_ld, rows, C, eps, act, pw, pwp, phw, phpwp, s);
+  return launch_ln<f16, float>(x, x_ld, gamma, beta, y, y_ld, rows, C, eps, act, pw, pwp, phw, phpwp, s);
 }
 
 extern "C" int cvmi_maxpool2x2(const void* x, int x_ld, void* y, int y_ld, int B, int H, int W, int C, int dtype, cvmi_stream_t stream_) {

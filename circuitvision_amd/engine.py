@@ -104,6 +104,8 @@ class Plan:
         self.ops = []
         self.keep = []          # objects that must outlive the plan (descriptors, buffers)
         self.graph = None
+        self.lanes, self.cur_lane = [], 0
+        self._lane_streams = {}
         self._lock = threading.Lock()
 
     @property
@@ -112,6 +114,21 @@ class Plan:
 
     def add(self, label, kind, thunk, bytes_=0, flops=0):
         self.ops.append((label, kind, thunk, bytes_, flops))
+        self.lanes.append(self.cur_lane)
+
+    # ---- independent chains: ops added between fork(n) and join() carry a lane id; under graph capture each lane
+    #      is launched on its own stream (fork / join through events), eager runs keep everything on one stream
+    def fork(self):
+        self.add("fork", "sync", lambda sp=None: None)
+        self.lanes[-1] = -1
+
+    def lane(self, i):
+        self.cur_lane = i
+
+    def join(self):
+        self.cur_lane = 0
+        self.add("join", "sync", lambda sp=None: None)
+        self.lanes[-1] = -2
 
     # ---- execution ---------------------------------------------------------------------------
     def run_eager(self):
@@ -124,12 +141,37 @@ class Plan:
         self.stream.synchronize()
         _lib.check(lib.cvmi_graph_begin(self.sptr), "graph_begin")
         try:
-            self.run_eager()
+            self._run_lanes()
         finally:
             g = C.c_void_p()
             rc = lib.cvmi_graph_end(self.sptr, C.byref(g))
         _lib.check(rc, "graph_end")
         self.graph = g
+
+    def _run_lanes(self):
+        """Issue the ops for capture: lane 0 on the plan's stream, other lanes on side streams between fork/join."""
+        active = {}
+        for (label, kind, thunk, _, _), lane in zip(self.ops, self.lanes):
+            if lane == -1:                                   # fork
+                self._fork_ev = torch.cuda.Event()
+                self._fork_ev.record(self.stream)
+                active = {}
+            elif lane == -2:                                 # join
+                for st in active.values():
+                    ev = torch.cuda.Event()
+                    ev.record(st)
+                    self.stream.wait_event(ev)
+                active = {}
+            elif lane == 0:
+                thunk()
+            else:
+                if lane not in self._lane_streams:
+                    self._lane_streams[lane] = torch.cuda.Stream(device=self.stream.device)
+                st = self._lane_streams[lane]
+                if lane not in active:
+                    st.wait_event(self._fork_ev)
+                    active[lane] = st
+                thunk(st.cuda_stream)
 
     def run(self):
         if self.graph is None:
@@ -190,10 +232,11 @@ def op_conv(plan, label, pc, srcs, dst, stride=1, pad=None, act=_lib.ACT_NONE, r
         N=pc.N, Kpad=pc.Kpad, act=act, dtype=pc.dtype, out_f32=out_f32, scalar_gather=1 if scalar_gather else 0,
         res_mod=res_mod, act_after_res=1 if act_after_res else 0, shuffle_cout=shuffle_cout)
     plan.keep.append((d, pc, srcs, dst, res))
-    sp = plan.sptr
+    sp0 = plan.sptr
     fn = lib.cvmi_conv2d
 
-    def thunk():
+    def thunk(sp=None):
+        sp = sp0 if sp is None else sp
         _lib.check(fn(C.byref(d), sp), label)
 
     M = v0.B * OH * OW
@@ -210,10 +253,11 @@ def op_dwconv(plan, label, pd, src, dst, act=_lib.ACT_NONE, res=None):
     args = (src.ptr, src.ld, pd.w.data_ptr(), pd.bias.data_ptr(), res.ptr if res is not None else None,
             res.ld if res is not None else 0, dst.ptr, dst.ld, src.B, src.H, src.W, pd.C, act, pd.dtype)
     plan.keep.append((pd, src, dst, res))
-    sp = plan.sptr
+    sp0 = plan.sptr
     fn = lib.cvmi_dwconv3x3
 
-    def thunk():
+    def thunk(sp=None):
+        sp = sp0 if sp is None else sp
         _lib.check(fn(*args, sp), label)
 
     n = src.B * src.H * src.W * pd.C
@@ -224,10 +268,11 @@ def op_sppf_pool(plan, label, buf, c):
     lib = _lib.load()
     args = (buf.t.data_ptr(), buf.C, buf.B, buf.H, buf.W, c, buf.dtype)
     plan.keep.append(buf)
-    sp = plan.sptr
+    sp0 = plan.sptr
     fn = lib.cvmi_sppf_pool
 
-    def thunk():
+    def thunk(sp=None):
+        sp = sp0 if sp is None else sp
         _lib.check(fn(*args, sp), label)
 
     n = buf.B * buf.H * buf.W * c
@@ -237,10 +282,11 @@ def op_sppf_pool(plan, label, buf, c):
 def op_attention(plan, label, desc, keep, bytes_=0, flops=0):
     lib = _lib.load()
     plan.keep.append((desc, keep))
-    sp = plan.sptr
+    sp0 = plan.sptr
     fn = lib.cvmi_attention
 
-    def thunk():
+    def thunk(sp=None):
+        sp = sp0 if sp is None else sp
         _lib.check(fn(C.byref(desc), sp), label)
 
     plan.add(label, "attention", thunk, bytes_, flops)
@@ -268,16 +314,22 @@ class Rows:
         return self.t.data_ptr() + self.offset * self.t.element_size()
 
 
-def op_layernorm(plan, label, src, gamma, beta, dst, eps=1e-6, act=_lib.ACT_NONE):
-    """src / dst: Rows (or View, treated as B*H*W rows)."""
+def op_layernorm(plan, label, src, gamma, beta, dst, eps=1e-6, act=_lib.ACT_NONE, pad=None):
+    """src / dst: Rows (or View, treated as B*H*W rows).  pad = (H, W, Hp, Wp): dst is the zero-padded grid."""
     lib = _lib.load()
     src, dst = _as_rows(src), _as_rows(dst)
-    assert src.rows == dst.rows and src.C == dst.C == gamma.numel()
-    args = (src.ptr, src.ld, src.dtype, gamma.data_ptr(), beta.data_ptr(), dst.ptr, dst.ld, dst.dtype, src.rows, src.C, float(eps), act)
+    assert src.C == dst.C == gamma.numel()
+    if pad is None:
+        assert src.rows == dst.rows
+        pad = (0, 0, 0, 0)
+    else:
+        assert src.rows % (pad[0] * pad[1]) == 0 and dst.rows == src.rows // (pad[0] * pad[1]) * pad[2] * pad[3]
+    args = (src.ptr, src.ld, src.dtype, gamma.data_ptr(), beta.data_ptr(), dst.ptr, dst.ld, dst.dtype, src.rows, src.C, float(eps), act) + tuple(pad)
     plan.keep.append((src, dst, gamma, beta))
-    sp, fn = plan.sptr, lib.cvmi_layernorm
+    sp0, fn = plan.sptr, lib.cvmi_layernorm
 
-    def thunk():
+    def thunk(sp=None):
+        sp = sp0 if sp is None else sp
         _lib.check(fn(*args, sp), label)
 
     plan.add(label, "layernorm", thunk, src.rows * src.C * (ESIZE[src.dtype] + ESIZE[dst.dtype]), 8 * src.rows * src.C)
@@ -296,9 +348,10 @@ def op_maxpool2(plan, label, src, dst):
     assert src.c == dst.c and (dst.H, dst.W) == (src.H // 2, src.W // 2) and src.dtype == dst.dtype
     args = (src.ptr, src.ld, dst.ptr, dst.ld, src.B, src.H, src.W, src.c, src.dtype)
     plan.keep.append((src, dst))
-    sp, fn = plan.sptr, lib.cvmi_maxpool2x2
+    sp0, fn = plan.sptr, lib.cvmi_maxpool2x2
 
-    def thunk():
+    def thunk(sp=None):
+        sp = sp0 if sp is None else sp
         _lib.check(fn(*args, sp), label)
 
     n = src.B * src.H * src.W * src.c
@@ -310,9 +363,10 @@ def op_cast(plan, label, src, dst):
     src, dst = _as_rows(src), _as_rows(dst)
     args = (src.ptr, src.ld, src.dtype, dst.ptr, dst.ld, dst.dtype, src.rows, src.C)
     plan.keep.append((src, dst))
-    sp, fn = plan.sptr, lib.cvmi_cast
+    sp0, fn = plan.sptr, lib.cvmi_cast
 
-    def thunk():
+    def thunk(sp=None):
+        sp = sp0 if sp is None else sp
         _lib.check(fn(*args, sp), label)
 
     plan.add(label, "cast", thunk, src.rows * src.C * (ESIZE[src.dtype] + ESIZE[dst.dtype]), 0)
@@ -321,9 +375,10 @@ def op_cast(plan, label, src, dst):
 def op_call(plan, label, kind, fn, args, keep=(), bytes_=0, flops=0):
     """Generic: fn(*args, stream)."""
     plan.keep.append(keep)
-    sp = plan.sptr
+    sp0 = plan.sptr
 
-    def thunk():
+    def thunk(sp=None):
+        sp = sp0 if sp is None else sp
         _lib.check(fn(*args, sp), label)
 
     plan.add(label, kind, thunk, bytes_, flops)

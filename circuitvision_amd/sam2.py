@@ -316,12 +316,12 @@ class Sam2Plan:
         self._build()
         torch.cuda.synchronize()
 
-    def buf(self, H, W, C, dtype=None, tag=None):
+    def buf(self, H, W, C, dtype=None, tag=None, zero=False):
         """Scratch buffers are shared between blocks of equal shape (launches are stream-ordered)."""
         dtype = self.dt if dtype is None else dtype
         key = (H, W, C, dtype, tag)
         if tag is None or key not in self.pool:
-            b = Buf(self.B, H, W, C, dtype, self.dev)
+            b = Buf(self.B, H, W, C, dtype, self.dev, zero=zero)
             self.act_bytes += b.nbytes
             if tag is None:
                 return b
@@ -358,33 +358,40 @@ class Sam2Plan:
         dim, dout, heads, ws = blk["dim"], blk["dim_out"], blk["heads"], blk["window"]
         hd = dout // heads
         gam, bet = wt.ln[f"b{i}.norm1"]
-        xn = self.buf(H, W, dim, tag="xn")
-        op_layernorm(self.plan, f"b{i}.norm1", x.view(), gam, bet, xn.view(), 1e-6)
-        if blk["q_pool"] and (ws == 0 or H % ws or W % ws):
-            raise NotImplementedError("q-pool block needs a window that divides the grid")
-        if ws > 0 and (H % ws or W % ws):
-            raise NotImplementedError(f"block {i}: window {ws} does not divide the {H}x{W} grid (padded windows: Hiera-T) -- not on the GPU path yet")
+        # Hiera pads the NORMALISED tokens up to a window multiple (zeros), attends inside the padded windows and crops
+        # after the un-partition: the padded grid is a zero-initialised buffer whose valid region the LayerNorm writes
+        Hp, Wp = (H, W) if ws == 0 else (-(-H // ws) * ws, -(-W // ws) * ws)
+        padded = (Hp, Wp) != (H, W)
+        if blk["q_pool"] and (ws == 0 or ws % 2 or Hp % 2 or Wp % 2):
+            raise NotImplementedError("q-pool block needs an even window")
+        if padded:
+            xn = self.buf(Hp, Wp, dim, tag="xn_padded", zero=True)
+            op_layernorm(self.plan, f"b{i}.norm1", x.view(), gam, bet, xn.view(), 1e-6, pad=(H, W, Hp, Wp))
+        else:
+            xn = self.buf(H, W, dim, tag="xn")
+            op_layernorm(self.plan, f"b{i}.norm1", x.view(), gam, bet, xn.view(), 1e-6)
         if dim != dout:
             pj = self.buf(H, W, dout, F32, tag="dimproj")
-            self.gemm(f"b{i}.dimproj", f"b{i}.dimproj", xn.view(), pj.view())
+            self.gemm(f"b{i}.dimproj", f"b{i}.dimproj", xn.view(), pj.view(), out_hw=(H, W) if padded else None)
             short = self.buf(H // 2, W // 2, dout, F32)
             op_maxpool2(self.plan, f"b{i}.pool", pj.view(), short.view())
         else:
             short = x
-        qkv = self.buf(H, W, 3 * dout, tag="qkv")
+        qkv = self.buf(Hp, Wp, 3 * dout, tag="qkv")
         self.gemm(f"b{i}.qkv", f"b{i}.qkv", xn.view(), qkv.view())
         OH, OW = (H // 2, W // 2) if blk["q_pool"] else (H, W)
-        ao = self.buf(OH, OW, dout, tag="ao")
+        OHp, OWp = (Hp // 2, Wp // 2) if blk["q_pool"] else (Hp, Wp)
+        ao = self.buf(OHp, OWp, dout, tag="ao")
         es = ESIZE[self.dt]
         base = qkv.t.data_ptr()
         C3 = 3 * dout
         if ws > 0:
-            nwin = B * (H // ws) * (W // ws)
+            nwin = B * (Hp // ws) * (Wp // ws)
             nq = (ws // 2) ** 2 if blk["q_pool"] else ws * ws
             desc = make_attn_desc(q=base, k=base + dout * es, v=base + 2 * dout * es, o=ao.t.data_ptr(),
                                   q_sb=0, q_sh=hd, q_st=C3, k_sb=0, k_sh=hd, k_st=C3, v_sb=0, v_sh=hd, v_st=C3,
                                   o_sb=0, o_sh=hd, o_st=dout, B=nwin, heads=heads, Nq=nq, Nk=ws * ws, dqk=hd, dv=hd,
-                                  scale=hd ** -0.5, dtype=self.dt, win=ws, grid_h=H, grid_w=W, q_pool=1 if blk["q_pool"] else 0)
+                                  scale=hd ** -0.5, dtype=self.dt, win=ws, grid_h=Hp, grid_w=Wp, q_pool=1 if blk["q_pool"] else 0)
             fl = 4 * nwin * heads * nq * ws * ws * hd
         else:
             N = H * W
@@ -396,7 +403,7 @@ class Sam2Plan:
         op_attention(self.plan, f"b{i}.attn", desc, (qkv, ao), bytes_=qkv.nbytes + ao.nbytes, flops=fl)
         self.plan.ops[-1] = (self.plan.ops[-1][0], "attn_global" if ws == 0 else "attn_window") + self.plan.ops[-1][2:]
         # x = shortcut + proj(attn)   (in place on the f32 residual stream)
-        self.gemm(f"b{i}.proj", f"b{i}.proj", ao.view(), short.view(), res=short.view())
+        self.gemm(f"b{i}.proj", f"b{i}.proj", ao.view(), short.view(), res=short.view(), out_hw=(OH, OW) if padded else None)
         x = short
         gam, bet = wt.ln[f"b{i}.norm2"]
         xn2 = self.buf(OH, OW, dout, tag="xn")

@@ -363,13 +363,16 @@ class Yolo11Plan:
         nc, c2, c3 = wt.nc, wt.det_c2, wt.det_c3
         ncp = (nc + 7) // 8 * 8
         boxes, clss = [], []
+        self.plan.fork()                       # 3 levels x {box, cls}: six independent chains
         for i, f in enumerate(feats):
+            self.plan.lane(2 * i)
             t1 = self.buf(f.H, f.W, c2).view()
             t2 = self.buf(f.H, f.W, c2).view()
             bx = self.buf(f.H, f.W, 64).view()
             self.cv(f"model.23.cv2.{i}.0", f, t1, 3, kind="head")
             self.cv(f"model.23.cv2.{i}.1", t1, t2, 3, kind="head")
             self.cv(f"model.23.cv2.{i}.2", t2, bx, act=ACT_NONE, kind="head")
+            self.plan.lane(2 * i + 1)
             d1 = self.buf(f.H, f.W, f.c).view()
             op_dwconv(self.plan, f"model.23.cv3.{i}.0.0", wt.packed[f"model.23.cv3.{i}.0.0"], f, d1, act=ACT_SILU)
             u1 = self.buf(f.H, f.W, c3).view()
@@ -383,6 +386,7 @@ class Yolo11Plan:
             self.cv(f"model.23.cv3.{i}.2", u2, cl.view(0, nc), act=ACT_NONE, kind="head")
             boxes.append(bx)
             clss.append(cl)
+        self.plan.join()
         self.box_bufs, self.cls_bufs = boxes, clss
         A = sum(f.H * f.W for f in feats)
         self.A = A
@@ -403,7 +407,7 @@ class Yolo11Plan:
         if not self.keep_scores:
             self.pred.zero_()
 
-        def decode():
+        def decode(sp=sp):
             _lib.check(lib.cvmi_detect_decode(box_p, box_ld, cls_p, cls_ld, hs, ws, strides, nl, Bn, nc, dt, pred_ptr, bs_ptr, bc_ptr, wcls, sp), "detect_decode")
 
         es = ESIZE[self.dt]
@@ -416,7 +420,7 @@ class Yolo11Plan:
             a = (pred_ptr, bs_ptr, bc_ptr, Bn, nc, A, float(self.conf), float(self.iou), int(self.max_det), 7680.0, self.det.data_ptr(),
                  self.det_idx.data_ptr(), self.det_count.data_ptr(), self.nms_ws.data_ptr())
 
-            def nms():
+            def nms(sp=sp):
                 _lib.check(lib.cvmi_yolo_nms_best(*a, sp), "yolo_nms")
 
             self.plan.add("nms", "nms", nms, Bn * A * 6 * 4, 0)

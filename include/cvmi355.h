@@ -159,9 +159,11 @@ int cvmi_nhwc_to_nchw_f32(const void* src, int src_dtype, int src_ld, float* dst
 /* LayerNorm over the channel axis of rows x C (nn.LayerNorm in Hiera / TwoWayTransformer, LayerNorm2d
  * in the mask decoder's upscaling); optional activation after the affine.  x / y dtypes independent
  * (fp16 mode keeps the residual stream in f32 and feeds fp16 to the GEMMs). gamma, beta: f32 [C]. */
+/* pad_w > 0: the rows are the pixels of [*, pad_h, pad_w] images and are written into a zero-padded
+ * [*, pad_hp, pad_wp] grid (Hiera pads the NORMALISED tokens up to a window multiple; padding stays 0). */
 int cvmi_layernorm(const void* x, int x_ld, int x_dtype, const float* gamma, const float* beta,
                    void* y, int y_ld, int y_dtype, long long rows, int C, float eps, int act,
-                   cvmi_stream_t stream);
+                   int pad_h, int pad_w, int pad_hp, int pad_wp, cvmi_stream_t stream);
 
 /* 2x2 / stride 2 max-pool, NHWC (Hiera shortcut path of the q-pooling blocks: do_pool(proj(x))). */
 int cvmi_maxpool2x2(const void* x, int x_ld, void* y, int y_ld, int B, int H, int W, int C, int dtype,

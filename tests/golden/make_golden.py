@@ -158,6 +158,9 @@ def main():
     # keep the fixture small: every 4th channel, every 4th row/col of the 256x64x64 product
     np.savez_compressed(os.path.join(OUT, "dense_prompt.npz"), e1=e1.numpy(), e2=e2.numpy(),
                         dense_sub=dense[:, ::4, ::4, ::4].numpy())
+    # sample circuit image shipped with the reference (static asset, data only; BASELINE config 1 input)
+    import shutil
+    shutil.copyfile(os.path.join(REF, "static", "images", "circuits_1.jpg"), os.path.join(OUT, "circuits_1.jpg"))
     print("golden fixtures written to", OUT)
 
 

@@ -262,3 +262,69 @@ def test_boundary_get_modified_sam2_and_transforms():
     rmask = (rfinal.squeeze() > 0.0).numpy().astype(np.uint8) * 255
     assert (mask != rmask).mean() < 1e-3
     assert mask.shape == img.shape[:2]
+
+
+def _tiny_targets():
+    from circuitvision_amd.sam2 import LORA_TARGETS_REFERENCE
+    return [x for x in LORA_TARGETS_REFERENCE if ".trunk." not in x]
+
+
+def _tiny_oracle(p):
+    w = osam.SAM2ImageWrapper(osam.SAM2Core(osam.HIERA_T, lora=True, lora_trunk={})).eval()
+    w.load_state_dict({("sam2_model." + k if not (k.startswith("dense_") or k.startswith("sparse_") or k.startswith("refinement_")) else k): v
+                       for k, v in p.state_dict().items()}, strict=True)
+    return w
+
+
+@pytest.mark.parametrize("dtype", [F32, F16])
+def test_sam2_hiera_tiny_padded_windows_match_oracle(dtype):
+    """SAM 2.1-tiny (BASELINE config 1): window 14 on the 64-grid and 7 on the 32-grid do not divide -> the
+    pad / attend / crop path, including the q-pooled 14 -> 7 transition block."""
+    from circuitvision_amd.sam2 import HIERA_T
+    sp, (hi, lo, iou, inter) = _run_wrapper(HIERA_T, _tiny_targets(), _tiny_oracle, 1024, dtype, B=1)
+    tol = dict(rtol=1e-3, atol=1e-3) if dtype == F32 else dict(rtol=3e-2, atol=3e-2)
+    torch.testing.assert_close(sp.feat_s1.t.float().permute(0, 3, 1, 2).cpu(), inter["s1"], **tol)
+    torch.testing.assert_close(sp.low_res.cpu(), lo, **tol)
+    torch.testing.assert_close(sp.iou.cpu(), iou, **tol)
+
+
+def test_config1_sample_image_yolo11n_plus_sam2_tiny():
+    """BASELINE configs[0]: the reference's sample circuit image through detector (YOLO11-n) and segmenter
+    (SAM 2.1-tiny) exactly as CircuitAnalyzer.bboxes / segment_with_sam2 drive them, f32, vs the oracle pipeline."""
+    from PIL import Image
+    from circuitvision_amd.detector import YOLO, non_max_suppression_by_confidence
+    from circuitvision_amd.sam2 import HIERA_T, SamSyntheticParams
+    from circuitvision_amd.sam2_infer import SAM2Model, SAM2Transforms
+    from oracle import nms as onms
+    from oracle import preprocess as opre
+    from oracle.yolo11 import YOLO11
+    img = np.asarray(Image.open(os.path.join(GOLD, "circuits_1.jpg")).convert("RGB"))
+    assert img.shape == (720, 1280, 3)
+    # --- detector (circuit_analyzer.py:267-287 + analysis_pipeline.py:106)
+    det = YOLO("synthetic:n:62:3", dtype="f32")
+    r = det.predict(img, verbose=False)[0]
+    oracle = YOLO11("n", 62).eval()
+    oracle.load_state_dict(det.params.state_dict(), strict=True)
+    x = torch.from_numpy(opre.yolo_preprocess(img))
+    assert x.shape == (1, 3, 384, 640)
+    with torch.no_grad():
+        ref = onms.yolo_nms(oracle(x), 0.25, 0.7, 300)[0]
+    ref[:, :4] = onms.scale_boxes(x.shape[2:], ref[:, :4], img.shape[:2])
+    assert len(r) == ref.shape[0] and r.boxes.cls.cpu().tolist() == ref[:, 5].tolist()
+    got_d = onms.boxes_to_dicts(r.boxes.xyxy.cpu().numpy().tolist(), r.boxes.conf.cpu().numpy().tolist(), r.boxes.cls.cpu().numpy().tolist(), r.names)
+    ref_d = onms.boxes_to_dicts(ref[:, :4].tolist(), ref[:, 4].tolist(), ref[:, 5].tolist(), r.names)
+    assert [b["persistent_uid"] for b in non_max_suppression_by_confidence(got_d, 0.6)] == [b["persistent_uid"] for b in onms.nms_by_confidence(ref_d, 0.6)]
+    # --- segmenter (circuit_analyzer.py:321-356)
+    p = SamSyntheticParams(seed=2, lora_targets=_tiny_targets(), std=0.05)
+    model = SAM2Model(HIERA_T, 1024, dtype="f32", use_refinement=True).load_params(p)
+    tr = SAM2Transforms(resolution=1024, mask_threshold=0, max_hole_area=0, max_sprinkle_area=0)
+    hi, lo, iou = model(tr(img).unsqueeze(0))
+    final = tr.postprocess_masks(hi, img.shape[:2])
+    mask = (final.detach().cpu().squeeze() > 0.0).numpy().astype(np.uint8) * 255
+    w = _tiny_oracle(p)
+    with torch.no_grad():
+        rhi, rlo, riou = w(osam.sam2_transform(img, 1024)[None])
+        rfinal = osam.postprocess_masks(rhi, img.shape[:2])
+    torch.testing.assert_close(lo.cpu(), rlo, rtol=1e-3, atol=1e-3)
+    rmask = (rfinal.squeeze() > 0.0).numpy().astype(np.uint8) * 255
+    assert mask.shape == (720, 1280) and (mask != rmask).mean() < 1e-3
