@@ -67,8 +67,8 @@ def parse_spec(path):
 
 
 class YOLO:
-    """`YOLO(path)`; path is a checkpoint (torch-saved dict with 'state_dict' (ultralytics keys),
-    'names', 'scale') or 'synthetic:<scale>:<nc>[:seed]' for seeded random weights."""
+    """`YOLO(path)`; path is an ultralytics `.pt` (read without ultralytics, see checkpoints.py), a converted
+    {'state_dict', 'names', 'scale'} file, or 'synthetic:<scale>:<nc>[:seed]' for seeded random weights."""
 
     def __init__(self, path, dtype="f16", device="cuda", imgsz=640, keep_scores=False):
         """keep_scores=True also materialises ultralytics' full [B, 4+nc, A] prediction tensor (tests / debugging)."""
@@ -83,10 +83,8 @@ class YOLO:
             params = SyntheticParams(seed=seed, nc=nc)
             names = {i: f"class{i}" for i in range(nc)}
         else:
-            ck = torch.load(path, map_location="cpu", weights_only=True)
-            if "state_dict" not in ck or "scale" not in ck:
-                raise ValueError("checkpoint must hold {'state_dict', 'names', 'scale'} (see INTEGRATION.md for the "
-                                 "one-off converter from an ultralytics .pt)")
+            from .checkpoints import load_ultralytics_pt
+            ck = load_ultralytics_pt(path)      # ultralytics .pt (restricted unpickler) or a converted {'state_dict','names','scale'} file
             scale, names = ck["scale"], {int(k): v for k, v in ck["names"].items()}
             nc = len(names)
             params = StateDictParams(ck["state_dict"])

@@ -131,6 +131,30 @@ class SamStateDictParams:
         return self._get(name, shape)
 
 
+class SamBaseCheckpointParams(SamStateDictParams):
+    """The SAM 2 base checkpoint (`{'model': state_dict}`, plain upstream keys) that `build_sam2` loads
+    (sam2_infer.py:333).  It has no LoRA tensors and none of the wrapper's own parameters; those start, as in the
+    reference before the fine-tuned state dict is loaded, from `torch.randn` (sam2_infer.py:207-209) / default conv
+    init -- seeded here so that runs are reproducible."""
+
+    WRAPPER = ("dense_embedding", "sparse_embedding", "refinement_layer.")
+
+    def __init__(self, sd, seed=0):
+        super().__init__(sd.get("model", sd) if isinstance(sd, dict) else sd)
+        self.seed = seed
+
+    def tensor(self, name, shape, kind="w"):
+        if name in self.sd:
+            return self._get(name, shape)
+        if name.startswith(self.WRAPPER):
+            h = int.from_bytes(hashlib.sha256(f"{self.seed}:{name}".encode()).digest()[:8], "little") & 0x7FFFFFFFFFFFFFFF
+            g = torch.Generator().manual_seed(h)
+            t = torch.empty(shape).normal_(0, 1.0 if "embedding" in name else 0.1, generator=g)
+            self.sd[name] = t
+            return t
+        raise KeyError(name)
+
+
 # ---- prepared weights -----------------------------------------------------------------------------------------
 def _lin(w):
     return w.reshape(w.shape[0], w.shape[1], 1, 1)

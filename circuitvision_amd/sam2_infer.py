@@ -12,7 +12,7 @@ import torch
 from . import _lib
 from ._lib import F16, F32
 from .engine import TORCH_DTYPE, require_gpu
-from .sam2 import HIERA_L, Sam2Plan, Sam2Weights, SamStateDictParams, SamSyntheticParams
+from .sam2 import HIERA_L, Sam2Plan, Sam2Weights, SamBaseCheckpointParams, SamStateDictParams, SamSyntheticParams
 
 # the reference picks its device at import time (sam2_infer.py:19-25); on PyTorch-ROCm "cuda" is the MI355X
 device = torch.device("cuda") if torch.cuda.is_available() else torch.device("cpu")
@@ -130,6 +130,8 @@ def get_modified_sam2(model_cfg_path, checkpoint_path, device="cuda", use_high_r
         seed = int(checkpoint_path.split(":")[1]) if ":" in checkpoint_path else 0
         targets = lora_target_modules if (use_peft and lora_target_modules is not None) else ()
         model.load_params(SamSyntheticParams(seed=seed, lora_targets=targets, r=lora_rank, alpha=lora_alpha))
+    elif isinstance(checkpoint_path, str) and os.path.exists(checkpoint_path):
+        model.load_params(SamBaseCheckpointParams(torch.load(checkpoint_path, map_location="cpu", weights_only=True)))
     return model
 
 

@@ -235,3 +235,18 @@ def test_state_dict_loader_merges_lora_like_synthetic_source():
     torch.testing.assert_close(q.weight("sam_mask_decoder.conv_s0", (32, 256, 1, 1)), w1)
     torch.testing.assert_close(q.weight("a.b", (24, 16)), w2)
     assert not torch.equal(w2, p.state_dict()["a.b.base_layer.weight"])
+
+
+def test_base_checkpoint_params_fill_wrapper_parameters():
+    """`{'model': sd}` base checkpoint (no LoRA, no wrapper tensors) feeds the weight walker; the wrapper's own
+    parameters are initialised (seeded) as the reference's constructor does."""
+    from circuitvision_amd._lib import F32
+    from circuitvision_amd.sam2 import Sam2Weights, SamBaseCheckpointParams
+    core = osam.randomize_(osam.SAM2Core(MINI, lora=False, image_size=256), seed=4)
+    p = SamBaseCheckpointParams({"model": core.state_dict()}, seed=1)
+    wt = Sam2Weights(p, MINI, 256, F32, device="cpu")
+    assert wt.refine_params.numel() == 849 and wt.const["dense"].shape == (256, 256)
+    q = SamBaseCheckpointParams({"model": core.state_dict()}, seed=1)
+    assert torch.equal(q.tensor("sparse_embedding", (1, 32, 256)), p.tensor("sparse_embedding", (1, 32, 256)))
+    with pytest.raises(KeyError):
+        p.tensor("image_encoder.trunk.blocks.99.norm1.weight", (16,))
