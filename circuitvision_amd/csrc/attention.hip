@@ -128,33 +128,66 @@ __global__ __launch_bounds__(256) void attn_f16_kernel(const AttnArgs p) {
   }
 
   const int nkt = (p.Nk + 31) / 32;
-  for (int kt = 0; kt < nkt; ++kt) {
-    __syncthreads();                           // previous tile fully consumed
-    // ---- stage K tile [32][DQKP] and V^T tile [DVP][32] -------------------------------------------
-    for (int idx = gt; idx < 32 * (DQKP / 8); idx += GS) {
+  // Staging: the next K / V^T tile is fetched into registers (branch-free, clamped addresses) BEFORE the MFMAs of
+  // the current tile and written to LDS after them, so the global latency overlaps the compute.
+  constexpr int KN = (32 * (DQKP / 8) + GS - 1) / GS, VN = (32 * (DVP / 8) + GS - 1) / GS;
+  u32x4 kreg[KN], vreg[VN];
+  bool kok[KN], vok[VN];
+  auto fetch = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < KN; ++i) {
+      const int idx = gt + i * GS;
       const int row = idx / (DQKP / 8), ch = idx - row * (DQKP / 8);
       const int key = kt * 32 + row;
-      u32x4 v = {0u, 0u, 0u, 0u};
-      if (key < p.Nk && ch * 8 < p.dqk) {
-        const long long off = tok_off(lb, key, p.k_sb, p.k_st, p.win, p.grid_h, p.grid_w) + (long long)lhd * p.k_sh + ch * 8;
-        v = *reinterpret_cast<const u32x4*>(p.k + off * 2);
-      }
-      *reinterpret_cast<u32x4*>(Ks + row * KROW + ch * 16) = v;
+      const bool ok = idx < 32 * (DQKP / 8) && key < p.Nk && ch * 8 < p.dqk;
+      const long long off = tok_off(lb, ok ? key : 0, p.k_sb, p.k_st, p.win, p.grid_h, p.grid_w) + (long long)lhd * p.k_sh + (ok ? ch * 8 : 0);
+      kreg[i] = *reinterpret_cast<const u32x4*>(p.k + off * 2);
+      kok[i] = ok;
     }
-    for (int idx = gt; idx < 32 * (DVP / 8); idx += GS) {
+#pragma unroll
+    for (int i = 0; i < VN; ++i) {
+      const int idx = gt + i * GS;
       const int ch = idx / 32, key_l = idx - ch * 32;       // consecutive threads -> consecutive keys
       const int key = kt * 32 + key_l;
-      f16x8 v;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = (f16)0.f;
-      if (key < p.Nk && ch * 8 < p.dv) {
-        const long long off = tok_off(lb, key, p.v_sb, p.v_st, p.win, p.grid_h, p.grid_w) + (long long)lhd * p.v_sh + ch * 8;
-        v = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(p.v + off * 2));
-      }
-#pragma unroll
-      for (int e = 0; e < 8; ++e) *reinterpret_cast<f16*>(Vs + (ch * 8 + e) * VROW + key_l * 2) = v[e];
+      const bool ok = idx < 32 * (DVP / 8) && key < p.Nk && ch * 8 < p.dv;
+      const long long off = tok_off(lb, ok ? key : 0, p.v_sb, p.v_st, p.win, p.grid_h, p.grid_w) + (long long)lhd * p.v_sh + (ok ? ch * 8 : 0);
+      vreg[i] = *reinterpret_cast<const u32x4*>(p.v + off * 2);
+      vok[i] = ok;
     }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int i = 0; i < KN; ++i) {
+      const int idx = gt + i * GS;
+      const int row = idx / (DQKP / 8), ch = idx - row * (DQKP / 8);
+      if (idx < 32 * (DQKP / 8)) *reinterpret_cast<u32x4*>(Ks + row * KROW + ch * 16) = kok[i] ? kreg[i] : u32x4{0u, 0u, 0u, 0u};
+    }
+#pragma unroll
+    for (int i = 0; i < VN; ++i) {
+      const int idx = gt + i * GS;
+      const int ch = idx / 32, key_l = idx - ch * 32;
+      if (idx < 32 * (DVP / 8)) {
+        const f16x8 v = __builtin_bit_cast(f16x8, vok[i] ? vreg[i] : u32x4{0u, 0u, 0u, 0u});
+#pragma unroll
+        for (int e = 0; e < 8; ++e) *reinterpret_cast<f16*>(Vs + (ch * 8 + e) * VROW + key_l * 2) = v[e];
+      }
+    }
+  };
+  constexpr bool PREFETCH = (GS == 256);        // per-wave tiles (GS = 64) would need 12 staging registers x 4: not worth a wave of occupancy
+  if constexpr (PREFETCH) {
+    fetch(0);
+    commit();
     __syncthreads();
+  }
+  for (int kt = 0; kt < nkt; ++kt) {
+    if constexpr (PREFETCH) {
+      if (kt + 1 < nkt) fetch(kt + 1);
+    } else {
+      __syncthreads();                         // previous tile fully consumed
+      fetch(kt);
+      commit();
+      __syncthreads();
+    }
 
     // ---- S^T tile: 32 keys x 32 queries ------------------------------------------------------------
     f32x16 sacc;
@@ -202,6 +235,11 @@ __global__ __launch_bounds__(256) void attn_f16_kernel(const AttnArgs p) {
         const u32x4 vv = {lo[0], lo[1], hi[0], hi[1]};
         oacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, vv), pf[s], oacc[t], 0, 0, 0);
       }
+    }
+    if constexpr (PREFETCH) {
+      __syncthreads();                         // every wave is done reading this tile
+      if (kt + 1 < nkt) commit();
+      __syncthreads();
     }
   }
 

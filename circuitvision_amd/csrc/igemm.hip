@@ -248,9 +248,9 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8 ? 4 : (BM * BN >= 128 *
     __syncthreads();
   }
 
+  constexpr bool FAST = FastMath<T>::value;
   // ---- epilogue: bias + act in registers -> LDS tile [BM][BN] (TO) -> coalesced 16-byte stores --
   char* const Ct = smem;
-  constexpr bool FAST = FastMath<T>::value;
   with_act<FAST>(p.act_after_res ? CVMI_ACT_NONE : p.act, [&](auto actf) {
 #pragma unroll
     for (int i = 0; i < TN; ++i) {
@@ -367,7 +367,7 @@ int launch_typed(ConvKArgs& a, hipStream_t stream) {
   const long long M = a.M;
   const int N = a.N;
   static const char* force_tile = getenv("CVMI_TILE");                         // tuning experiments only: "BMxBN"
-  if (force_tile) {
+  if (force_tile && strchr(force_tile, (int)120)) {
     const int bm = atoi(force_tile), bnn = atoi(strchr(force_tile, 'x') + 1);
     if (bm == 256 && bnn == 32) return launch_cfg<T, TO, 256, 32, 4, 1>(a, stream);
     if (bm == 128 && bnn == 32) return launch_cfg<T, TO, 128, 32, 4, 1>(a, stream);
@@ -375,7 +375,6 @@ int launch_typed(ConvKArgs& a, hipStream_t stream) {
     if (bm == 64 && bnn == 64) return launch_cfg<T, TO, 64, 64, 2, 2>(a, stream);
     if (bm == 128 && bnn == 128) return launch_cfg<T, TO, 128, 128, 2, 2>(a, stream);
     if (bm == 64 && bnn == 128) return launch_cfg<T, TO, 64, 128, 2, 2>(a, stream);
-    if (bm == 256 && bnn == 128) return launch_cfg<T, TO, 256, 128, 4, 2>(a, stream);
   }
   // Tile choice: BN covers Cout where it can (each gathered pixel row is then read once); BM
   // shrinks when the grid would not fill 256 CUs x 2.
@@ -447,8 +446,7 @@ extern "C" int cvmi_conv2d(const cvmi_conv_desc* d, cvmi_stream_t stream_) {
   }
   a.div_ctot.init((unsigned)ctot); a.div_kw.init((unsigned)d->KW);
   hipStream_t stream = (hipStream_t)stream_;
-  static const bool no_tile = getenv("CVMI_NO_TILE") != nullptr;                 // tuning experiments only
-  if (!no_tile && (d->KH > 1) && d->y_ld >= d->N) {
+  if (d->KH > 1 && d->y_ld >= d->N) {
     const int rc = cvmi_conv_tile_try(d, stream);
     if (rc >= 0) return rc;
   }

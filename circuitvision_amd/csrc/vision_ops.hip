@@ -5,51 +5,76 @@
 namespace {
 
 // ------------------------------------------------------------------------------------------------
+// depthwise 3x3: a thread owns one 16-byte channel chunk and a strip of 4 output pixels along x: the 3 x 6 input
+// columns of the strip are loaded once (18 loads for 4 outputs instead of 36) and the 9 tap weights of the chunk stay
+// in registers for the whole strip.
 template <typename T>
-__global__ __launch_bounds__(256) void dwconv3x3_kernel(const char* __restrict__ x, int x_ld, const char* __restrict__ w,
-                                                       const float* __restrict__ bias, const char* __restrict__ res, int res_ld,
-                                                       char* __restrict__ y, int y_ld, int B, int H, int W, int C, int act) {
+__global__ __launch_bounds__(256) void dwconv3x3_strip_kernel(const char* __restrict__ x, int x_ld, const char* __restrict__ w,
+                                                             const float* __restrict__ bias, const char* __restrict__ res, int res_ld,
+                                                             char* __restrict__ y, int y_ld, int B, int H, int W, int C, int act) {
   constexpr int VEC = Elem<T>::VEC;
   constexpr bool FAST = FastMath<T>::value;
   const int nch = C / VEC;
-  const long long total = (long long)B * H * W * nch;
-  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
-    const int ch = (int)(idx % nch);
-    const long long pix = idx / nch;
-    const int px = (int)(pix % W);
-    const long long t = pix / W;
-    const int py = (int)(t % H);
-    const int b = (int)(t / H);
-    float acc[VEC];
+  const int strips = (W + 3) / 4;
+  const long long total = (long long)B * H * strips * nch;
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int ch = (int)(idx % nch);
+  long long t = idx / nch;
+  const int sx = (int)(t % strips); t /= strips;
+  const int py = (int)(t % H);
+  const int b = (int)(t / H);
+  const int px0 = sx * 4;
+  float wt[9][VEC], bv[VEC];
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) acc[e] = bias[ch * VEC + e];
+  for (int k = 0; k < 9; ++k) unpack16<T>(*reinterpret_cast<const u32x4*>(w + ((size_t)k * C + ch * VEC) * sizeof(T)), wt[k]);
 #pragma unroll
-    for (int ky = 0; ky < 3; ++ky) {
-      const int iy = py + ky - 1;
-      if ((unsigned)iy >= (unsigned)H) continue;
+  for (int e = 0; e < VEC; ++e) bv[e] = bias[ch * VEC + e];
+  float acc[4][VEC];
 #pragma unroll
-      for (int kx = 0; kx < 3; ++kx) {
-        const int ix = px + kx - 1;
-        if ((unsigned)ix >= (unsigned)W) continue;
-        const size_t ip = ((size_t)b * H + iy) * W + ix;
-        const u32x4 xv = *reinterpret_cast<const u32x4*>(x + (ip * x_ld + ch * VEC) * sizeof(T));
-        const u32x4 wv = *reinterpret_cast<const u32x4*>(w + ((size_t)(ky * 3 + kx) * C + ch * VEC) * sizeof(T));
-        float xf[VEC], wf[VEC];
-        unpack16<T>(xv, xf);
-        unpack16<T>(wv, wf);
+  for (int q = 0; q < 4; ++q)
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) acc[e] = fmaf(xf[e], wf[e], acc[e]);
+    for (int e = 0; e < VEC; ++e) acc[q][e] = bv[e];
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky) {
+    const int iy = py + ky - 1;
+    const bool yok = (unsigned)iy < (unsigned)H;
+    const int iyc = yok ? iy : 0;
+#pragma unroll
+    for (int cx = 0; cx < 6; ++cx) {                        // input columns px0-1 .. px0+4
+      const int ix = px0 + cx - 1;
+      const bool ok = yok && (unsigned)ix < (unsigned)W;
+      const int ixc = ok ? ix : 0;
+      const u32x4 raw = *reinterpret_cast<const u32x4*>(x + ((((size_t)b * H + iyc) * W + ixc) * x_ld + ch * VEC) * sizeof(T));
+      float xf[VEC];
+      unpack16<T>(raw, xf);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) xf[e] = ok ? xf[e] : 0.f;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int kx = cx - q;                              // tap column of output q that sees input column cx
+        if (kx >= 0 && kx < 3) {
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) acc[q][e] = fmaf(xf[e], wt[ky * 3 + kx][e], acc[q][e]);
+        }
       }
     }
+  }
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) acc[e] = act_apply<FAST>(acc[e], act);
-    if (res) {
-      float rf[VEC];
-      unpack16<T>(*reinterpret_cast<const u32x4*>(res + ((size_t)pix * res_ld + ch * VEC) * sizeof(T)), rf);
+  for (int q = 0; q < 4; ++q) {
+    const int px = px0 + q;
+    if (px < W) {
+      const size_t pix = ((size_t)b * H + py) * W + px;
 #pragma unroll
-      for (int e = 0; e < VEC; ++e) acc[e] += rf[e];
+      for (int e = 0; e < VEC; ++e) acc[q][e] = act_apply<FAST>(acc[q][e], act);
+      if (res) {
+        float rf[VEC];
+        unpack16<T>(*reinterpret_cast<const u32x4*>(res + (pix * res_ld + ch * VEC) * sizeof(T)), rf);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) acc[q][e] += rf[e];
+      }
+      *reinterpret_cast<u32x4*>(y + (pix * y_ld + ch * VEC) * sizeof(T)) = pack16<T>(acc[q]);
     }
-    *reinterpret_cast<u32x4*>(y + ((size_t)pix * y_ld + ch * VEC) * sizeof(T)) = pack16<T>(acc);
   }
 }
 
@@ -373,12 +398,14 @@ extern "C" int cvmi_dwconv3x3(const void* x, int x_ld, const void* w, const floa
   CVMI_CHECK(x_ld % vec == 0 && y_ld % vec == 0 && (!res || res_ld % vec == 0), "dwconv3x3: ld not 16-byte aligned");
   CVMI_CHECK((((uintptr_t)x | (uintptr_t)w | (uintptr_t)y | (uintptr_t)res) & 15) == 0, "dwconv3x3: pointer not 16-byte aligned");
   hipStream_t stream = (hipStream_t)stream_;
-  const long long total = (long long)B * H * W * (C / vec);
+  const long long total = (long long)B * H * ((W + 3) / 4) * (C / vec);
+  CVMI_CHECK(total < (1ll << 31) * 256, "dwconv3x3: grid too large");
+  const unsigned blocks = (unsigned)((total + 255) / 256);
   if (dtype == CVMI_F16)
-    hipLaunchKernelGGL(dwconv3x3_kernel<f16>, dim3(grid_for(total)), dim3(256), 0, stream, (const char*)x, x_ld, (const char*)w, bias,
+    hipLaunchKernelGGL(dwconv3x3_strip_kernel<f16>, dim3(blocks), dim3(256), 0, stream, (const char*)x, x_ld, (const char*)w, bias,
                        (const char*)res, res_ld, (char*)y, y_ld, B, H, W, C, act);
   else
-    hipLaunchKernelGGL(dwconv3x3_kernel<float>, dim3(grid_for(total)), dim3(256), 0, stream, (const char*)x, x_ld, (const char*)w, bias,
+    hipLaunchKernelGGL(dwconv3x3_strip_kernel<float>, dim3(blocks), dim3(256), 0, stream, (const char*)x, x_ld, (const char*)w, bias,
                        (const char*)res, res_ld, (char*)y, y_ld, B, H, W, C, act);
   CVMI_LAUNCH_CHECK();
   return 0;
