@@ -103,6 +103,99 @@ __device__ __forceinline__ u32x4 gather_chunk(const ConvKArgs& p, int k, int b, 
   return v;
 }
 
+// ---- shared epilogue: bias + act in registers -> LDS tile [BM][BN] (TO) -> coalesced 16-byte stores (+ residual,
+//      batch-broadcast residual, activation-after-residual, ConvTranspose scatter) -----------------------------------
+template <typename T, typename TO, int BM, int BN, int WM, int WN>
+__device__ __forceinline__ void gemm_epilogue(const ConvKArgs& p, f32x16 (&acc)[BN / WN / 32][BM / WM / 32], char* smem, int m0, int n0) {
+  constexpr int NT = WM * WN * 64;
+  constexpr int WTM = BM / WM, WTN = BN / WN;
+  constexpr int TM = WTM / 32, TN = WTN / 32;
+  constexpr int OES = sizeof(TO);
+  constexpr int OVEC = 16 / OES;
+  constexpr int CROWB = BN * OES + 16;
+  constexpr bool FAST = FastMath<T>::value;
+  const int tid = threadIdx.x;
+  const int wv = tid >> 6, lane = tid & 63;
+  const int wm = wv % WM, wn = wv / WM;
+  const int lr = lane & 31, lh = lane >> 5;
+  const int ohow = p.OH * p.OW;
+  char* const Ct = smem;
+  with_act<FAST>(p.act_after_res ? CVMI_ACT_NONE : p.act, [&](auto actf) {
+#pragma unroll
+    for (int i = 0; i < TN; ++i) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int nl = wn * WTN + i * 32 + 8 * q + 4 * lh;      // 4 consecutive channels
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + n0 + nl);
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+          const int ml = wm * WTM + j * 32 + lr;
+          float v[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = actf(acc[i][j][4 * q + e] + bv[e]);
+          char* dst = Ct + ml * CROWB + nl * OES;
+          if constexpr (OES == 2) {
+            f16x4 hv = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
+            *reinterpret_cast<f16x4*>(dst) = hv;
+          } else {
+            f32x4 fv = {v[0], v[1], v[2], v[3]};
+            *reinterpret_cast<f32x4*>(dst) = fv;
+          }
+        }
+      }
+    }
+  });
+  __syncthreads();
+  constexpr int NCH = BN / OVEC;                  // 16-byte chunks per output row
+  for (int idx = tid; idx < BM * NCH; idx += NT) {
+    const int row = idx / NCH, ch = idx - row * NCH;
+    const int m = m0 + row, n = n0 + ch * OVEC;
+    if (m >= p.M || n >= p.N) continue;
+    u32x4 cv = *reinterpret_cast<const u32x4*>(Ct + row * CROWB + ch * 16);
+    size_t ypix = (size_t)m, rpix = p.res_mod > 0 ? (size_t)(m % p.res_mod) : (size_t)m;
+    int nn = n;
+    if (p.shuf_c > 0) {                            // ConvTranspose 2x2/s2: scatter to the 2x grid
+      const int q = n / p.shuf_c;
+      nn = n - q * p.shuf_c;
+      const int b = m / ohow, r = m - b * ohow;
+      const int oy = r / p.OW, ox = r - oy * p.OW;
+      ypix = ((size_t)b * (2 * p.OH) + 2 * oy + (q >> 1)) * (size_t)(2 * p.OW) + 2 * ox + (q & 1);
+      rpix = ypix;
+    }
+    char* yp = p.y + (ypix * p.y_ld + nn) * OES;
+    if (n + OVEC <= p.N) {
+      if (p.res || p.act_after_res) {
+        float a[OVEC];
+        unpack16<TO>(cv, a);
+        if (p.res) {
+          float r[OVEC];
+          unpack16<TO>(*reinterpret_cast<const u32x4*>(p.res + (rpix * p.res_ld + nn) * OES), r);
+#pragma unroll
+          for (int e = 0; e < OVEC; ++e) a[e] += r[e];
+        }
+        if (p.act_after_res) {
+#pragma unroll
+          for (int e = 0; e < OVEC; ++e) a[e] = act_apply<FAST>(a[e], p.act);
+        }
+        cv = pack16<TO>(a);
+      }
+      *reinterpret_cast<u32x4*>(yp) = cv;
+    } else {                                       // ragged channel tail: element-wise
+      float a[OVEC];
+      unpack16<TO>(cv, a);
+#pragma unroll
+      for (int e = 0; e < OVEC; ++e) {
+        if (n + e < p.N) {
+          float av = a[e];
+          if (p.res) av += (float)reinterpret_cast<const TO*>(p.res + (rpix * p.res_ld + nn) * OES)[e];
+          if (p.act_after_res) av = act_apply<FAST>(av, p.act);
+          reinterpret_cast<TO*>(yp)[e] = (TO)av;
+        }
+      }
+    }
+  }
+}
+
 template <typename T, typename TO, int BM, int BN, int WM, int WN, int BKB, bool PLAIN>
 __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8 ? 4 : (BM * BN >= 128 * 128 ? 2 : 3))) void igemm_kernel(const ConvKArgs p) {
   // BKB = data bytes per LDS row per K-tile (64 or 128); PLAIN = 1x1 / stride 1 / one source: A is a plain
@@ -248,83 +341,121 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8 ? 4 : (BM * BN >= 128 *
     __syncthreads();
   }
 
-  constexpr bool FAST = FastMath<T>::value;
-  // ---- epilogue: bias + act in registers -> LDS tile [BM][BN] (TO) -> coalesced 16-byte stores --
-  char* const Ct = smem;
-  with_act<FAST>(p.act_after_res ? CVMI_ACT_NONE : p.act, [&](auto actf) {
+  gemm_epilogue<T, TO, BM, BN, WM, WN>(p, acc, smem, m0, n0);
+}
+
+// ---- plain GEMM with direct-to-LDS staging -------------------------------------------------------------------
+// For A = plain row-major matrix and K a multiple of one 128-byte tile, the K-tiles go global -> LDS by
+// global_load_lds (16 bytes per lane, no VGPR round trip, no ds_write -- the register-staged kernel above spends
+// ~80 % of the LDS write bandwidth a full-rate MFMA stream would need).  The DMA image is lane-linear (1 KiB = 8 rows
+// of 128 bytes per wave-instruction), so rows cannot be padded: bank conflicts are avoided by an XOR swizzle of the
+// 16-byte slots, applied on the SOURCE address when loading and on the LDS address when reading
+// (slot' = slot ^ ((row >> 1) & 7): the 16 lanes of every ds_read_b128 group then hit 16 distinct slots).
+// Two LDS stages; the next tile's DMA is issued before the MFMAs of the current one and drained by the barrier.
+template <typename T, typename TO, int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(WM * WN * 64, 2) void gemm_glds_kernel(const ConvKArgs p) {
+  constexpr int ES = sizeof(T);
+  constexpr int VEC = 16 / ES;
+  constexpr int BKB = 128, BK = BKB / ES;
+  constexpr int NT = WM * WN * 64, NW = WM * WN;
+  constexpr int WTM = BM / WM, WTN = BN / WN;
+  constexpr int TM = WTM / 32, TN = WTN / 32;
+  constexpr int STAGE = (BM + BN) * BKB;
+  constexpr int PIECES = (BM + BN) / 8;            // 1-KiB pieces (8 rows) per stage
+  static_assert(PIECES % NW == 0, "pieces must split evenly over the waves");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  int wg = blockIdx.x;
+  {
+    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = wg & 7, j = wg >> 3;
+    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+  }
+  const int bn = wg % p.nb_n, bm = wg / p.nb_n;
+  const int m0 = bm * BM, n0 = bn * BN;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int wm = wv % WM, wn = wv / WM;
+  const int lr = lane & 31, lh = lane >> 5;
+
+  // per-lane source pointers of this wave's pieces (k advances by one tile per iteration)
+  const char* src[PIECES / NW];
 #pragma unroll
-    for (int i = 0; i < TN; ++i) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int nl = wn * WTN + i * 32 + 8 * q + 4 * lh;      // 4 consecutive channels
-        const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + n0 + nl);
-#pragma unroll
-        for (int j = 0; j < TM; ++j) {
-          const int ml = wm * WTM + j * 32 + lr;
-          float v[4];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = actf(acc[i][j][4 * q + e] + bv[e]);
-          char* dst = Ct + ml * CROWB + nl * OES;
-          if constexpr (OES == 2) {
-            f16x4 hv = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
-            *reinterpret_cast<f16x4*>(dst) = hv;
-          } else {
-            f32x4 fv = {v[0], v[1], v[2], v[3]};
-            *reinterpret_cast<f32x4*>(dst) = fv;
-          }
-        }
-      }
-    }
-  });
-  __syncthreads();
-  constexpr int NCH = BN / OVEC;                  // 16-byte chunks per output row
-  for (int idx = tid; idx < BM * NCH; idx += NT) {
-    const int row = idx / NCH, ch = idx - row * NCH;
-    const int m = m0 + row, n = n0 + ch * OVEC;
-    if (m >= p.M || n >= p.N) continue;
-    u32x4 cv = *reinterpret_cast<const u32x4*>(Ct + row * CROWB + ch * 16);
-    size_t ypix = (size_t)m, rpix = p.res_mod > 0 ? (size_t)(m % p.res_mod) : (size_t)m;
-    int nn = n;
-    if (p.shuf_c > 0) {                            // ConvTranspose 2x2/s2: scatter to the 2x grid
-      const int q = n / p.shuf_c;
-      nn = n - q * p.shuf_c;
-      const int b = m / ohow, r = m - b * ohow;
-      const int oy = r / p.OW, ox = r - oy * p.OW;
-      ypix = ((size_t)b * (2 * p.OH) + 2 * oy + (q >> 1)) * (size_t)(2 * p.OW) + 2 * ox + (q & 1);
-      rpix = ypix;
-    }
-    char* yp = p.y + (ypix * p.y_ld + nn) * OES;
-    if (n + OVEC <= p.N) {
-      if (p.res || p.act_after_res) {
-        float a[OVEC];
-        unpack16<TO>(cv, a);
-        if (p.res) {
-          float r[OVEC];
-          unpack16<TO>(*reinterpret_cast<const u32x4*>(p.res + (rpix * p.res_ld + nn) * OES), r);
-#pragma unroll
-          for (int e = 0; e < OVEC; ++e) a[e] += r[e];
-        }
-        if (p.act_after_res) {
-#pragma unroll
-          for (int e = 0; e < OVEC; ++e) a[e] = act_apply<FAST>(a[e], p.act);
-        }
-        cv = pack16<TO>(a);
-      }
-      *reinterpret_cast<u32x4*>(yp) = cv;
-    } else {                                       // ragged channel tail: element-wise
-      float a[OVEC];
-      unpack16<TO>(cv, a);
-#pragma unroll
-      for (int e = 0; e < OVEC; ++e) {
-        if (n + e < p.N) {
-          float av = a[e];
-          if (p.res) av += (float)reinterpret_cast<const TO*>(p.res + (rpix * p.res_ld + nn) * OES)[e];
-          if (p.act_after_res) av = act_apply<FAST>(av, p.act);
-          reinterpret_cast<TO*>(yp)[e] = (TO)av;
-        }
-      }
+  for (int i = 0; i < PIECES / NW; ++i) {
+    const int piece = wv * (PIECES / NW) + i;
+    const int row = piece * 8 + (lane >> 3);                    // row inside the stage: [0, BM) = A, [BM, BM+BN) = W
+    const int slot = (lane & 7) ^ ((row >> 1) & 7);             // logical 16-byte chunk that lands in physical slot lane & 7
+    if (row < BM) {
+      int m = m0 + row;
+      m = m < p.M ? m : p.M - 1;                                // tail rows: any valid row (never stored)
+      src[i] = p.x0 + ((size_t)m * p.x0_ld + slot * VEC) * ES;
+    } else {
+      src[i] = p.w + ((size_t)(n0 + row - BM) * p.Kpad + slot * VEC) * ES;
     }
   }
+  auto issue = [&](int stage, int kt) {
+#pragma unroll
+    for (int i = 0; i < PIECES / NW; ++i) {
+      const int piece = wv * (PIECES / NW) + i;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + (size_t)kt * BKB),
+                                       (__attribute__((address_space(3))) void*)(smem + stage * STAGE + piece * 1024), 16, 0, 0);
+    }
+  };
+
+  f32x16 acc[TN][TM];
+#pragma unroll
+  for (int i = 0; i < TN; ++i)
+#pragma unroll
+    for (int j = 0; j < TM; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // fragment addresses: row r of a 32-row group, swizzled slot per k-step
+  int a_off[TM], w_off[TN], a_sw[TM], w_sw[TN];
+#pragma unroll
+  for (int j = 0; j < TM; ++j) { const int row = wm * WTM + j * 32 + lr; a_off[j] = row * BKB; a_sw[j] = (row >> 1) & 7; }
+#pragma unroll
+  for (int i = 0; i < TN; ++i) { const int row = BM + wn * WTN + i * 32 + lr; w_off[i] = row * BKB; w_sw[i] = (row >> 1) & 7; }
+
+  const int nk = p.K / BK;
+  issue(0, 0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const char* st = smem + (kt & 1) * STAGE;
+    if (kt + 1 < nk) issue((kt + 1) & 1, kt + 1);
+#pragma unroll
+    for (int s2 = 0; s2 < BKB / 32; ++s2) {
+      u32x4 wf[TN], xf[TM];
+#pragma unroll
+      for (int i = 0; i < TN; ++i) wf[i] = *reinterpret_cast<const u32x4*>(st + w_off[i] + (((2 * s2 + lh) ^ w_sw[i]) << 4));
+#pragma unroll
+      for (int j = 0; j < TM; ++j) xf[j] = *reinterpret_cast<const u32x4*>(st + a_off[j] + (((2 * s2 + lh) ^ a_sw[j]) << 4));
+#pragma unroll
+      for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) Mma<T>::run(wf[i], xf[j], acc[i][j]);
+    }
+    __syncthreads();                               // drains this wave's DMA (vmcnt(0)) and frees the stage just read
+  }
+  gemm_epilogue<T, TO, BM, BN, WM, WN>(p, acc, smem, m0, n0);
+}
+
+template <typename T, typename TO, int BM, int BN, int WM, int WN>
+int launch_glds(ConvKArgs& a, hipStream_t stream) {
+  constexpr size_t stage = (size_t)2 * (BM + BN) * 128;
+  constexpr size_t epi = (size_t)BM * (BN * sizeof(TO) + 16);
+  constexpr size_t lds = stage > epi ? stage : epi;
+  static bool attr_done = false;
+  if (!attr_done && lds > 64 * 1024) {
+    CVMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_glds_kernel<T, TO, BM, BN, WM, WN>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_done = true;
+  }
+  a.nb_n = cdiv(a.N, BN);
+  const long long blocks = (long long)cdiv(a.M, BM) * a.nb_n;
+  CVMI_CHECK(blocks > 0 && blocks < (1ll << 31), "conv2d: bad grid %lld", blocks);
+  hipLaunchKernelGGL((gemm_glds_kernel<T, TO, BM, BN, WM, WN>), dim3((unsigned)blocks), dim3(WM * WN * 64), lds, stream, a);
+  CVMI_LAUNCH_CHECK();
+  return 0;
 }
 
 template <typename T, typename TO, int BM, int BN, int WM, int WN, int BKB, bool PLAIN>
@@ -366,6 +497,12 @@ template <typename T, typename TO>
 int launch_typed(ConvKArgs& a, hipStream_t stream) {
   const long long M = a.M;
   const int N = a.N;
+  static const int use_glds = getenv("CVMI_GLDS") ? atoi(getenv("CVMI_GLDS")) : 1;           // tuning experiments only
+  if (use_glds && a.plain && (a.K * (int)sizeof(T)) % 128 == 0 && a.K * (int)sizeof(T) >= 256 && N >= 96 &&
+      (long long)cdiv(M, 128) * cdiv(N, 128) >= 512) {                                 // large GEMMs only: small grids need the smaller tiles below
+    if (use_glds == 2 || N <= 640) return launch_glds<T, TO, 128, 64, 2, 2>(a, stream);      // measured: wins up to N = 576
+    return launch_glds<T, TO, 128, 128, 2, 2>(a, stream);
+  }
   static const char* force_tile = getenv("CVMI_TILE");                         // tuning experiments only: "BMxBN"
   if (force_tile && strchr(force_tile, (int)120)) {
     const int bm = atoi(force_tile), bnn = atoi(strchr(force_tile, 'x') + 1);

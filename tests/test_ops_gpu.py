@@ -63,6 +63,14 @@ def test_conv2d(dtype, cfg):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+def test_conv2d_direct_to_lds_gemm(dtype):
+    """Plain GEMMs with K a multiple of one 128-byte tile take the global_load_lds kernel (swizzled LDS image)."""
+    _conv_case(dtype, 2, 256, 64, 64, 192, 1, 1, ACT_SILU)                 # 128x64 tiles, 4 (f16) / 8 (f32) K-tiles
+    _conv_case(dtype, 1, 576, 70, 70, 432, 1, 1, ACT_GELU, res=True)        # 128x128 tiles, ragged M (4900) and N, residual
+    _conv_case(dtype, 3, 128, 40, 40, 96, 1, 1, ACT_NONE)                   # exactly two tiles
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_conv2d_large_m_tiles(dtype):
     _conv_case(dtype, 2, 16, 264, 256, 16, 3, 2, ACT_SILU)      # M = 2*132*128 -> BM=256 config for N<=32? (M>=131072 not reached) still covers tails
     _conv_case(dtype, 8, 16, 128, 130, 32, 1, 1, ACT_SILU)      # M = 133120 >= 256*512 -> 256x32 tile
