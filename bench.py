@@ -234,20 +234,32 @@ def main():
                 k[0] += ms / reps; k[1] += 1; k[2] += b / reps; k[3] += f / reps
         stack_kinds = ("stem", "conv", "head", "dwconv", "pool", "attention")
         stack_ms = sum(acc[k][0] for k in stack_kinds if k in acc)
-        algo_bytes = (a.batch * ALGO_ACT_MB_PER_IMAGE + ALGO_WEIGHT_MB) * 1e6 if (a.scale == "n" and a.dtype == "f16") \
-            else float(sum(acc[k][2] for k in stack_kinds if k in acc)) + wt.param_bytes
-        achieved = algo_bytes / (stack_ms * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
-        if os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get("hbm_bytes_per_step")
-            except Exception:
-                traffic = None
-        roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                    "kernel": "conv stack (igemm_kernel + dwconv/pool/attention) per step",
-                    "kernel_ms_per_step": round(stack_ms, 4), "algorithmic_bytes_per_step": int(algo_bytes)}
+        is_cfg1 = a.scale == "n" and a.dtype == "f16"
+        if a.scale in ("n", "s"):
+            # HBM-bound scales: SURVEY.md 8(d) algorithmic bytes (config 2) or, for other variants, the plan's own
+            # layer-granular minimum (inputs + outputs of every fused launch) + weights
+            algo_bytes = (a.batch * ALGO_ACT_MB_PER_IMAGE + ALGO_WEIGHT_MB) * 1e6 if is_cfg1 \
+                else float(sum(acc[k][2] for k in stack_kinds if k in acc)) + wt.param_bytes
+            achieved = algo_bytes / (stack_ms * 1e-3) / 1e9
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
+            if is_cfg1 and a.batch == 32 and os.path.exists(tpath):      # PMC pass of this exact workload (tools/traffic.py)
+                try:
+                    traffic = json.load(open(tpath)).get("hbm_bytes_per_step")
+                except Exception:
+                    traffic = None
+            roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                        "kernel": "conv stack (igemm / conv_tile / dwconv / pool / attention launches) per step",
+                        "kernel_ms_per_step": round(stack_ms, 4), "algorithmic_bytes_per_step": int(algo_bytes)}
+        else:
+            # m / l / x are MFMA-bound (87 GFLOP / image for l)
+            fl = float(sum(acc[k][3] for k in stack_kinds if k in acc))
+            achieved = fl / (stack_ms * 1e-3) / 1e12
+            roofline = {"bound": "mfma", "achieved": round(achieved, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                        "kernel": "conv stack (igemm / conv_tile launches) per step", "kernel_ms_per_step": round(stack_ms, 4),
+                        "algorithmic_flops_per_step": int(fl)}
         breakdown = {k: {"ms": round(v[0], 4), "launches": v[1] // reps if v[1] >= reps else v[1],
                          "plan_bytes": int(v[2]), "gflop": round(v[3] / 1e9, 3)} for k, v in acc.items()}
 
