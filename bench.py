@@ -34,8 +34,10 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--workload", default="yolo11n", choices=["yolo11n", "yolo11l", "sam2l"],
-                    help="yolo11n = BASELINE configs[1] (default, the bench line); sam2l = configs[2]")
+    ap.add_argument("--workload", default="yolo11n", choices=["yolo11n", "yolo11l", "sam2l", "sam2l_box"],
+                    help="yolo11n = BASELINE configs[1] (default, the bench line); sam2l = configs[2]; "
+                         "sam2l_box = one GPU's share of configs[4] (16 images x 32 box prompts)")
+    ap.add_argument("--prompts", type=int, default=32, help="box prompts per image (sam2l_box)")
     ap.add_argument("--batch", type=int, default=None, help="images per GPU per step (default 32 YOLO / 16 SAM)")
     ap.add_argument("--scale", default=None)
     ap.add_argument("--dtype", default="f16")
@@ -68,7 +70,7 @@ SAM_FLOP_PER_IMAGE = 1.83e12     # trunk linear 1606 G 
 MFMA_PEAK_TFLOPS = 2500.0        # dense fp16/bf16 (MI355X_MICROARCH.md)
 
 
-def sam_cpu_baseline(state_dict, seconds=20.0):
+def sam_cpu_baseline(state_dict, seconds=20.0, boxes=None):
     import torch
     from oracle import sam2_model as osam
     w = osam.SAM2ImageWrapper(osam.SAM2Core(osam.HIERA_L, lora=True)).eval()
@@ -78,11 +80,24 @@ def sam_cpu_baseline(state_dict, seconds=20.0):
     with torch.no_grad():
         n, t0 = 0, time.perf_counter()
         while n < 1 or time.perf_counter() - t0 < seconds:
-            w(x)
+            if boxes is None:
+                w(x)
+            else:
+                osam.predict_boxes(w, x, boxes[:1])
             n += 1
         dt = time.perf_counter() - t0
+    what = "wrapper forward" if boxes is None else f"encoder + {boxes.shape[1]} box prompts"
     return {"value": round(n / dt, 4), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{n} synthetic 1024x1024 images (batch 1), SAM2.1 Hiera-L fp32 oracle wrapper forward, {dt:.1f} s"}
+            "sample": f"{n} synthetic 1024x1024 images (batch 1), SAM2.1 Hiera-L fp32 oracle {what}, {dt:.1f} s"}
+
+
+def synthetic_boxes(B, P, R=1024, seed=0):
+    """P boxes per image, xyxy in the R x R input space, sides U(24, 200)."""
+    import torch
+    g = torch.Generator().manual_seed(seed)
+    side = 24 + 176 * torch.rand(B, P, 2, generator=g)
+    xy = torch.rand(B, P, 2, generator=g) * (R - side)
+    return torch.cat((xy, xy + side), -1)
 
 
 def run_sam(a):
@@ -105,7 +120,13 @@ def run_sam(a):
     if world > 1:
         broadcast_packed(wt.pc, src=0)
     stream = torch.cuda.Stream()
-    sp = Sam2Plan(wt, B, stream)
+    NPR = a.prompts if a.workload == "sam2l_box" else 0
+    sp = Sam2Plan(wt, B, stream, prompts=NPR)
+    boxes = None
+    if NPR:
+        boxes = synthetic_boxes(B, NPR, seed=rank)
+        sp.coords[:, :2].copy_(boxes.reshape(B * NPR, 2, 2))
+        sp.labels.copy_(torch.tensor([2, 3, -1], dtype=torch.int32).expand(B * NPR, 3))
     lib = _lib.load()
     for b in range(B):
         img = torch.from_numpy(circuit_image(768, 1024, seed=20250704 + rank * B + b)).cuda()
@@ -144,14 +165,15 @@ def run_sam(a):
         breakdown = {k: {"ms": round(v[0], 3), "launches": v[1] // reps, "gflop": round(v[3] / 1e9, 1),
                          "tflops": round(v[3] / max(v[0], 1e-9) / 1e9, 1)} for k, v in acc.items()}
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        cpu = sam_cpu_baseline(params.state_dict())
+        cpu = sam_cpu_baseline(params.state_dict(), boxes=boxes)
     if rank == 0:
         print(json.dumps({
             "metric": "circuit images/sec (YOLOv11 640² + SAM2.1-L 1024²) at 1/2/4/8 MI355X", "value": round(world * B * a.steps / dt, 3),
             "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
-            "config": {"workload": f"SAM2.1 Hiera-L 1024x1024 batch={B}/GPU learned-prompt wrapper forward (BASELINE configs[2])",
-                       "images_per_step": world * B, "weights": "seeded random, LoRA merged"},
+            "config": {"workload": (f"SAM2.1 Hiera-L 1024x1024 batch={B}/GPU learned-prompt wrapper forward (BASELINE configs[2])" if not NPR else
+                                    f"SAM2.1 Hiera-L 1024x1024 batch={B}/GPU, {NPR} box prompts per image, fp16 (one GPU's share of BASELINE configs[4])"),
+                       "images_per_step": world * B, "masks_per_step": world * B * max(NPR, 1), "weights": "seeded random, LoRA merged"},
             "roofline": roofline, "cpu_baseline": cpu, "breakdown": breakdown}), flush=True)
     if world > 1:
         dist.destroy_process_group()
@@ -159,7 +181,7 @@ def run_sam(a):
 
 def main():
     a = parse()
-    if a.workload == "sam2l":
+    if a.workload in ("sam2l", "sam2l_box"):
         if a.steps == 50 and a.warmup == 10:
             a.steps, a.warmup = 5, 2
         return run_sam(a)

@@ -25,7 +25,7 @@ class ConvDesc(C.Structure):
         ("KH", C.c_int), ("KW", C.c_int), ("stride", C.c_int), ("pad", C.c_int),
         ("N", C.c_int), ("Kpad", C.c_int), ("act", C.c_int), ("dtype", C.c_int),
         ("out_f32", C.c_int), ("scalar_gather", C.c_int),
-        ("res_mod", C.c_int), ("act_after_res", C.c_int), ("shuffle_cout", C.c_int),
+        ("res_mod", C.c_int), ("act_after_res", C.c_int), ("shuffle_cout", C.c_int), ("res_rep", C.c_int),
     ]
 
 
@@ -67,6 +67,8 @@ SIGNATURES = {
     "cvmi_layernorm": (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _i, C.c_longlong, _i, _f, _i, _i, _i, _i, _i, _vp]),
     "cvmi_maxpool2x2": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "cvmi_cast": (_i, [_vp, _i, _i, _vp, _i, _i, C.c_longlong, _i, _vp]),
+    "cvmi_prompt_tokens": (_i, [_vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "cvmi_repeat_images": (_i, [_vp, _vp, C.c_longlong, _i, _i, _vp]),
     "cvmi_hyper_masks": (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _vp, _i, _i, _f, _vp]),
     "cvmi_select_mask": (_i, [_vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp, _i, _i, _vp]),
     "cvmi_bilinear_f32": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _vp, _f, _vp]),

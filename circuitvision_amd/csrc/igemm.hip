@@ -31,7 +31,7 @@ struct ConvKArgs {
   int H, W, OH, OW, KW, stride, pad;
   int M, N, K, Kpad;
   int act, scalar_gather;
-  int res_mod, act_after_res, shuf_c;
+  int res_mod, act_after_res, shuf_c, res_rep;
   int plain;
   int nb_n;
   FastDiv div_ctot, div_kw;
@@ -160,7 +160,7 @@ __device__ __forceinline__ void gemm_epilogue(const ConvKArgs& p, f32x16 (&acc)[
       const int b = m / ohow, r = m - b * ohow;
       const int oy = r / p.OW, ox = r - oy * p.OW;
       ypix = ((size_t)b * (2 * p.OH) + 2 * oy + (q >> 1)) * (size_t)(2 * p.OW) + 2 * ox + (q & 1);
-      rpix = ypix;
+      rpix = p.res_rep > 1 ? ((size_t)(b / p.res_rep) * (2 * p.OH) + 2 * oy + (q >> 1)) * (size_t)(2 * p.OW) + 2 * ox + (q & 1) : ypix;
     }
     char* yp = p.y + (ypix * p.y_ld + nn) * OES;
     if (n + OVEC <= p.N) {
@@ -572,10 +572,11 @@ extern "C" int cvmi_conv2d(const cvmi_conv_desc* d, cvmi_stream_t stream_) {
   a.H = d->H; a.W = d->W; a.OH = d->OH; a.OW = d->OW; a.KW = d->KW; a.stride = d->stride; a.pad = d->pad;
   a.M = (int)M; a.N = d->N; a.K = (int)K; a.Kpad = d->Kpad;
   a.act = d->act; a.scalar_gather = d->scalar_gather; a.nb_n = 1;
-  a.res_mod = d->res_mod; a.act_after_res = d->act_after_res; a.shuf_c = d->shuffle_cout;
+  a.res_mod = d->res_mod; a.act_after_res = d->act_after_res; a.shuf_c = d->shuffle_cout; a.res_rep = d->res_rep;
   a.plain = (d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0 && d->c1 == 0 && d->up0 == 0 && !d->scalar_gather &&
              d->OH == d->H && d->OW == d->W) ? 1 : 0;
   CVMI_CHECK(d->res_mod >= 0 && d->shuffle_cout >= 0, "conv2d: negative res_mod / shuffle_cout");
+  CVMI_CHECK(d->res_rep <= 1 || (d->shuffle_cout > 0 && d->res && d->B % d->res_rep == 0), "conv2d: res_rep needs shuffle_cout, a residual and B %% res_rep == 0");
   if (d->shuffle_cout > 0) {
     CVMI_CHECK(d->N == 4 * d->shuffle_cout && d->shuffle_cout % ovec == 0 && d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0 &&
                d->res_mod == 0, "conv2d: shuffle_cout needs a 1x1 conv with N == 4*shuffle_cout (multiple of %d)", ovec);

@@ -125,7 +125,54 @@ __global__ __launch_bounds__(256) void cast_kernel(const TI* __restrict__ x, int
   }
 }
 
+// ---- prompt tokens (upstream PromptEncoder._embed_points + decoder token concat) ------------------------------
+// one workgroup of 256 threads per prompt; thread c owns channel c of every token
+template <typename TL>
+__global__ __launch_bounds__(256) void prompt_tokens_kernel(const float* __restrict__ coords, const int* __restrict__ labels, const float* __restrict__ gauss,
+                                                           const float* __restrict__ out_tokens, const float* __restrict__ table, float size,
+                                                           float* __restrict__ tok, TL* __restrict__ tok_lp, int K, int T0) {
+  const int i = blockIdx.x, c = threadIdx.x, T = T0 + K;
+  float* t = tok + (size_t)i * T * 256;
+  TL* tl = tok_lp ? tok_lp + (size_t)i * T * 256 : nullptr;
+  for (int r = 0; r < T0; ++r) {
+    const float v = out_tokens[r * 256 + c];
+    t[r * 256 + c] = v;
+    if (tl) tl[r * 256 + c] = (TL)v;
+  }
+  const int g = c & 127;
+  const float g0 = gauss[g], g1 = gauss[128 + g];
+  for (int j = 0; j < K; ++j) {
+    const int lab = labels[(size_t)i * K + j];
+    float v;
+    if (lab < 0) {
+      v = table[c];
+    } else {
+      const float x = 2.f * ((coords[((size_t)i * K + j) * 2] + 0.5f) / size) - 1.f;
+      const float y = 2.f * ((coords[((size_t)i * K + j) * 2 + 1] + 0.5f) / size) - 1.f;
+      const float a = 6.283185307179586f * (x * g0 + y * g1);
+      v = (c < 128 ? sinf(a) : cosf(a)) + table[(1 + lab) * 256 + c];
+    }
+    t[(T0 + j) * 256 + c] = v;
+    if (tl) tl[(T0 + j) * 256 + c] = (TL)v;
+  }
+}
+
+__global__ __launch_bounds__(256) void repeat_images_kernel(const u32x4* __restrict__ src, u32x4* __restrict__ dst, long long chunks, int rep) {
+  // grid.y = image; every 16-byte chunk is read once and stored `rep` times
+  const int b = blockIdx.y;
+  const u32x4* s = src + (size_t)b * chunks;
+  u32x4* d = dst + (size_t)b * rep * chunks;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < chunks; i += (long long)gridDim.x * blockDim.x) {
+    const u32x4 v = s[i];
+    for (int r = 0; r < rep; ++r) d[(size_t)r * chunks + i] = v;
+  }
+}
+
 // ---- mask decoder tail ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void zero_i32_kernel(int* __restrict__ p, int n) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = 0;
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void hyper_masks_kernel(const float* __restrict__ hyper, int hyper_ld, const T* __restrict__ up, int up_ld, int C,
                                                          float* __restrict__ masks, int* __restrict__ areas, int P, float delta) {
@@ -492,12 +539,38 @@ extern "C" int cvmi_cast(const void* x, int x_ld, int x_dtype, void* y, int y_ld
   return 0;
 }
 
+extern "C" int cvmi_prompt_tokens(const float* coords, const int* labels, const float* gauss, const float* out_tokens, const float* table,
+                                  float image_size, float* tokens_f32, void* tokens_lp, int dtype, int n, int K, int T0, cvmi_stream_t stream_) {
+  CVMI_CHECK(coords && labels && gauss && out_tokens && table && tokens_f32 && n > 0 && K > 0 && T0 >= 0 && image_size > 0.f, "prompt_tokens: bad arguments");
+  CVMI_CHECK(!tokens_lp || dtype == CVMI_F16 || dtype == CVMI_F32, "prompt_tokens: bad dtype");
+  hipStream_t s = (hipStream_t)stream_;
+  const dim3 g(n), b(256);
+  const float inv = image_size;
+  if (tokens_lp && dtype == CVMI_F16)
+    hipLaunchKernelGGL(prompt_tokens_kernel<f16>, g, b, 0, s, coords, labels, gauss, out_tokens, table, inv, tokens_f32, (f16*)tokens_lp, K, T0);
+  else
+    hipLaunchKernelGGL(prompt_tokens_kernel<float>, g, b, 0, s, coords, labels, gauss, out_tokens, table, inv, tokens_f32, (float*)tokens_lp, K, T0);
+  CVMI_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int cvmi_repeat_images(const void* src, void* dst, long long bytes_per_image, int B, int rep, cvmi_stream_t stream_) {
+  CVMI_CHECK(src && dst && bytes_per_image > 0 && bytes_per_image % 16 == 0 && B > 0 && B <= 65535 && rep > 0, "repeat_images: bad arguments");
+  CVMI_CHECK((((uintptr_t)src | (uintptr_t)dst) & 15) == 0, "repeat_images: pointers must be 16-byte aligned");
+  const long long chunks = bytes_per_image / 16;
+  const dim3 g(grid_for(chunks, 256, 64), B), b(256);
+  hipLaunchKernelGGL(repeat_images_kernel, g, b, 0, (hipStream_t)stream_, (const u32x4*)src, (u32x4*)dst, chunks, rep);
+  CVMI_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int cvmi_hyper_masks(const float* hyper, int hyper_ld, const void* up, int up_ld, int up_dtype, int C, float* masks, int* areas, int B,
                                 int P, float delta, cvmi_stream_t stream_) {
   CVMI_CHECK(hyper && up && masks && areas && B > 0 && P > 0 && C > 0 && C <= 64 && hyper_ld >= C && up_ld >= C, "hyper_masks: bad arguments");
   CVMI_CHECK(up_dtype == CVMI_F16 || up_dtype == CVMI_F32, "hyper_masks: bad dtype");
   hipStream_t s = (hipStream_t)stream_;
-  CVMI_HIP(hipMemsetAsync(areas, 0, sizeof(int) * 2 * B, s));
+  // a kernel, not hipMemsetAsync: a memset node of this small size did not replay reliably inside a captured graph
+  hipLaunchKernelGGL(zero_i32_kernel, dim3((2 * B + 255) / 256), dim3(256), 0, s, areas, 2 * B);
   const dim3 g(grid_for(P, 256, 64), B), b(256);
   if (up_dtype == CVMI_F16) hipLaunchKernelGGL(hyper_masks_kernel<f16>, g, b, 0, s, hyper, hyper_ld, (const f16*)up, up_ld, C, masks, areas, P, delta);
   else hipLaunchKernelGGL(hyper_masks_kernel<float>, g, b, 0, s, hyper, hyper_ld, (const float*)up, up_ld, C, masks, areas, P, delta);

@@ -202,7 +202,7 @@ class Plan:
 
 # ---- op wrappers (each appends one launch to a plan) --------------------------------------------
 def op_conv(plan, label, pc, srcs, dst, stride=1, pad=None, act=_lib.ACT_NONE, res=None, out_hw=None,
-            scalar_gather=False, kind="conv", res_mod=0, act_after_res=False, shuffle_cout=0):
+            scalar_gather=False, kind="conv", res_mod=0, act_after_res=False, shuffle_cout=0, res_rep=0):
     """srcs: [(View, up)] (1 or 2 channel-concatenated sources).  dst / res: View."""
     lib = _lib.load()
     (v0, up0) = srcs[0]
@@ -222,6 +222,8 @@ def op_conv(plan, label, pc, srcs, dst, stride=1, pad=None, act=_lib.ACT_NONE, r
         assert (dst.B, dst.H, dst.W) == (v0.B, 2 * OH, 2 * OW) and dst.c == shuffle_cout and pc.N == 4 * shuffle_cout, label
     else:
         assert (dst.B, dst.H, dst.W) == (v0.B, OH, OW) and dst.c == pc.N, (label, (dst.B, dst.H, dst.W, dst.c), (v0.B, OH, OW, pc.N))
+    if res_rep > 1:
+        assert shuffle_cout and res is not None and res.B * res_rep == v0.B, (label, "res_rep needs a per-image residual")
     out_f32 = 1 if (dst.dtype == F32 and pc.dtype == F16) else 0
     d = ConvDesc(
         x0=v0.ptr, x1=(v1.ptr if v1 is not None else None), w=pc.w.data_ptr(), bias=pc.bias.data_ptr(),
@@ -230,7 +232,7 @@ def op_conv(plan, label, pc, srcs, dst, stride=1, pad=None, act=_lib.ACT_NONE, r
         c0=v0.c, c1=(v1.c if v1 is not None else 0), up0=up0, up1=up1,
         B=v0.B, H=H, W=W, OH=OH, OW=OW, KH=pc.KH, KW=pc.KW, stride=stride, pad=pad,
         N=pc.N, Kpad=pc.Kpad, act=act, dtype=pc.dtype, out_f32=out_f32, scalar_gather=1 if scalar_gather else 0,
-        res_mod=res_mod, act_after_res=1 if act_after_res else 0, shuffle_cout=shuffle_cout)
+        res_mod=res_mod, act_after_res=1 if act_after_res else 0, shuffle_cout=shuffle_cout, res_rep=res_rep)
     plan.keep.append((d, pc, srcs, dst, res))
     sp0 = plan.sptr
     fn = lib.cvmi_conv2d

@@ -244,6 +244,21 @@ class Sam2Weights:
         cpe = 2 * math.pi * ((2 * torch.stack((xx, yy), -1) - 1) @ G)
         self.key_pe = torch.cat((torch.sin(cpe), torch.cos(cpe)), -1).reshape(fs * fs, 256)      # get_dense_pe(), [pixels, 256]
         self.sparse = self.p.tensor("sparse_embedding", (1, 32, 256), "unit")[0]
+        # upstream prompt encoder (box / point prompts, `infer_masks(images, boxes)`): label table, no-mask dense
+        # embedding and the predictor's no_mem_embed, the last two folded into the embed GEMM's bias
+        PE = "sam_prompt_encoder"
+        try:
+            table = torch.cat([self.p.tensor(f"{PE}.not_a_point_embed.weight", (1, 256), "unit")]
+                              + [self.p.tensor(f"{PE}.point_embeddings.{i}.weight", (1, 256), "unit") for i in range(4)], 0)
+            no_mask = self.p.tensor(f"{PE}.no_mask_embed.weight", (1, 256), "unit")[0]
+            no_mem = self.p.tensor("no_mem_embed", (1, 1, 256), "unit").reshape(256)
+        except KeyError:
+            self.prompt_ok = False                  # a checkpoint stripped of the prompt encoder: learned-prompt path only
+            return
+        self.prompt_ok = True
+        self._pack("embed_box", _lin(torch.cat((wn[1], wn[0]), 1)), bn[1] + bn[0] + no_mask + no_mem)
+        self.const["prompt_table"] = table.float().contiguous().to(self.device)
+        self.const["gauss"] = G.float().contiguous().to(self.device)
 
     def _attn(self, key, mod, inner, q_pe=None, k_pe=None):
         """One Attention module.  q / k / v projections packed separately; constants (x + pe) W^T folded."""
@@ -262,6 +277,7 @@ class Sam2Weights:
         self.const["tokens"] = tokens.float().to(dev)
         kpe = self.key_pe
         self.n_tok = tokens.shape[0]
+        self._sa_w, self._x_w = {}, {}
 
         def cres(t):                       # constant residual in the GEMM's output dtype
             return t.contiguous().to(od).to(dev)
@@ -270,6 +286,7 @@ class Sam2Weights:
             L = f"{D}.transformer.layers.{l}"
             # self attention: q, k (+ token pe unless layer 0), v from the same queries -> one GEMM of N = 768
             sa = self._attn(f"l{l}.sa", f"{L}.self_attn", 256)
+            self._sa_w[l] = (sa["q_proj"][0], sa["k_proj"][0])
             w = torch.cat([sa[n][0] for n in ("q_proj", "k_proj", "v_proj")], 0)
             b = torch.cat([sa[n][1] for n in ("q_proj", "k_proj", "v_proj")], 0)
             self._pack(f"l{l}.sa.qkv", _lin(w), b)
@@ -294,8 +311,23 @@ class Sam2Weights:
             self._pack(f"l{l}.i2t.kv", _lin(torch.cat((i2t["k_proj"][0], i2t["v_proj"][0]), 0)), torch.cat((i2t["k_proj"][1], i2t["v_proj"][1]), 0))
             self.const[f"l{l}.i2t.kv_pe"] = cres(torch.cat((tokens @ i2t["k_proj"][0].t(), torch.zeros(self.n_tok, 128)), 1))
             self._norm(f"l{l}.norm4", f"{L}.norm4", 256)
+            self._x_w[l] = {"t2i.q": t2i["q_proj"][0], "i2t.k": i2t["k_proj"][0]}
         F_ = f"{D}.transformer.final_attn_token_to_image"
         fa = self._attn("final", F_, 128)
+        # prompted mode: the token PE is per prompt, so (tokens0 @ W^T) is one run-time GEMM whose column groups are
+        # the residuals the constant-folded path reads from `const[...]`
+        zeros = lambda n: torch.zeros(n, 256)
+        groups = [("l1.sa.qkv_pe", torch.cat((self._sa_w[1][0], self._sa_w[1][1], zeros(256)), 0))]
+        for l in (0, 1):
+            groups.append((f"l{l}.t2i.q_pe", self._x_w[l]["t2i.q"]))
+            groups.append((f"l{l}.i2t.kv_pe", torch.cat((self._x_w[l]["i2t.k"], zeros(128)), 0)))
+        groups.append(("final.q_pe", fa["q_proj"][0]))
+        self.pe_off, off = {}, 0
+        for name, w in groups:
+            self.pe_off[name] = (off, w.shape[0])
+            off += w.shape[0]
+        self._pack("token_pe", _lin(torch.cat([w for _, w in groups], 0)), torch.zeros(off))
+        self.const["out_tokens"] = tokens[:6].float().contiguous().to(dev)
         self._pack("final.q", _lin(fa["q_proj"][0]), fa["q_proj"][1])
         self.const["final.q_pe"] = cres(tokens @ fa["q_proj"][0].t())
         self._pack("final.kv", _lin(torch.cat((fa["k_proj"][0], fa["v_proj"][0]), 0)), torch.cat((fa["k_proj"][1], fa["v_proj"][1]), 0))
@@ -329,10 +361,18 @@ class Sam2Weights:
 
 
 class Sam2Plan:
-    """Launch plan for B images: x [B, R, R, 3] (NHWC, normalised) -> high_res, low_res, iou."""
+    """Launch plan for B images: x [B, R, R, 3] (NHWC, normalised) -> high_res, low_res, iou.
 
-    def __init__(self, wt, B, stream, dynamic_multimask_via_stability=True):
+    prompts = 0: the reference's learned-prompt wrapper forward (one mask per image, sam2_infer.py:220-275).
+    prompts = P > 0: upstream prompting, P prompts of `points` labelled points per image (a box = 2 corners + 1
+    padding point); the caller fills `coords` [B*P, points, 2] / `labels` [B*P, points] before each run and the decoder
+    runs on B*P (image, prompt) pairs, image-major (MaskDecoder repeat_image=True); outputs are [B*P, 1, ...]."""
+
+    def __init__(self, wt, B, stream, dynamic_multimask_via_stability=True, prompts=0, points=3, high_res=True):
         self.wt, self.B, self.dt, self.dev = wt, B, wt.dtype, wt.device
+        self.P, self.K, self.want_high_res = prompts, points, high_res
+        if prompts and not wt.prompt_ok:
+            raise _lib.CvmiError("this checkpoint carries no sam_prompt_encoder tensors: box / point prompts are unavailable")
         self.plan = Plan(stream)
         self.pool = {}
         self.dynamic = dynamic_multimask_via_stability
@@ -340,12 +380,13 @@ class Sam2Plan:
         self._build()
         torch.cuda.synchronize()
 
-    def buf(self, H, W, C, dtype=None, tag=None, zero=False):
+    def buf(self, H, W, C, dtype=None, tag=None, zero=False, batch=None):
         """Scratch buffers are shared between blocks of equal shape (launches are stream-ordered)."""
         dtype = self.dt if dtype is None else dtype
-        key = (H, W, C, dtype, tag)
+        batch = self.B if batch is None else batch
+        key = (batch, H, W, C, dtype, tag)
         if tag is None or key not in self.pool:
-            b = Buf(self.B, H, W, C, dtype, self.dev, zero=zero)
+            b = Buf(batch, H, W, C, dtype, self.dev, zero=zero)
             self.act_bytes += b.nbytes
             if tag is None:
                 return b
@@ -457,17 +498,44 @@ class Sam2Plan:
         feat_s1 = self.buf(f1, f1, 64)
         self.gemm("feat_s0", "feat_s0", s0.view(), feat_s0.view(), kind="neck")
         self.gemm("feat_s1", "feat_s1", s1.view(), feat_s1.view(), kind="neck")
-        # src = FPN level 2 + learned dense prompt   (f32: it is the decoder's residual stream "keys")
-        keys = self.buf(fs, fs, 256, F32)
-        dense = wt.const["dense"]
-        self.gemm("embed", "embed", [(s2.view(), 0), (s3.view(), 1)], keys.view(), res=_ConstView(dense, 256), res_mod=fs * fs, kind="neck")
-        self.feat_s0, self.feat_s1, self.keys0 = feat_s0, feat_s1, keys
-        P, T = fs * fs, wt.n_tok
-        # token stream (f32).  Layer 0 reads the constant tokens (qn0) and REPLACES the stream, so it needs no init.
-        q = Buf(B, 1, T, 256, F32, self.dev, zero=True)
         lib = _lib.load()
-        qn0 = Buf(B, 1, T, 256, dt, self.dev)
-        qn0.t.copy_(wt.const["tokens"].to(TORCH_DTYPE[dt]).view(1, 1, T, 256).expand(B, 1, T, 256))
+        NP = self.P                                   # prompts per image (0: learned prompts)
+        NB = B * NP if NP else B                      # decoder batch: (image, prompt) pairs, image-major
+        P = fs * fs
+        bufd = lambda *a, **k: self.buf(*a, batch=NB, **k)
+        if not NP:
+            # src = FPN level 2 + learned dense prompt   (f32: it is the decoder's residual stream "keys")
+            keys = self.buf(fs, fs, 256, F32)
+            dense = wt.const["dense"]
+            self.gemm("embed", "embed", [(s2.view(), 0), (s3.view(), 1)], keys.view(), res=_ConstView(dense, 256), res_mod=fs * fs, kind="neck")
+            T = wt.n_tok
+            # token stream (f32).  Layer 0 reads the constant tokens (qn0) and REPLACES the stream, so it needs no init.
+            qn0 = Buf(B, 1, T, 256, dt, self.dev)
+            qn0.t.copy_(wt.const["tokens"].to(TORCH_DTYPE[dt]).view(1, 1, T, 256).expand(B, 1, T, 256))
+            tpe = lambda name, C_: dict(res=_ConstView(wt.const[name], C_), res_mod=T)
+        else:
+            # src = FPN level 2 + no_mem_embed + no_mask_embed (both in the GEMM bias), repeated for the prompts of each image
+            emb = self.buf(fs, fs, 256, F32)
+            self.gemm("embed", "embed_box", [(s2.view(), 0), (s3.view(), 1)], emb.view(), kind="neck")
+            keys = bufd(fs, fs, 256, F32)
+            op_call(self.plan, "repeat_embed", "decoder", lib.cvmi_repeat_images, (emb.t.data_ptr(), keys.t.data_ptr(), P * 256 * 4, B, NP),
+                    keep=(emb, keys), bytes_=(B + NB) * P * 256 * 4)
+            T = 6 + self.K
+            self.coords = torch.zeros(NB, self.K, 2, dtype=torch.float32, device=self.dev)
+            self.labels = torch.full((NB, self.K), -1, dtype=torch.int32, device=self.dev)
+            tok0 = Buf(NB, 1, T, 256, F32, self.dev)
+            qn0 = Buf(NB, 1, T, 256, dt, self.dev)
+            op_call(self.plan, "prompt_tokens", "decoder", lib.cvmi_prompt_tokens,
+                    (self.coords.data_ptr(), self.labels.data_ptr(), wt.const["gauss"].data_ptr(), wt.const["out_tokens"].data_ptr(),
+                     wt.const["prompt_table"].data_ptr(), float(R), tok0.t.data_ptr(), qn0.t.data_ptr(), dt, NB, self.K, 6),
+                    keep=(tok0, qn0), bytes_=NB * T * 256 * 6)
+            npe = wt.pc["token_pe"].N
+            pe_all = Buf(NB, 1, T, npe, dt, self.dev)
+            self.gemm("token_pe", "token_pe", qn0.view(), pe_all.view(), kind="decoder")
+            tpe = lambda name, C_: dict(res=pe_all.view(wt.pe_off[name][0], C_))
+            self.tokens0 = tok0
+        self.feat_s0, self.feat_s1, self.keys0 = feat_s0, feat_s1, keys
+        q = Buf(NB, 1, T, 256, F32, self.dev, zero=True)
 
         def ln(label, key, src, dst):
             gam, bet = wt.ln[key]
@@ -477,24 +545,24 @@ class Sam2Plan:
             es = ESIZE[dt]
             desc = make_attn_desc(q=qb.t.data_ptr() + q_off * es, k=kb.t.data_ptr() + k_off * es, v=vb.t.data_ptr() + v_off * es, o=ob.t.data_ptr(),
                                   q_sb=Nq * qb.C, q_sh=hd, q_st=qb.C, k_sb=Nk * kb.C, k_sh=hd, k_st=kb.C, v_sb=Nk * vb.C, v_sh=hd, v_st=vb.C,
-                                  o_sb=Nq * ob.C, o_sh=hd, o_st=ob.C, B=B, heads=8, Nq=Nq, Nk=Nk, dqk=hd, dv=hd, scale=hd ** -0.5, dtype=dt,
+                                  o_sb=Nq * ob.C, o_sh=hd, o_st=ob.C, B=NB, heads=8, Nq=Nq, Nk=Nk, dqk=hd, dv=hd, scale=hd ** -0.5, dtype=dt,
                                   win=0, grid_h=0, grid_w=0, q_pool=0)
-            op_attention(self.plan, label, desc, (qb, kb, vb, ob), flops=4 * B * 8 * Nq * Nk * hd)
+            op_attention(self.plan, label, desc, (qb, kb, vb, ob), flops=4 * NB * 8 * Nq * Nk * hd)
             self.plan.ops[-1] = (self.plan.ops[-1][0], "decoder") + self.plan.ops[-1][2:]
 
-        qn = self.buf(1, T, 256, tag="qn")           # compute-dtype copies of the f32 streams
-        kn = self.buf(fs, fs, 256, tag="kn")
+        qn = bufd(1, T, 256, tag="qn")           # compute-dtype copies of the f32 streams
+        kn = bufd(fs, fs, 256, tag="kn")
         G = lambda *a, **k: self.gemm(*a, kind="decoder", **k)
         for l in (0, 1):
             p = f"l{l}"
             # --- self attention on the tokens
-            qkv = self.buf(1, T, 768, tag="sa_qkv")
+            qkv = bufd(1, T, 768, tag="sa_qkv")
             if l == 0:
                 G(f"{p}.sa.qkv", f"{p}.sa.qkv", qn0.view(), qkv.view())
             else:
                 op_cast(self.plan, f"{p}.sa.cast", q.view(), qn.view())
-                G(f"{p}.sa.qkv", f"{p}.sa.qkv", qn.view(), qkv.view(), res=_ConstView(wt.const[f"{p}.sa.qkv_pe"], 768), res_mod=T)
-            ao = self.buf(1, T, 256, tag="sa_ao")
+                G(f"{p}.sa.qkv", f"{p}.sa.qkv", qn.view(), qkv.view(), **tpe(f"{p}.sa.qkv_pe", 768))
+            ao = bufd(1, T, 256, tag="sa_ao")
             attention(f"{p}.sa.attn", qkv, 0, qkv, 256, qkv, 512, ao, T, T, 32)
             if l == 0:
                 G(f"{p}.sa.out", f"{p}.sa.out", ao.view(), q.view())                         # layer 0: queries REPLACED (skip_first_layer_pe)
@@ -504,90 +572,93 @@ class Sam2Plan:
             # --- tokens attend to the image
             op_cast(self.plan, f"{p}.t2i.castq", q.view(), qn.view())
             op_cast(self.plan, f"{p}.t2i.castk", keys.view(), kn.view())
-            tq = self.buf(1, T, 128, tag="t2i_q")
-            G(f"{p}.t2i.q", f"{p}.t2i.q", qn.view(), tq.view(), res=_ConstView(wt.const[f"{p}.t2i.q_pe"], 128), res_mod=T)
-            kv = self.buf(fs, fs, 256, tag="t2i_kv")
+            tq = bufd(1, T, 128, tag="t2i_q")
+            G(f"{p}.t2i.q", f"{p}.t2i.q", qn.view(), tq.view(), **tpe(f"{p}.t2i.q_pe", 128))
+            kv = bufd(fs, fs, 256, tag="t2i_kv")
             G(f"{p}.t2i.kv", f"{p}.t2i.kv", kn.view(), kv.view(), res=_ConstView(wt.const[f"{p}.t2i.kv_pe"], 256), res_mod=P)
-            ao2 = self.buf(1, T, 128, tag="t2i_ao")
+            ao2 = bufd(1, T, 128, tag="t2i_ao")
             attention(f"{p}.t2i.attn", tq, 0, kv, 0, kv, 128, ao2, T, P, 16)
             G(f"{p}.t2i.out", f"{p}.t2i.out", ao2.view(), q.view(), res=q.view())
             ln(f"{p}.norm2", f"{p}.norm2", q, q)
             # --- MLP on the tokens
             op_cast(self.plan, f"{p}.mlp.cast", q.view(), qn.view())
-            hid = self.buf(1, T, 2048, tag="mlp_hid")
+            hid = bufd(1, T, 2048, tag="mlp_hid")
             G(f"{p}.mlp1", f"{p}.mlp1", qn.view(), hid.view(), act=ACT_RELU)
             G(f"{p}.mlp2", f"{p}.mlp2", hid.view(), q.view(), res=q.view())
             ln(f"{p}.norm3", f"{p}.norm3", q, q)
             # --- image attends to the tokens
             op_cast(self.plan, f"{p}.i2t.castq", q.view(), qn.view())
-            iq = self.buf(fs, fs, 128, tag="i2t_q")
+            iq = bufd(fs, fs, 128, tag="i2t_q")
             G(f"{p}.i2t.q", f"{p}.i2t.q", kn.view(), iq.view(), res=_ConstView(wt.const[f"{p}.i2t.q_pe"], 128), res_mod=P)
-            ikv = self.buf(1, T, 256, tag="i2t_kv")
-            G(f"{p}.i2t.kv", f"{p}.i2t.kv", qn.view(), ikv.view(), res=_ConstView(wt.const[f"{p}.i2t.kv_pe"], 256), res_mod=T)
-            ao3 = self.buf(fs, fs, 128, tag="i2t_ao")
+            ikv = bufd(1, T, 256, tag="i2t_kv")
+            G(f"{p}.i2t.kv", f"{p}.i2t.kv", qn.view(), ikv.view(), **tpe(f"{p}.i2t.kv_pe", 256))
+            ao3 = bufd(fs, fs, 128, tag="i2t_ao")
             attention(f"{p}.i2t.attn", iq, 0, ikv, 0, ikv, 128, ao3, P, T, 16)
             G(f"{p}.i2t.out", f"{p}.i2t.out", ao3.view(), keys.view(), res=keys.view())
             ln(f"{p}.norm4", f"{p}.norm4", keys, keys)
         # --- final token -> image attention
         op_cast(self.plan, "final.castq", q.view(), qn.view())
         op_cast(self.plan, "final.castk", keys.view(), kn.view())
-        tq = self.buf(1, T, 128, tag="t2i_q")
-        G("final.q", "final.q", qn.view(), tq.view(), res=_ConstView(wt.const["final.q_pe"], 128), res_mod=T)
-        kv = self.buf(fs, fs, 256, tag="t2i_kv")
+        tq = bufd(1, T, 128, tag="t2i_q")
+        G("final.q", "final.q", qn.view(), tq.view(), **tpe("final.q_pe", 128))
+        kv = bufd(fs, fs, 256, tag="t2i_kv")
         G("final.kv", "final.kv", kn.view(), kv.view(), res=_ConstView(wt.const["final.kv_pe"], 256), res_mod=P)
-        ao2 = self.buf(1, T, 128, tag="t2i_ao")
+        ao2 = bufd(1, T, 128, tag="t2i_ao")
         attention("final.attn", tq, 0, kv, 0, kv, 128, ao2, T, P, 16)
         G("final.out", "final.out", ao2.view(), q.view(), res=q.view())
         ln("norm_final", "norm_final", q, q)
         self.tokens_out, self.keys_out = q, keys
         # --- upscaling: act1(ln1(dc1(src) + s1)) ; act2(dc2(.) + s0)
-        u1 = self.buf(f1, f1, 64)
-        G("up1", "up1", kn.view(), u1.view(), res=feat_s1.view(), shuffle_cout=64)
+        u1 = bufd(f1, f1, 64)
+        G("up1", "up1", kn.view(), u1.view(), res=feat_s1.view(), shuffle_cout=64, res_rep=NP)
         gam, bet = wt.ln["up_ln"]
         op_layernorm(self.plan, "up_ln", u1.view(), gam, bet, u1.view(), 1e-6, act=ACT_GELU)
-        u2 = self.buf(f0, f0, 32)
-        G("up2", "up2", u1.view(), u2.view(), res=feat_s0.view(), shuffle_cout=32, act=ACT_GELU, act_after_res=True)
+        u2 = bufd(f0, f0, 32)
+        G("up2", "up2", u1.view(), u2.view(), res=feat_s0.view(), shuffle_cout=32, act=ACT_GELU, act_after_res=True, res_rep=NP)
         self.up = u2
         # --- hypernetwork MLPs on the 4 mask tokens, IoU head on the iou token (rows strided by T*256)
         op_cast(self.plan, "heads.cast", q.view(), qn.view())
-        hyper = Buf(B, 1, 4, 32, F32, self.dev)
+        hyper = Buf(NB, 1, 4, 32, F32, self.dev)
         for i in range(4):
-            src = _RowsView(qn.t, B, 256, ld=T * 256, offset=(2 + i) * 256, dtype=dt)
-            h1 = self.buf(1, 1, 256, tag="h1"); h2 = self.buf(1, 1, 256, tag="h2")
+            src = _RowsView(qn.t, NB, 256, ld=T * 256, offset=(2 + i) * 256, dtype=dt)
+            h1 = bufd(1, 1, 256, tag="h1"); h2 = bufd(1, 1, 256, tag="h2")
             G(f"hyper{i}.0", f"hyper{i}.0", src, h1.view(), act=ACT_RELU)
             G(f"hyper{i}.1", f"hyper{i}.1", h1.view(), h2.view(), act=ACT_RELU)
-            G(f"hyper{i}.2", f"hyper{i}.2", h2.view(), _RowsView(hyper.t, B, 32, ld=128, offset=i * 32, dtype=F32))
-        iou4 = Buf(B, 1, 1, 4, F32, self.dev)
-        src = _RowsView(qn.t, B, 256, ld=T * 256, offset=256, dtype=dt)
-        h1 = self.buf(1, 1, 256, tag="h1"); h2 = self.buf(1, 1, 256, tag="h2")
+            G(f"hyper{i}.2", f"hyper{i}.2", h2.view(), _RowsView(hyper.t, NB, 32, ld=128, offset=i * 32, dtype=F32))
+        iou4 = Buf(NB, 1, 1, 4, F32, self.dev)
+        src = _RowsView(qn.t, NB, 256, ld=T * 256, offset=256, dtype=dt)
+        h1 = bufd(1, 1, 256, tag="h1"); h2 = bufd(1, 1, 256, tag="h2")
         G("iou.0", "iou.0", src, h1.view(), act=ACT_RELU)
         G("iou.1", "iou.1", h1.view(), h2.view(), act=ACT_RELU)
         G("iou.2", "iou.2", h2.view(), iou4.view(), act=ACT_SIGMOID)
         self.hyper, self.iou4 = hyper, iou4
         # --- masks, dynamic multimask selection, upsample + refinement
         P0 = f0 * f0
-        self.masks4 = torch.empty(B, 4, f0, f0, dtype=torch.float32, device=self.dev)
-        self.areas = torch.zeros(B, 2, dtype=torch.int32, device=self.dev)
-        self.low_res = torch.empty(B, 1, f0, f0, dtype=torch.float32, device=self.dev)
-        self.iou = torch.empty(B, 1, dtype=torch.float32, device=self.dev)
-        self.sel = torch.zeros(B, dtype=torch.int32, device=self.dev)
-        self.high_res = torch.empty(B, 1, R, R, dtype=torch.float32, device=self.dev)
+        self.masks4 = torch.empty(NB, 4, f0, f0, dtype=torch.float32, device=self.dev)
+        self.areas = torch.zeros(NB, 2, dtype=torch.int32, device=self.dev)
+        self.low_res = torch.empty(NB, 1, f0, f0, dtype=torch.float32, device=self.dev)
+        self.iou = torch.empty(NB, 1, dtype=torch.float32, device=self.dev)
+        self.sel = torch.zeros(NB, dtype=torch.int32, device=self.dev)
         op_call(self.plan, "hyper_masks", "tail", lib.cvmi_hyper_masks,
-                (hyper.t.data_ptr(), 32, u2.t.data_ptr(), 32, dt, 32, self.masks4.data_ptr(), self.areas.data_ptr(), B, P0, 0.05),
-                keep=(hyper, u2), bytes_=B * P0 * (32 * ESIZE[dt] + 16), flops=2 * B * P0 * 128)
+                (hyper.t.data_ptr(), 32, u2.t.data_ptr(), 32, dt, 32, self.masks4.data_ptr(), self.areas.data_ptr(), NB, P0, 0.05),
+                keep=(hyper, u2), bytes_=NB * P0 * (32 * ESIZE[dt] + 16), flops=2 * NB * P0 * 128)
         op_call(self.plan, "select_mask", "tail", lib.cvmi_select_mask,
                 (self.masks4.data_ptr(), self.areas.data_ptr(), iou4.t.data_ptr(), 4, 1 if self.dynamic else 0, 0.98, self.low_res.data_ptr(),
-                 self.iou.data_ptr(), self.sel.data_ptr(), B, P0), bytes_=B * P0 * 8)
-        if wt.refine_params is not None:
+                 self.iou.data_ptr(), self.sel.data_ptr(), NB, P0), bytes_=NB * P0 * 8)
+        if not self.want_high_res:
+            self.high_res = None
+            return
+        self.high_res = torch.empty(NB, 1, R, R, dtype=torch.float32, device=self.dev)
+        if wt.refine_params is not None and not NP:            # the refinement head belongs to the learned-prompt wrapper (sam2_infer.py:269-270)
             import ctypes as C
             ks = (C.c_int * len(wt.kernels))(*wt.kernels)
             taps = sum(k * k for k in wt.kernels)
             op_call(self.plan, "upsample_refine", "tail", lib.cvmi_upsample_refine,
-                    (self.low_res.data_ptr(), B, f0, f0, self.high_res.data_ptr(), R, R, wt.refine_params.data_ptr(), ks, len(wt.kernels), 4),
-                    keep=(ks,), bytes_=B * (P0 + R * R) * 4, flops=2 * B * R * R * 4 * taps)
+                    (self.low_res.data_ptr(), NB, f0, f0, self.high_res.data_ptr(), R, R, wt.refine_params.data_ptr(), ks, len(wt.kernels), 4),
+                    keep=(ks,), bytes_=NB * (P0 + R * R) * 4, flops=2 * NB * R * R * 4 * taps)
         else:
             op_call(self.plan, "upsample", "tail", lib.cvmi_bilinear_f32,
-                    (self.low_res.data_ptr(), B, f0, f0, self.high_res.data_ptr(), R, R, None, 0.0), bytes_=B * (P0 + R * R) * 4)
+                    (self.low_res.data_ptr(), NB, f0, f0, self.high_res.data_ptr(), R, R, None, 0.0), bytes_=NB * (P0 + R * R) * 4)
 
 class _ConstView:
     """Constant [rows, C] device tensor posing as a residual View (ptr, ld)."""

@@ -70,45 +70,77 @@ class SAM2Model:
     def to(self, *_a, **_k):
         return self
 
-    def plan(self, B):
+    def plan(self, B, prompts=0, high_res=True):
         if self.weights is None:
             raise RuntimeError("SAM2 weights not loaded (call load_state_dict first)")
-        if B not in self._plans:
+        key = (B, prompts, high_res)
+        if key not in self._plans:
             with torch.cuda.device(self.dev):
-                self._plans[B] = Sam2Plan(self.weights, B, self.stream, self.dynamic)
-        return self._plans[B]
+                self._plans[key] = Sam2Plan(self.weights, B, self.stream, self.dynamic, prompts=prompts, high_res=high_res)
+        return self._plans[key]
 
-    def __call__(self, images, points=None, point_labels=None, masks_prompt=None, multimask_output=False):
-        if not (torch.is_tensor(images) and images.dim() == 4 and images.shape[1] == 3 and images.shape[2] == images.shape[3] == self.image_size):
-            raise ValueError(f"expected a [B,3,{self.image_size},{self.image_size}] tensor")
-        if multimask_output:
-            raise NotImplementedError("the wrapper always runs multimask_output=False (sam2_infer.py:257)")
+    def _stage_images(self, p, images):
+        """Checked copy of a [B,3,R,R] tensor into the plan's NHWC input buffer (on the model's stream)."""
         lib = _lib.load()
         B = images.shape[0]
+        x = images.to(self.dev)
+        if x.dtype not in (torch.float32, torch.float16):
+            x = x.float()
+        src_dt = F32 if x.dtype == torch.float32 else F16
+        torch.cuda.current_stream().synchronize()
+        sp = self.stream.cuda_stream
+        if x.permute(0, 2, 3, 1).is_contiguous():            # already channels-last memory (SAM2Transforms output)
+            _lib.check(lib.cvmi_cast(x.data_ptr(), 3, src_dt, p.x_in.t.data_ptr(), 3, self.dtype, B * self.image_size ** 2, 3, sp), "cast")
+        else:
+            x = x.contiguous()
+            _lib.check(lib.cvmi_nchw_to_nhwc(x.data_ptr(), src_dt, p.x_in.t.data_ptr(), self.dtype, 3, B, 3, self.image_size, self.image_size, sp), "nchw_to_nhwc")
+        return x                                              # keep alive until the stream has consumed it
+
+    def _check_images(self, images):
+        if not (torch.is_tensor(images) and images.dim() == 4 and images.shape[1] == 3 and images.shape[2] == images.shape[3] == self.image_size):
+            raise ValueError(f"expected a [B,3,{self.image_size},{self.image_size}] tensor")
+
+    def __call__(self, images, points=None, point_labels=None, masks_prompt=None, multimask_output=False):
+        self._check_images(images)
+        if multimask_output:
+            raise NotImplementedError("the wrapper always runs multimask_output=False (sam2_infer.py:257)")
         with self._lock, torch.cuda.device(self.dev):
-            p = self.plan(B)
-            x = images.to(self.dev)
-            if x.dtype not in (torch.float32, torch.float16):
-                x = x.float()
-            src_dt = F32 if x.dtype == torch.float32 else F16
-            torch.cuda.current_stream().synchronize()
-            sp = self.stream.cuda_stream
-            if x.permute(0, 2, 3, 1).is_contiguous():            # already channels-last memory (SAM2Transforms output)
-                _lib.check(lib.cvmi_cast(x.data_ptr(), 3, src_dt, p.x_in.t.data_ptr(), 3, self.dtype, B * self.image_size ** 2, 3, sp), "cast")
-            else:
-                x = x.contiguous()
-                _lib.check(lib.cvmi_nchw_to_nhwc(x.data_ptr(), src_dt, p.x_in.t.data_ptr(), self.dtype, 3, B, 3, self.image_size, self.image_size, sp), "nchw_to_nhwc")
+            p = self.plan(images.shape[0])
+            keep = self._stage_images(p, images)
             p.plan.run()
             self.stream.synchronize()
+            del keep
             return p.high_res.clone(), p.low_res.clone(), p.iou.clone()
 
     forward = __call__
 
-    def infer_masks(self, images, boxes=None):
-        """Batched segmentation entry point (north_star): images [B,3,R,R]; boxes=None == SAM2ImageWrapper.forward."""
-        if boxes is not None:
-            raise NotImplementedError("box prompts (BASELINE configs 4-5, upstream semantics) are not built yet")
-        return self(images)
+    def infer_masks(self, images, boxes=None, return_high_res=True):
+        """Batched segmentation entry point (north_star).  images [B,3,R,R].
+        boxes=None: exactly `SAM2ImageWrapper.forward` (learned prompts) -> (high_res [B,1,R,R], low_res [B,1,R/4,R/4], iou [B,1]).
+        boxes [B,P,4] (xyxy in the R x R input pixel space, e.g. detector boxes scaled by R / original size): upstream
+        SAM2ImagePredictor box prompting on the same weights, one mask per box (multimask_output=False with the stability
+        fallback) -> (high_res logits [B,P,R,R] or None, low_res logits [B,P,R/4,R/4] (unclamped), iou [B,P])."""
+        if boxes is None:
+            return self(images)
+        self._check_images(images)
+        bx = torch.as_tensor(boxes, dtype=torch.float32)
+        B = images.shape[0]
+        if bx.dim() != 3 or bx.shape[0] != B or bx.shape[2] != 4 or bx.shape[1] == 0:
+            raise ValueError(f"boxes must be [B={B}, P>0, 4] xyxy, got {tuple(bx.shape)}")
+        P = bx.shape[1]
+        R, f0 = self.image_size, self.image_size // 4
+        with self._lock, torch.cuda.device(self.dev):
+            p = self.plan(B, prompts=P, high_res=return_high_res)
+            corners = bx.reshape(B * P, 2, 2)
+            p.coords[:, :2].copy_(corners, non_blocking=False)
+            p.coords[:, 2].zero_()
+            p.labels.copy_(torch.tensor([2, 3, -1], dtype=torch.int32).expand(B * P, 3))
+            keep = self._stage_images(p, images)
+            p.plan.run()
+            self.stream.synchronize()
+            del keep
+            hi = p.high_res.view(B, P, R, R).clone() if return_high_res else None
+            return hi, p.low_res.view(B, P, f0, f0).clone(), p.iou.view(B, P).clone()
 
 
 def get_modified_sam2(model_cfg_path, checkpoint_path, device="cuda", use_high_res_features=True, use_peft=True, lora_rank=12,

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define CVMI_VERSION 100
+#define CVMI_VERSION 101
 
 typedef void* cvmi_stream_t; /* hipStream_t */
 
@@ -81,6 +81,8 @@ typedef struct cvmi_conv_desc {
   int shuffle_cout;                 /* > 0: ConvTranspose2d(k=2,s=2) as GEMM: N = 4*shuffle_cout, column
                                        n = (dy*2+dx)*shuffle_cout + co is stored at output pixel
                                        (2*oy+dy, 2*ox+dx), channel co of a [B,2*OH,2*OW,*] tensor (y, res) */
+  int res_rep;                      /* > 1 (with shuffle_cout): the residual has B / res_rep images, image b reads
+                                       residual image b / res_rep (high-res features shared by the prompts of an image) */
 } cvmi_conv_desc;
 int cvmi_conv2d(const cvmi_conv_desc* d, cvmi_stream_t stream);
 
@@ -172,6 +174,21 @@ int cvmi_maxpool2x2(const void* x, int x_ld, void* y, int y_ld, int B, int H, in
 /* rows x C copy with dtype conversion (f32 <-> f16). */
 int cvmi_cast(const void* x, int x_ld, int x_dtype, void* y, int y_ld, int y_dtype, long long rows, int C,
               cvmi_stream_t stream);
+
+/* Prompt tokens of the SAM 2 mask decoder for n prompts of K labelled points each (upstream PromptEncoder
+ * `_embed_points` + MaskDecoder token concat; box = corners labelled 2 / 3 + one padding point labelled -1):
+ *   tokens[i, 0:T0]   = out_tokens (obj-score, iou, 4 mask tokens)
+ *   tokens[i, T0 + j] = label -1 ? table[0] : [sin, cos](2*pi * ((2*(coords[i,j] + 0.5)/image_size - 1) @ gauss)) + table[1 + label]
+ * coords f32 [n,K,2] (x, y in input pixels), labels i32 [n,K] in {-1,0,1,2,3}, gauss f32 [2,128],
+ * out_tokens f32 [T0,256], table f32 [5,256] (not_a_point, point_embeddings 0..3).
+ * Writes tokens_f32 [n, T0+K, 256] and (optional) the same values in `dtype` to tokens_lp. */
+int cvmi_prompt_tokens(const float* coords, const int* labels, const float* gauss, const float* out_tokens,
+                       const float* table, float image_size, float* tokens_f32, void* tokens_lp, int dtype,
+                       int n, int K, int T0, cvmi_stream_t stream);
+
+/* dst[b*rep + r] = src[b] for r < rep: image-major broadcast of per-image tensors to the prompts of each image
+ * (upstream MaskDecoder repeat_image=True).  bytes_per_image must be a multiple of 16. */
+int cvmi_repeat_images(const void* src, void* dst, long long bytes_per_image, int B, int rep, cvmi_stream_t stream);
 
 /* Mask decoder tail: masks[b,i,p] = sum_c hyper[b,i,c] * up[b,p,c] for the 4 mask tokens (c = 32),
  * plus the stability counters of token 0 (area over +delta / -delta) for

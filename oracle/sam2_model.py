@@ -8,7 +8,7 @@ Follows, in the reference:
   * src/sam2_infer.py:29-56     SAM2Transforms.__call__ (ToTensor / Resize / Normalize)
   * src/circuit_analyzer.py:156-223  LoRA target list and factory kwargs (r=4, alpha=16)
   * models/configs/sam2.1_hiera_l.yaml   hyper-parameters
-The network itself (Hiera, FpnNeck, PromptEncoder PE, MaskDecoder, TwoWayTransformer) lives in the
+The network itself (Hiera, FpnNeck, PromptEncoder, MaskDecoder, TwoWayTransformer) lives in the
 un-vendored facebookresearch/sam2 package (requirements.txt:12, unpinned HEAD) and LoRA in `peft`
 (requirements.txt:13): restated here from the published algorithm (SURVEY.md 8(a) rows B3-B13,
 Table H) with upstream parameter names, and cross-checked on CPU against the independent
@@ -222,6 +222,49 @@ def dense_pe(gaussian, h, w):
     return torch.cat((torch.sin(c), torch.cos(c)), -1).permute(2, 0, 1).unsqueeze(0)
 
 
+class PromptEncoder(nn.Module):
+    """Upstream sam2 PromptEncoder, the part box / point prompting uses (no mask input): random-Fourier
+    encoding of pixel-centre coordinates plus one learned vector per label.  Labels: -1 padding ("not a point"),
+    0 / 1 negative / positive click, 2 / 3 box top-left / bottom-right corner.  The reference never calls this
+    (its prompts are learned constants, src/sam2_infer.py:206-209); it serves `infer_masks(images, boxes)`."""
+
+    def __init__(self, dim=256, image_size=1024):
+        super().__init__()
+        self.image_size = image_size
+        self.pe_layer = nn.Module()
+        self.pe_layer.register_buffer("positional_encoding_gaussian_matrix", torch.randn(2, dim // 2))
+        self.point_embeddings = nn.ModuleList(nn.Embedding(1, dim) for _ in range(4))
+        self.not_a_point_embed = nn.Embedding(1, dim)
+        self.no_mask_embed = nn.Embedding(1, dim)
+
+    def encode_coords(self, coords):
+        """coords [..., 2] (x, y) in input pixels -> [..., dim]."""
+        c = 2 * (coords / self.image_size) - 1
+        c = 2 * math.pi * (c @ self.pe_layer.positional_encoding_gaussian_matrix)
+        return torch.cat((torch.sin(c), torch.cos(c)), -1)
+
+    def embed_points(self, coords, labels, pad):
+        """coords [P, K, 2], labels [P, K] -> sparse [P, K (+1), dim]."""
+        coords = coords + 0.5                                            # pixel centre
+        if pad:
+            coords = torch.cat((coords, torch.zeros(coords.shape[0], 1, 2)), 1)
+            labels = torch.cat((labels, -torch.ones(labels.shape[0], 1, dtype=labels.dtype)), 1)
+        e = self.encode_coords(coords)
+        e = torch.where((labels == -1)[..., None], torch.zeros_like(e), e)
+        e = e + torch.where((labels == -1)[..., None], self.not_a_point_embed.weight, torch.zeros_like(e))
+        for i in range(4):
+            e = e + torch.where((labels == i)[..., None], self.point_embeddings[i].weight, torch.zeros_like(e))
+        return e
+
+    def embed_boxes(self, boxes):
+        """boxes [P, 4] xyxy -> [P, 3, dim]: the predictor hands boxes over as two labelled points (2, 3) + padding."""
+        labels = torch.tensor([[2, 3]], dtype=torch.long).expand(boxes.shape[0], 2)
+        return self.embed_points(boxes.reshape(-1, 2, 2), labels, pad=True)
+
+    def dense_no_mask(self, fs):
+        return self.no_mask_embed.weight.reshape(1, -1, 1, 1).expand(1, -1, fs, fs)
+
+
 # ---- mask decoder ------------------------------------------------------------------------------------------------
 class Attention(nn.Module):
     def __init__(self, dim, heads, downsample=1, lora=()):
@@ -324,10 +367,14 @@ class MaskDecoder(nn.Module):
         self.pred_obj_score_head = MLP(dim, dim, 1, 3)
         self.dynamic, self.delta, self.thresh = dynamic_multimask_via_stability, stability_delta, stability_thresh
 
-    def predict_masks(self, image_embeddings, image_pe, sparse, dense, high_res):
-        B = image_embeddings.shape[0]
+    def predict_masks(self, image_embeddings, image_pe, sparse, dense, high_res, repeat_image=False):
         out_tokens = torch.cat((self.obj_score_token.weight, self.iou_token.weight, self.mask_tokens.weight), 0)
-        # B > 1: B independent images sharing the learned tokens (SURVEY.md 8(a) batch note)
+        if repeat_image:
+            # upstream box / point prompting: ONE image, sparse [P, K, 256]; the image embedding is repeated per prompt
+            # and the high-res features broadcast over the prompt axis
+            image_embeddings = image_embeddings.repeat_interleave(sparse.shape[0], 0)
+        B = image_embeddings.shape[0]
+        # B > 1 without repeat_image: B independent images sharing the learned tokens (SURVEY.md 8(a) batch note)
         tokens = torch.cat((out_tokens.unsqueeze(0).expand(B, -1, -1), sparse.expand(B, -1, -1)), 1)
         src = image_embeddings + dense
         pos = image_pe.expand(B, -1, -1, -1)
@@ -344,8 +391,8 @@ class MaskDecoder(nn.Module):
         masks = (hyper @ up.view(b, c, h * w)).view(b, -1, h, w)
         return masks, self.iou_prediction_head(iou_tok), self.pred_obj_score_head(hs[:, 0])
 
-    def forward(self, image_embeddings, image_pe, sparse, dense, high_res, multimask_output=False):
-        masks, iou, obj = self.predict_masks(image_embeddings, image_pe, sparse, dense, high_res)
+    def forward(self, image_embeddings, image_pe, sparse, dense, high_res, multimask_output=False, repeat_image=False):
+        masks, iou, obj = self.predict_masks(image_embeddings, image_pe, sparse, dense, high_res, repeat_image)
         if multimask_output:
             return masks[:, 1:], iou[:, 1:], obj
         if self.dynamic and not self.training:
@@ -398,10 +445,9 @@ class SAM2Core(nn.Module):
         self.image_encoder.trunk = Hiera(**hiera, lora_blocks=lora_trunk)
         chans = self.image_encoder.trunk.channel_list[::-1]
         self.image_encoder.neck = FpnNeck(chans, 256, (2, 3), lora_convs=(2, 3) if lora else ())
-        self.sam_prompt_encoder = nn.Module()
-        self.sam_prompt_encoder.pe_layer = nn.Module()
-        self.sam_prompt_encoder.pe_layer.register_buffer("positional_encoding_gaussian_matrix", torch.randn(2, 128))
+        self.sam_prompt_encoder = PromptEncoder(256, image_size)
         self.sam_mask_decoder = MaskDecoder(256, 3, lora, dynamic_multimask_via_stability)
+        self.no_mem_embed = nn.Parameter(torch.zeros(1, 1, 256))           # added to the image embedding by the image predictor
 
 
 class SAM2ImageWrapper(nn.Module):
@@ -436,6 +482,29 @@ class SAM2ImageWrapper(nn.Module):
         if return_intermediates:
             return high, low, iou, dict(embed=embed, s0=high_res[0], s1=high_res[1])
         return high, low, iou
+
+
+def predict_boxes(wrapper, images, boxes, multimask_output=False):
+    """Upstream SAM2ImagePredictor semantics (set_image_batch + _predict with box prompts) on the wrapper's
+    (fine-tuned) weights: per image, P boxes (xyxy, in the model's input pixel space) -> P masks.
+      image_embed = FPN level 2 + no_mem_embed   (yaml `directly_add_no_mem_embed: true`, models/configs/sam2.1_hiera_l.yaml:95)
+      sparse = corners as points labelled 2 / 3 + one padding point;  dense = no_mask_embed
+      decoder with repeat_image=True; multimask_output=False -> token 0, or the best multimask when unstable
+    images [B,3,R,R], boxes [B,P,4] -> high_res logits [B,P,R,R] (plain bilinear, no refinement head), low_res [B,P,R/4,R/4], iou [B,P]."""
+    m = wrapper.sam2_model
+    embed, high_res = wrapper.encode(images)
+    embed = embed + m.no_mem_embed.view(1, -1, 1, 1)
+    fs = embed.shape[-1]
+    pe = dense_pe(m.sam_prompt_encoder.pe_layer.positional_encoding_gaussian_matrix, fs, fs)
+    dense = m.sam_prompt_encoder.dense_no_mask(fs)
+    his, lows, ious = [], [], []
+    for b in range(images.shape[0]):
+        sparse = m.sam_prompt_encoder.embed_boxes(boxes[b].float())
+        low, iou, _ = m.sam_mask_decoder(embed[b:b + 1], pe, sparse, dense, [h[b:b + 1] for h in high_res],
+                                         multimask_output=multimask_output, repeat_image=True)
+        his.append(F.interpolate(low, size=(m.image_size, m.image_size), mode="bilinear", align_corners=False)[:, 0])
+        lows.append(low[:, 0]); ious.append(iou[:, 0])
+    return torch.stack(his), torch.stack(lows), torch.stack(ious)
 
 
 def postprocess_masks(masks, orig_hw):

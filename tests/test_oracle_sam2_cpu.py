@@ -250,3 +250,67 @@ def test_base_checkpoint_params_fill_wrapper_parameters():
     assert torch.equal(q.tensor("sparse_embedding", (1, 32, 256)), p.tensor("sparse_embedding", (1, 32, 256)))
     with pytest.raises(KeyError):
         p.tensor("image_encoder.trunk.blocks.99.norm1.weight", (16,))
+
+
+def test_prompt_encoder_boxes_match_independent_implementation():
+    """Box prompts (upstream semantics; BASELINE configs 4-5): corners as points labelled 2 / 3 + one padding point."""
+    C, M = _hf_models(True)
+    pe = osam.randomize_(osam.PromptEncoder(256, 1024), seed=4, std=0.5).eval()
+    hf = M.Sam2PromptEncoder(C.Sam2PromptEncoderConfig()).eval()
+    with torch.no_grad():
+        hf.shared_embedding.positional_embedding.copy_(pe.pe_layer.positional_encoding_gaussian_matrix)
+        hf.point_embed.weight.copy_(torch.cat([e.weight for e in pe.point_embeddings], 0))
+        hf.not_a_point_embed.weight.copy_(pe.not_a_point_embed.weight)
+        hf.no_mask_embed.weight.copy_(pe.no_mask_embed.weight)
+    g = torch.Generator().manual_seed(0)
+    xy = torch.rand(5, 2, generator=g) * 800
+    boxes = torch.cat((xy, xy + 24 + torch.rand(5, 2, generator=g) * 176), 1)
+    with torch.no_grad():
+        mine = pe.embed_boxes(boxes)
+        sparse, dense = hf(None, None, boxes[None].clone(), None)
+        torch.testing.assert_close(mine, sparse[0], rtol=1e-5, atol=1e-5)
+        torch.testing.assert_close(pe.dense_no_mask(64), dense, rtol=0, atol=0)
+        # clicks: positive / negative points with padding
+        pts = torch.rand(3, 2, 2, generator=g) * 1000
+        lab = torch.tensor([[1, 0], [1, 1], [0, -1]])
+        mine = pe.embed_points(pts, lab, pad=True)
+        ref, _ = hf(pts[None].clone(), lab[None], None, None)
+        torch.testing.assert_close(mine, ref[0], rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("dynamic", [False, True])
+def test_mask_decoder_box_prompts_match_independent_implementation(dynamic):
+    """repeat_image=True: one image embedding, P prompts, high-res features broadcast over the prompt axis."""
+    C, M = _hf_models(True)
+    dec = osam.randomize_(osam.MaskDecoder(256, 3, lora=False, dynamic_multimask_via_stability=dynamic), seed=6, std=0.08).eval()
+    hf = M.Sam2MaskDecoder(C.Sam2MaskDecoderConfig(dynamic_multimask_via_stability=dynamic)).eval()
+    hf.load_state_dict(_map_decoder(dec.state_dict()), strict=True)
+    g = torch.Generator().manual_seed(2)
+    emb, pe = torch.randn(1, 256, 16, 16, generator=g), torch.randn(1, 256, 16, 16, generator=g)
+    sparse = torch.randn(4, 3, 256, generator=g)
+    dense = torch.randn(1, 256, 1, 1, generator=g).expand(1, 256, 16, 16)
+    s0, s1 = torch.randn(1, 32, 64, 64, generator=g), torch.randn(1, 64, 32, 32, generator=g)
+    with torch.no_grad():
+        m, iou, obj = dec(emb, pe, sparse, dense, [s0, s1], multimask_output=False, repeat_image=True)
+        rm, riou, _, robj = hf(image_embeddings=emb, image_positional_embeddings=pe, sparse_prompt_embeddings=sparse[None],
+                               dense_prompt_embeddings=dense, multimask_output=False, high_resolution_features=[s0, s1])
+    assert m.shape == (4, 1, 64, 64)
+    torch.testing.assert_close(m, rm[0], rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(iou, riou[0], rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(obj, robj[0], rtol=1e-4, atol=1e-4)
+
+
+def test_predict_boxes_shapes_and_independence_tiny_trunk():
+    """predict_boxes: per-prompt results do not depend on the other prompts or images in the batch."""
+    hiera = dict(embed_dim=16, num_heads=1, stages=(1, 1, 2, 1), global_att_blocks=(3,), window_spec=(8, 4, 16, 8))
+    core = osam.SAM2Core(hiera, lora=False, image_size=256)
+    w = osam.randomize_(osam.SAM2ImageWrapper(core), seed=1, std=0.1).eval()
+    x = torch.randn(2, 3, 256, 256, generator=torch.Generator().manual_seed(3))
+    boxes = torch.tensor([[[10., 20., 100., 90.], [50., 60., 200., 220.], [0., 0., 255., 255.]],
+                          [[30., 30., 60., 80.], [100., 10., 180., 40.], [5., 200., 250., 250.]]])
+    with torch.no_grad():
+        hi, lo, iou = osam.predict_boxes(w, x, boxes)
+        hi1, lo1, iou1 = osam.predict_boxes(w, x[1:], boxes[1:, 1:2])
+    assert hi.shape == (2, 3, 256, 256) and lo.shape == (2, 3, 64, 64) and iou.shape == (2, 3)
+    torch.testing.assert_close(lo[1, 1], lo1[0, 0], rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(iou[1, 1], iou1[0, 0], rtol=1e-4, atol=1e-5)

@@ -328,3 +328,160 @@ def test_config1_sample_image_yolo11n_plus_sam2_tiny():
     torch.testing.assert_close(lo.cpu(), rlo, rtol=1e-3, atol=1e-3)
     rmask = (rfinal.squeeze() > 0.0).numpy().astype(np.uint8) * 255
     assert mask.shape == (720, 1280) and (mask != rmask).mean() < 1e-3
+
+
+# ---- box / point prompts (upstream SAM 2 semantics; `infer_masks(images, boxes)`, BASELINE configs 4-5) ---------------
+def _boxes(B, P, R, seed=0):
+    """xyxy in the R x R input space, sides U(24, 200) scaled to R / 1024."""
+    g = torch.Generator().manual_seed(seed)
+    side = (24 + 176 * torch.rand(B, P, 2, generator=g)) * (R / 1024)
+    xy = torch.rand(B, P, 2, generator=g) * (R - side)
+    return torch.cat((xy, xy + side), -1)
+
+
+def test_prompt_tokens_vs_oracle():
+    lib = _lib.load()
+    pe = osam.randomize_(osam.PromptEncoder(256, 1024), seed=4, std=0.5).eval()
+    g = torch.Generator().manual_seed(1)
+    out_tokens = torch.randn(6, 256, generator=g)
+    n, K = 37, 3
+    coords = torch.rand(n, K, 2, generator=g) * 1024
+    labels = torch.randint(-1, 4, (n, K), generator=g).int()
+    with torch.no_grad():
+        ref = pe.embed_points(coords, labels.long(), pad=False)
+    ref = torch.cat((out_tokens[None].expand(n, -1, -1), ref), 1)
+    table = torch.cat([pe.not_a_point_embed.weight] + [e.weight for e in pe.point_embeddings], 0).detach().contiguous().cuda()
+    gauss = pe.pe_layer.positional_encoding_gaussian_matrix.contiguous().cuda()
+    cd, ld, od = coords.cuda(), labels.cuda(), out_tokens.cuda()
+    t32 = torch.zeros(n, 6 + K, 256, device="cuda")
+    t16 = torch.zeros(n, 6 + K, 256, device="cuda", dtype=torch.float16)
+    torch.cuda.synchronize()
+    _lib.check(lib.cvmi_prompt_tokens(cd.data_ptr(), ld.data_ptr(), gauss.data_ptr(), od.data_ptr(), table.data_ptr(), 1024.0,
+                                      t32.data_ptr(), t16.data_ptr(), F16, n, K, 6, None), "prompt_tokens")
+    torch.cuda.synchronize()
+    torch.testing.assert_close(t32.cpu(), ref, rtol=1e-4, atol=1e-4)          # sin / cos of arguments up to ~ +-40 rad
+    torch.testing.assert_close(t16.float().cpu(), ref, rtol=2e-3, atol=2e-3)
+
+
+def test_repeat_images_and_shared_residual():
+    """repeat_image=True plumbing: per-image tensors broadcast to the prompts of each image; ConvTranspose skip shared."""
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(3)
+    src = torch.randn(3, 40, generator=g).cuda()
+    dst = torch.zeros(3 * 4, 40, device="cuda")
+    torch.cuda.synchronize()
+    _lib.check(lib.cvmi_repeat_images(src.data_ptr(), dst.data_ptr(), 160, 3, 4, None), "repeat")
+    torch.cuda.synchronize()
+    assert torch.equal(dst.cpu(), src.cpu().repeat_interleave(4, 0))
+    x = torch.randn(6, 64, 6, 5, generator=g)
+    w = torch.randn(64, 32, 2, 2, generator=g) / 8
+    b = torch.randn(32, generator=g)
+    skip = torch.randn(2, 32, 12, 10, generator=g)
+    ref = F.gelu(F.conv_transpose2d(x, w, b, stride=2) + skip.repeat_interleave(3, 0))
+    pc = PackedConv(w.permute(2, 3, 1, 0).reshape(128, 64, 1, 1), b.repeat(4), F32)
+    xb, sb = to_buf(x, F32), to_buf(skip, F32)
+    yb = Buf(6, 12, 10, 32, F32, zero=True)
+    plan = Plan(stream())
+    op_conv(plan, "ct", pc, [(xb.view(), 0)], yb.view(), act=ACT_GELU, res=sb.view(), shuffle_cout=32, act_after_res=True, res_rep=3)
+    run(plan)
+    torch.testing.assert_close(from_view(yb.view()), ref, **TOL[F32])
+
+
+def _run_boxes(hiera, targets, oracle_fn, image_size, dtype, B, P, seed=5):
+    from circuitvision_amd.sam2 import Sam2Plan, Sam2Weights, SamSyntheticParams
+    p = SamSyntheticParams(seed=seed, lora_targets=targets, std=0.05)
+    wt = Sam2Weights(p, hiera, image_size, dtype)
+    oracle = oracle_fn(p)
+    x = torch.randn(B, 3, image_size, image_size, generator=torch.Generator().manual_seed(0)).to(TORCH_DTYPE[dtype]).float()
+    boxes = _boxes(B, P, image_size, seed=seed)
+    with torch.no_grad():
+        ref = osam.predict_boxes(oracle, x, boxes)
+    sp = Sam2Plan(wt, B, torch.cuda.Stream(), prompts=P)
+    sp.x_in.t.copy_(x.permute(0, 2, 3, 1).to(TORCH_DTYPE[dtype]))
+    sp.coords[:, :2].copy_(boxes.reshape(B * P, 2, 2))
+    sp.labels.copy_(torch.tensor([2, 3, -1], dtype=torch.int32).expand(B * P, 3))
+    torch.cuda.synchronize()
+    sp.plan.run_eager()
+    torch.cuda.synchronize()
+    return sp, ref
+
+
+@pytest.mark.parametrize("dtype", [F32, F16])
+def test_sam2_box_prompts_mini_match_oracle(dtype):
+    """Prompt encoder + repeat_image decoder on B*P (image, prompt) pairs vs the oracle's per-image loop."""
+    B, P, R = 2, 5, 256
+    sp, (hi, lo, iou) = _run_boxes(MINI, mini_targets(), lambda p: mini_oracle(p, R), R, dtype, B, P)
+    tol = dict(rtol=1e-3, atol=1e-3) if dtype == F32 else dict(rtol=3e-2, atol=3e-2)
+    torch.testing.assert_close(sp.low_res.view(B, P, R // 4, R // 4).cpu(), lo, **tol)
+    torch.testing.assert_close(sp.iou.view(B, P).cpu(), iou, **tol)
+    torch.testing.assert_close(sp.high_res.view(B, P, R, R).cpu(), hi, **tol)
+    assert float((lo[:, 0] - lo[:, 1]).abs().max()) > 1e-3            # the prompts do change the masks
+
+
+def test_infer_masks_boxes_boundary_and_graph_replay():
+    """`infer_masks(images, boxes)` through the model object: graph replay with new boxes, boxes=None == forward."""
+    from circuitvision_amd.sam2 import Sam2Weights, SamSyntheticParams
+    from circuitvision_amd.sam2_infer import SAM2Model
+    R, B, P = 256, 2, 3
+    model = SAM2Model(MINI, R, dtype="f32", use_refinement=True)
+    p = SamSyntheticParams(seed=8, lora_targets=mini_targets(), std=0.05)
+    model.load_params(p)
+    oracle = mini_oracle(p, R)
+    x = torch.randn(B, 3, R, R, generator=torch.Generator().manual_seed(2))
+    for seed in (1, 2):
+        boxes = _boxes(B, P, R, seed=seed)
+        hi, lo, iou = model.infer_masks(x, boxes)
+        with torch.no_grad():
+            rhi, rlo, riou = osam.predict_boxes(oracle, x, boxes)
+        assert hi.shape == (B, P, R, R) and lo.shape == (B, P, R // 4, R // 4) and iou.shape == (B, P)
+        torch.testing.assert_close(lo.cpu(), rlo, rtol=1e-3, atol=1e-3)
+        torch.testing.assert_close(hi.cpu(), rhi, rtol=1e-3, atol=1e-3)
+        torch.testing.assert_close(iou.cpu(), riou, rtol=1e-3, atol=1e-3)
+    hi2, lo2, _ = model.infer_masks(x, boxes.numpy(), return_high_res=False)
+    assert hi2 is None and torch.equal(lo2.cpu(), lo.cpu())
+    a, b = model.infer_masks(x), model(x)
+    assert all(torch.equal(u, v) for u, v in zip(a, b))
+    with pytest.raises(ValueError):
+        model.infer_masks(x, boxes[:1])
+
+
+def test_sam2_box_prompts_hiera_l_f16_match_oracle():
+    """BASELINE config 5 shape at B=1, 8 boxes: SAM 2.1 Hiera-L 1024^2, fp16 operands / f32 streams.
+    Tolerance: mask logits within 5e-2 x logit scale of the fp32 oracle, binary-mask IoU >= 0.99 per prompt set."""
+    from circuitvision_amd.sam2 import HIERA_L, LORA_TARGETS_REFERENCE
+
+    def make(p):
+        w = osam.SAM2ImageWrapper(osam.SAM2Core(osam.HIERA_L, lora=True)).eval()
+        w.load_state_dict({("sam2_model." + k if not (k.startswith("dense_") or k.startswith("sparse_") or k.startswith("refinement_")) else k): v
+                           for k, v in p.state_dict().items()}, strict=True)
+        return w
+    B, P = 1, 8
+    sp, (hi, lo, iou) = _run_boxes(HIERA_L, LORA_TARGETS_REFERENCE, make, 1024, F16, B, P)
+    got = sp.low_res.view(B, P, 256, 256).cpu()
+    scale = float(lo.abs().max())
+    err = float((got - lo).abs().max())
+    print(f"Hiera-L f16 boxes: low-res logit scale {scale:.3f}, max abs err {err:.4f}, iou err {float((sp.iou.view(B, P).cpu() - iou).abs().max()):.2e}")
+    assert err <= 5e-2 * max(1.0, scale)
+    a, b = sp.high_res.view(B, P, 1024, 1024).cpu() > 0, hi > 0
+    inter_, union = (a & b).sum().item(), (a | b).sum().item()
+    assert union == 0 or inter_ / union >= 0.99
+    torch.testing.assert_close(sp.iou.view(B, P).cpu(), iou, rtol=0, atol=2e-2)
+
+
+def test_wrapper_graph_replay_with_new_images():
+    """The captured graph replayed on different images: every per-call state (stability counters) is reset inside the graph."""
+    from circuitvision_amd.sam2 import SamSyntheticParams
+    from circuitvision_amd.sam2_infer import SAM2Model
+    R = 256
+    model = SAM2Model(MINI, R, dtype="f32", use_refinement=True)
+    p = SamSyntheticParams(seed=5, lora_targets=mini_targets(), std=0.05)
+    model.load_params(p)
+    oracle = mini_oracle(p, R)
+    for seed in (0, 1, 2):
+        x = torch.randn(2, 3, R, R, generator=torch.Generator().manual_seed(seed)) * (1 + seed)
+        hi, lo, iou = model(x)
+        with torch.no_grad():
+            rhi, rlo, riou = oracle(x)
+        torch.testing.assert_close(lo.cpu(), rlo, rtol=1e-3, atol=1e-3)
+        torch.testing.assert_close(iou.cpu(), riou, rtol=1e-3, atol=1e-3)
+        torch.testing.assert_close(hi.cpu(), rhi, rtol=1e-3, atol=1e-3)
