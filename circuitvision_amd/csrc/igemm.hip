@@ -458,6 +458,263 @@ int launch_glds(ConvKArgs& a, hipStream_t stream) {
   return 0;
 }
 
+// ---- 256 x 256 tile GEMM: 8 waves, direct-to-LDS staging that stays in flight across barriers -----------------------
+// One workgroup per CU (128 KiB of LDS: two 64-KiB stages of X[256][64] + W[256][64] f16).  Waves form a 2 (pixel
+// halves) x 4 (channel quarters) grid, wave tile 128 px x 64 ch = 4 x 2 MFMA tiles of 32 x 32.  A K-tile (64 deep)
+// is computed in 4 phases of 8 MFMAs; each phase reads only the fragments it newly needs:
+//     phase 1: W c0, X p0 p1 -> (c0;p0,p1)     phase 2: W c1 -> (c1;p0,p1)
+//     phase 3: X p2 p3       -> (c1;p2,p3)     phase 4: --   -> (c0;p2,p3)
+// The stage is DMA'd (global_load_lds, 16 B per lane, XOR-swizzled source slots as in gemm_glds_kernel) in four
+// 128-row "half-tiles" named after the phase that consumes them: XA (p0 p1 of both pixel halves), WA (c0 of the
+// four channel quarters), WB (c1), XB (p2 p3).  One half-tile (2 DMA instructions per lane) is issued per phase,
+// into a region whose last reader finished at least one full phase earlier:
+//     phase (t,1): XB(t+1)   (t,2): XA(t+2)   (t,3): WA(t+2)   (t,4): WB(t+2)
+// and ONE counted wait per K-tile, `s_waitcnt vmcnt(6)` in phase 4 (everything but the three half-tiles just issued
+// has landed, i.e. all of tile t+1), followed by that phase's barriers, orders the DMA before the reads of (t+1,1).
+// Every phase is  [ds_reads; DMA issue; lgkmcnt(0)] s_barrier [8 MFMAs] s_barrier ; the two pixel halves (one wave of
+// each per SIMD) run offset by one barrier, so one wave's LDS reads overlap the other's MFMAs.
+// Hazards (both wave groups, group 1 one barrier behind; barrier instances numbered globally):
+//   RAW  every wave waits vmcnt before its first barrier of (t,4); readers of (t+1,1) have passed the barrier after it.
+//   WAR  reads are retired (lgkmcnt(0)) BEFORE the phase's first barrier, so a region read in phase p is free once
+//        every wave is past that barrier: any wave issuing phase p+1's DMA is.
+template <typename TO, bool STAGGER>
+__global__ __launch_bounds__(512, 1) void gemm256_kernel(const ConvKArgs p) {
+  using T = f16;
+  constexpr int BM = 256, BN = 256, BKB = 128;
+  constexpr int STAGE = (BM + BN) * BKB;                  // 64 KiB
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  int wg = blockIdx.x;
+  {
+    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = wg & 7, j = wg >> 3;
+    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+  }
+  const int bn = wg % p.nb_n, bm = wg / p.nb_n;
+  const int m0 = bm * BM, n0 = bn * BN;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int wr = wv >> 2, wc = wv & 3;                    // waves wv and wv + 4 share a SIMD: one of each pixel half
+  const int lr = lane & 31, lh = lane >> 5;
+
+  // DMA sources / LDS destinations: half-tile h (0 XA, 1 WA, 2 WB, 3 XB) = 16 pieces of 8 rows, 2 per wave
+  const char* src[4][2];
+  int dst[4][2];
+#pragma unroll
+  for (int h = 0; h < 4; ++h)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int q = wv * 2 + i;
+      const int row0 = (h == 0 || h == 3) ? (q >> 3) * 128 + (h == 3 ? 64 : 0) + (q & 7) * 8
+                                          : BM + (q >> 2) * 64 + (h == 2 ? 32 : 0) + (q & 3) * 8;
+      const int row = row0 + (lane >> 3);
+      const int slot = (lane & 7) ^ ((row >> 1) & 7);
+      if (row < BM) {
+        int m = m0 + row;
+        m = m < p.M ? m : p.M - 1;
+        src[h][i] = p.x0 + ((size_t)m * p.x0_ld + slot * 8) * 2;
+      } else {
+        int n = n0 + row - BM;
+        n = n < p.N ? n : p.N - 1;
+        src[h][i] = p.w + ((size_t)n * p.Kpad + slot * 8) * 2;
+      }
+      dst[h][i] = row0 * BKB;
+    }
+#define G256_ISSUE(h, stage, kt)                                                                                         \
+  do {                                                                                                                   \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[h][0] + (size_t)(kt) * BKB),   \
+                                     (__attribute__((address_space(3))) void*)(smem + (stage) * STAGE + dst[h][0]), 16, 0, 0); \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[h][1] + (size_t)(kt) * BKB),   \
+                                     (__attribute__((address_space(3))) void*)(smem + (stage) * STAGE + dst[h][1]), 16, 0, 0); \
+  } while (0)
+
+  f32x16 acc[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // fragment addresses: rows are (32-aligned base + lr), so one swizzle value serves every fragment of the lane
+  const int sw = (lr >> 1) & 7;
+  int ko[4];
+#pragma unroll
+  for (int s2 = 0; s2 < 4; ++s2) ko[s2] = ((2 * s2 + lh) ^ sw) << 4;
+  const int xbase = (wr * 128 + lr) * BKB, wbase = (BM + wc * 64 + lr) * BKB;
+
+  const int nk = p.K / 64;
+  // prologue: all of tile 0, and XA WA WB of tile 1
+  G256_ISSUE(0, 0, 0); G256_ISSUE(1, 0, 0); G256_ISSUE(2, 0, 0); G256_ISSUE(3, 0, 0);
+  if (nk > 1) {
+    G256_ISSUE(0, 1, 1); G256_ISSUE(1, 1, 1); G256_ISSUE(2, 1, 1);
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __builtin_amdgcn_s_barrier();
+  if (STAGGER && wr == 1) __builtin_amdgcn_s_barrier();
+
+  u32x4 xf[2][4], wf[2][4];
+#define G256_READ_X(slot_, j)                                                                                            \
+  _Pragma("unroll") for (int s2 = 0; s2 < 4; ++s2)                                                                       \
+      xf[slot_][s2] = *reinterpret_cast<const u32x4*>(st + xbase + (j) * 32 * BKB + ko[s2])
+#define G256_READ_W(i)                                                                                                   \
+  _Pragma("unroll") for (int s2 = 0; s2 < 4; ++s2)                                                                       \
+      wf[i][s2] = *reinterpret_cast<const u32x4*>(st + wbase + (i) * 32 * BKB + ko[s2])
+#define G256_SYNC_IN()                                                                                                   \
+  do {                                                                                                                   \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                   \
+    __builtin_amdgcn_sched_barrier(0);                                                                                   \
+    __builtin_amdgcn_s_barrier();                                                                                        \
+    __builtin_amdgcn_sched_barrier(0);                                                                                   \
+    __builtin_amdgcn_s_setprio(1);                                                                                       \
+  } while (0)
+#define G256_SYNC_OUT()                                                                                                  \
+  do {                                                                                                                   \
+    __builtin_amdgcn_s_setprio(0);                                                                                       \
+    __builtin_amdgcn_sched_barrier(0);                                                                                   \
+    __builtin_amdgcn_s_barrier();                                                                                        \
+    __builtin_amdgcn_sched_barrier(0);                                                                                   \
+  } while (0)
+  // the empty asm statements pin the MFMAs between the two barriers of their phase: hipcc otherwise sinks the (pure)
+  // MFMA calls below the second barrier, in among the next phase's loads
+#define G256_MMA(i, j0)                                                                                                  \
+  asm volatile("" : "+v"(wf[i][0]), "+v"(wf[i][1]), "+v"(wf[i][2]), "+v"(wf[i][3]));                                     \
+  _Pragma("unroll") for (int s2 = 0; s2 < 4; ++s2) {                                                                     \
+    Mma<T>::run(wf[i][s2], xf[0][s2], acc[i][j0]);                                                                       \
+    Mma<T>::run(wf[i][s2], xf[1][s2], acc[i][(j0) + 1]);                                                                 \
+  }                                                                                                                      \
+  asm volatile("" : "+v"(acc[i][j0]), "+v"(acc[i][(j0) + 1]))
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const int b = kt & 1;
+    const char* st = smem + b * STAGE;
+    const bool more1 = kt + 1 < nk, more2 = kt + 2 < nk;     // wave-uniform
+    // ---- phase 1
+    G256_READ_W(0);
+    G256_READ_X(0, 0);
+    G256_READ_X(1, 1);
+    if (more1) G256_ISSUE(3, b ^ 1, kt + 1);
+    G256_SYNC_IN();
+    G256_MMA(0, 0);
+    G256_SYNC_OUT();
+    // ---- phase 2
+    G256_READ_W(1);
+    if (more2) G256_ISSUE(0, b, kt + 2);
+    G256_SYNC_IN();
+    G256_MMA(1, 0);
+    G256_SYNC_OUT();
+    // ---- phase 3
+    G256_READ_X(0, 2);
+    G256_READ_X(1, 3);
+    if (more2) G256_ISSUE(1, b, kt + 2);
+    G256_SYNC_IN();
+    G256_MMA(1, 2);
+    G256_SYNC_OUT();
+    // ---- phase 4
+    if (more2) {
+      G256_ISSUE(2, b, kt + 2);
+      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    } else if (more1) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    G256_SYNC_IN();
+    G256_MMA(0, 2);
+    G256_SYNC_OUT();
+  }
+  if (STAGGER && wr == 0) __builtin_amdgcn_s_barrier();
+#undef G256_ISSUE
+#undef G256_READ_X
+#undef G256_READ_W
+#undef G256_SYNC_IN
+#undef G256_SYNC_OUT
+#undef G256_MMA
+
+  // ---- epilogue: bias + act -> LDS tile -> 16-byte stores (+ residual); f32 output goes in two 128-column passes
+  constexpr int OES = sizeof(TO), OVEC = 16 / OES;
+  constexpr int NPASS = OES == 4 ? 2 : 1, CW = BN / NPASS;
+  constexpr int CROWB = CW * OES + 16;
+  constexpr int NCH = CW / OVEC;
+  char* const Ct = smem;
+#pragma unroll
+  for (int pass = 0; pass < NPASS; ++pass) {
+    if (NPASS == 1 || (wc >> 1) == pass) {
+      const int cbase = NPASS == 1 ? wc * 64 : (wc & 1) * 64;
+      with_act<true>(p.act_after_res ? CVMI_ACT_NONE : p.act, [&](auto actf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int nl = cbase + i * 32 + 8 * q + 4 * lh;
+            const int n = n0 + pass * CW + nl;
+            f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+            if (n < p.N) bv = *reinterpret_cast<const f32x4*>(p.bias + n);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const int ml = wr * 128 + j * 32 + lr;
+              float v[4];
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = actf(acc[i][j][4 * q + e] + bv[e]);
+              char* d = Ct + ml * CROWB + nl * OES;
+              if constexpr (OES == 2) {
+                f16x4 hv = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
+                *reinterpret_cast<f16x4*>(d) = hv;
+              } else {
+                f32x4 fv = {v[0], v[1], v[2], v[3]};
+                *reinterpret_cast<f32x4*>(d) = fv;
+              }
+            }
+          }
+        }
+      });
+    }
+    __syncthreads();
+    for (int idx = tid; idx < BM * NCH; idx += 512) {
+      const int row = idx / NCH, ch = idx - row * NCH;
+      const int m = m0 + row, n = n0 + pass * CW + ch * OVEC;
+      if (m >= p.M || n >= p.N) continue;
+      u32x4 cv = *reinterpret_cast<const u32x4*>(Ct + row * CROWB + ch * 16);
+      const size_t rpix = p.res_mod > 0 ? (size_t)(m % p.res_mod) : (size_t)m;
+      if (p.res || p.act_after_res) {
+        float a[OVEC];
+        unpack16<TO>(cv, a);
+        if (p.res) {
+          float r[OVEC];
+          unpack16<TO>(*reinterpret_cast<const u32x4*>(p.res + (rpix * p.res_ld + n) * OES), r);
+#pragma unroll
+          for (int e = 0; e < OVEC; ++e) a[e] += r[e];
+        }
+        if (p.act_after_res) {
+#pragma unroll
+          for (int e = 0; e < OVEC; ++e) a[e] = act_apply<true>(a[e], p.act);
+        }
+        cv = pack16<TO>(a);
+      }
+      *reinterpret_cast<u32x4*>(p.y + ((size_t)m * p.y_ld + n) * OES) = cv;
+    }
+    if (pass + 1 < NPASS) __syncthreads();
+  }
+}
+
+template <typename TO>
+int launch_g256(ConvKArgs& a, hipStream_t stream, int stagger) {
+  constexpr int lds = 2 * 512 * 128;                     // two stages; the epilogue tile (256 x 528 B) is larger: 135168
+  constexpr int epi = 256 * ((sizeof(TO) == 4 ? 128 : 256) * (int)sizeof(TO) + 16);
+  constexpr int bytes = lds > epi ? lds : epi;
+  static bool attr_done = false;
+  if (!attr_done) {
+    CVMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<TO, true>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    CVMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<TO, false>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    attr_done = true;
+  }
+  a.nb_n = cdiv(a.N, 256);
+  const long long blocks = (long long)cdiv(a.M, 256) * a.nb_n;
+  CVMI_CHECK(blocks > 0 && blocks < (1ll << 31), "conv2d: bad grid %lld", blocks);
+  if (stagger) hipLaunchKernelGGL((gemm256_kernel<TO, true>), dim3((unsigned)blocks), dim3(512), bytes, stream, a);
+  else hipLaunchKernelGGL((gemm256_kernel<TO, false>), dim3((unsigned)blocks), dim3(512), bytes, stream, a);
+  CVMI_LAUNCH_CHECK();
+  return 0;
+}
+
 template <typename T, typename TO, int BM, int BN, int WM, int WN, int BKB, bool PLAIN>
 int launch_cfg2(ConvKArgs& a, hipStream_t stream) {
   constexpr int ROWB = BKB + 16;
@@ -498,6 +755,17 @@ int launch_typed(ConvKArgs& a, hipStream_t stream) {
   const long long M = a.M;
   const int N = a.N;
   static const int use_glds = getenv("CVMI_GLDS") ? atoi(getenv("CVMI_GLDS")) : 1;           // tuning experiments only
+  static const int use_g256 = getenv("CVMI_G256") ? atoi(getenv("CVMI_G256")) : 1;           // 0 off, 1 staggered, 2 lock-step
+  if constexpr (sizeof(T) == 2) {
+    // big plain f16 GEMMs: >= one 256^2 tile per CU and little column-tile waste (N = 576 -> 3 tiles, 75 % used)
+    // measured on Hiera-L shapes: wins when >= 80 % of the column tiles and of the last round of 256 tiles is used
+    // (N = 576 -> 75 % of 3 column tiles: ties / loses against the 128-row kernels below)
+    if (use_g256 && a.plain && a.K % 64 == 0 && a.K >= 256 && N % 8 == 0 && N >= 512 && a.shuf_c == 0) {
+      const long long tiles = (long long)cdiv(M, 256) * cdiv(N, 256);
+      const double col_eff = (double)N / (cdiv(N, 256) * 256), wave_eff = (double)tiles / (double)(cdiv(tiles, 256) * 256);
+      if (tiles >= 256 && ((col_eff >= 0.8 && wave_eff >= 0.8) || use_g256 >= 3)) return launch_g256<TO>(a, stream, use_g256 != 2);
+    }
+  }
   if (use_glds && a.plain && (a.K * (int)sizeof(T)) % 128 == 0 && a.K * (int)sizeof(T) >= 256 && N >= 96 &&
       (long long)cdiv(M, 128) * cdiv(N, 128) >= 512) {                                 // large GEMMs only: small grids need the smaller tiles below
     if (use_glds == 2 || N <= 640) return launch_glds<T, TO, 128, 64, 2, 2>(a, stream);      // measured: wins up to N = 576

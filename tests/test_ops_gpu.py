@@ -254,3 +254,42 @@ def test_graph_capture_replays_identically():
     plan.run(); plan.run()
     plan.stream.synchronize()
     assert torch.equal(eager, y2.t)
+
+
+@pytest.mark.parametrize("M,N,K,out_f32,act", [
+    (8192, 2048, 576, False, _lib.ACT_NONE),      # odd number of K-tiles (9)
+    (8192, 2048, 256, False, _lib.ACT_GELU),      # 4 K-tiles
+    (8192, 2048, 128 * 5, True, _lib.ACT_NONE),   # f32 output + residual: two-pass epilogue
+    (25600, 1160, 320, True, _lib.ACT_NONE),      # ragged N (last column tile 136 / 256 valid), f32 + residual, 5 K-tiles
+    (25600, 1160, 256, False, _lib.ACT_RELU),     # ragged N, f16 output
+])
+def test_gemm_256_tile_counted_dma_pipeline(M, N, K, out_f32, act):
+    """gemm256_kernel (8 waves, DMA in flight across barriers, staggered wave groups): values vs an fp32 matmul of the
+    same f16 operands, and bit-identical results over repeated launches (a DMA / LDS race shows as run-to-run noise)."""
+    g = torch.Generator().manual_seed(M + N + K)
+    x = quant(torch.randn(M, K, generator=g), F16)
+    w = quant(torch.randn(N, K, generator=g) / K ** 0.5, F16)
+    b = torch.randn(N, generator=g)
+    res = torch.randn(M, N, generator=g) if out_f32 else None
+    ref = x @ w.t() + b
+    if act == _lib.ACT_GELU:
+        ref = torch.nn.functional.gelu(ref)
+    if res is not None:
+        ref = ref + res
+    xb = Buf(1, 1, M, K, F16); xb.t.copy_(x.view(1, 1, M, K).half())
+    yb = Buf(1, 1, M, N, F32 if out_f32 else F16, zero=True)
+    rb = None
+    if res is not None:
+        rb = Buf(1, 1, M, N, F32); rb.t.copy_(res.view(1, 1, M, N))
+    pc = PackedConv(w.view(N, K, 1, 1), b, F16)
+    plan = Plan(stream())
+    op_conv(plan, "g256", pc, [(xb.view(), 0)], yb.view(), act=act, res=rb.view() if rb is not None else None)
+    run(plan)
+    first = yb.t.clone()
+    got = first.float().view(M, N).cpu()
+    tol = dict(rtol=2e-3, atol=2e-3) if out_f32 else dict(rtol=1e-2, atol=1e-2)
+    torch.testing.assert_close(got, ref, **tol)
+    for _ in range(5):
+        yb.t.zero_()
+        run(plan)
+        assert torch.equal(yb.t, first)

@@ -18,6 +18,14 @@ SHAPES = [  # name, M, N, K, act, out_f32+res
     ("s3.fc1 ", 65536, 2304, 576, ACT_GELU, False),
     ("s3.fc2 ", 65536, 576, 2304, ACT_NONE, True),
     ("s3.proj", 65536, 576, 576, ACT_NONE, True),
+    ("s2.qkv ", 262144, 864, 288, ACT_NONE, False),
+    ("s2.fc1 ", 262144, 1152, 288, ACT_GELU, False),
+    ("s2.fc2 ", 262144, 288, 1152, ACT_NONE, True),
+    ("s4.qkv ", 16384, 3456, 1152, ACT_NONE, False),
+    ("s4.fc1 ", 16384, 4608, 1152, ACT_GELU, False),
+    ("s4.fc2 ", 16384, 1152, 4608, ACT_NONE, True),
+    ("sq4096 ", 4096, 4096, 4096, ACT_NONE, False),
+    ("sq8192 ", 8192, 8192, 8192, ACT_NONE, False),
     ("y.2cv2 ", 819200, 64, 48, ACT_SILU, False),
     ("y.4cv2 ", 204800, 128, 96, ACT_SILU, False),
 ]
