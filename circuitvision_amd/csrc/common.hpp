@@ -61,9 +61,13 @@ template <> struct Elem<float> {
 
 // exact-GELU with erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, far below fp16 resolution): ~15 instructions
 // instead of libm erff's ~45; used only where the result is stored as fp16.
+// v_rcp_f32 (1 ulp).  `__frcp_rn` is the correctly rounded reciprocal: hipcc expands it to the 11-instruction IEEE division
+// sequence, which made every fp16-mode activation epilogue ~3x longer than its arithmetic.
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+
 __device__ __forceinline__ float gelu_fast(float v) {
   const float x = fabsf(v) * 0.70710678118654752440f;
-  const float t = __frcp_rn(fmaf(0.3275911f, x, 1.0f));
+  const float t = fast_rcp(fmaf(0.3275911f, x, 1.0f));
   float poly = fmaf(1.061405429f, t, -1.453152027f);
   poly = fmaf(poly, t, 1.421413741f);
   poly = fmaf(poly, t, -0.284496736f);
@@ -76,11 +80,11 @@ __device__ __forceinline__ float gelu_fast(float v) {
 template <bool FAST> __device__ __forceinline__ float act_apply(float v, int act) {
   switch (act) {
     case CVMI_ACT_SILU:
-      return FAST ? v * __frcp_rn(1.0f + __expf(-v)) : v / (1.0f + expf(-v));
+      return FAST ? v * fast_rcp(1.0f + __expf(-v)) : v / (1.0f + expf(-v));
     case CVMI_ACT_RELU: return v > 0.f ? v : 0.f;
     case CVMI_ACT_GELU: return FAST ? gelu_fast(v) : 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
     case CVMI_ACT_SIGMOID:
-      return FAST ? __frcp_rn(1.0f + __expf(-v)) : 1.0f / (1.0f + expf(-v));
+      return FAST ? fast_rcp(1.0f + __expf(-v)) : 1.0f / (1.0f + expf(-v));
     default: return v;
   }
 }

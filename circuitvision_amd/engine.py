@@ -10,7 +10,7 @@ import threading
 import torch
 
 from . import _lib
-from ._lib import F16, F32, AttnDesc, ConvDesc
+from ._lib import F16, F32, AttnDesc, C3k2Desc, ConvDesc
 
 TORCH_DTYPE = {F16: torch.float16, F32: torch.float32}
 ESIZE = {F16: 2, F32: 4}
@@ -247,6 +247,32 @@ def op_conv(plan, label, pc, srcs, dst, stride=1, pad=None, act=_lib.ACT_NONE, r
     bytes_ = in_elems * es + M * pc.N * oes + (M * pc.N * oes if res is not None else 0)
     plan.add(label, kind, thunk, bytes_, 2 * M * pc.N * pc.K)
     return d
+
+
+def c3k2_supported(c1, c, h, c2, fuse_cv1, dtype):
+    return bool(_lib.load().cvmi_c3k2_supported(c1, c, h, c2, 1 if fuse_cv1 else 0, dtype))
+
+
+def op_c3k2(plan, label, src, dst, pc_cv1, pc_m1, pc_m2, pc_cv2, c, h, fuse_cv1, shortcut=True):
+    """Fused C3k2 block (one launch).  src: block input (fuse_cv1) or the [a|b] view; dst: block output view."""
+    lib = _lib.load()
+    assert (src.B, src.H, src.W) == (dst.B, dst.H, dst.W) and dst.c == pc_cv2.N
+    assert src.c == (pc_cv1.Cin if fuse_cv1 else 2 * c), (label, src.c)
+    d = C3k2Desc(x=src.ptr, y=dst.ptr, w0=pc_cv1.w.data_ptr() if fuse_cv1 else None, w1=pc_m1.w.data_ptr(), w2=pc_m2.w.data_ptr(),
+                 w3=pc_cv2.w.data_ptr(), b0=pc_cv1.bias.data_ptr() if fuse_cv1 else None, b1=pc_m1.bias.data_ptr(), b2=pc_m2.bias.data_ptr(),
+                 b3=pc_cv2.bias.data_ptr(), x_ld=src.ld, y_ld=dst.ld, kpad0=pc_cv1.Kpad if fuse_cv1 else 0, kpad1=pc_m1.Kpad, kpad2=pc_m2.Kpad,
+                 kpad3=pc_cv2.Kpad, B=src.B, H=src.H, W=src.W, c1=pc_cv1.Cin if fuse_cv1 else 0, c=c, h=h, c2=pc_cv2.N,
+                 fuse_cv1=1 if fuse_cv1 else 0, shortcut=1 if shortcut else 0, dtype=pc_cv2.dtype)
+    plan.keep.append((d, src, dst, pc_cv1, pc_m1, pc_m2, pc_cv2))
+    sp0, fn = plan.sptr, lib.cvmi_c3k2
+
+    def thunk(sp=None):
+        sp = sp0 if sp is None else sp
+        _lib.check(fn(C.byref(d), sp), label)
+
+    px = src.B * src.H * src.W
+    flops = 2 * px * ((pc_cv1.Cin * 2 * c if fuse_cv1 else 0) + 9 * c * h * 2 + 3 * c * pc_cv2.N)
+    plan.add(label, "conv", thunk, px * (src.c + dst.c) * ESIZE[pc_cv2.dtype], flops)
 
 
 def op_dwconv(plan, label, pd, src, dst, act=_lib.ACT_NONE, res=None):

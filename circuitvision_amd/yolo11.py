@@ -15,12 +15,14 @@ Design notes (MI355X):
 """
 import hashlib
 import math
+import os
 
 import torch
 
 from . import _lib
 from ._lib import ACT_NONE, ACT_SILU, F16, F32
-from .engine import ESIZE, Buf, PackedConv, PackedDW, Plan, op_attention, op_call, op_conv, op_dwconv, op_sppf_pool, make_attn_desc
+from .engine import (ESIZE, Buf, PackedConv, PackedDW, Plan, c3k2_supported, make_attn_desc, op_attention, op_c3k2, op_call, op_conv,
+                     op_dwconv, op_sppf_pool)
 
 SCALES = {"n": (0.50, 0.25, 1024), "s": (0.50, 0.50, 1024), "m": (0.50, 1.00, 512),
           "l": (1.00, 1.00, 512), "x": (1.00, 1.50, 512)}
@@ -228,10 +230,11 @@ class Yolo11Plan:
     """Launch plan of the full forward for one (B, H, W): input NHWC [B,H,W,3] -> pred f32 [B,4+nc,A]
     -> NMS outputs."""
 
-    def __init__(self, weights, B, H, W, stream, conf=0.25, iou=0.7, max_det=300, with_nms=True, keep_scores=True):
+    def __init__(self, weights, B, H, W, stream, conf=0.25, iou=0.7, max_det=300, with_nms=True, keep_scores=True, fuse_c3k2=True):
         """keep_scores=False: the decode kernel skips the class-score rows of `pred` (NMS takes the per-anchor
         best class straight from the decode kernel); the detections are identical."""
         self.keep_scores = keep_scores
+        self.fuse_c3k2 = fuse_c3k2 and os.environ.get("CVMI_FUSE_C3K2", "1") != "0"
         assert H % 32 == 0 and W % 32 == 0, "network input must be a multiple of stride 32"
         self.wt, self.B, self.H, self.W = weights, B, H, W
         self.dt, self.dev = weights.dtype, weights.device
@@ -270,6 +273,22 @@ class Yolo11Plan:
         v0, up0 = srcs[0]
         H, W = v0.H << up0, v0.W << up0
         c = int(c2 * e)
+        if dst is None:
+            dst = self.buf(H, W, c2).view()
+        # small-channel blocks: one fused launch (c3k2_fused.hip), with cv1 folded in when the block has a single source
+        if self.fuse_c3k2 and not c3k and n == 1:
+            h = int(c * 0.5)
+            pk = self.wt.packed
+            one_src = len(srcs) == 1 and up0 == 0
+            args = (pk[f"{name}.cv1"], pk[f"{name}.m.0.cv1"], pk[f"{name}.m.0.cv2"], pk[f"{name}.cv2"], c, h)
+            if one_src and c3k2_supported(v0.c, c, h, c2, True, self.dt):
+                op_c3k2(self.plan, name, v0, dst, *args, fuse_cv1=True)
+                return dst
+            if c3k2_supported(0, c, h, c2, False, self.dt):
+                Y = self.buf(H, W, 2 * c)
+                self.cv(f"{name}.cv1", srcs, Y.view())
+                op_c3k2(self.plan, f"{name}.fused", Y.view(), dst, *args, fuse_cv1=False)
+                return dst
         Y = self.buf(H, W, (2 + n) * c)
         self.cv(f"{name}.cv1", srcs, Y.view(0, 2 * c))
         for i in range(n):
@@ -278,8 +297,6 @@ class Yolo11Plan:
                 self.c3k(f"{name}.m.{i}", src, out, c)
             else:
                 self.bottleneck(f"{name}.m.{i}", src, out, c, 0.5)
-        if dst is None:
-            dst = self.buf(H, W, c2).view()
         self.cv(f"{name}.cv2", Y.view(), dst)
         return dst
 

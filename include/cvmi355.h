@@ -86,6 +86,22 @@ typedef struct cvmi_conv_desc {
 } cvmi_conv_desc;
 int cvmi_conv2d(const cvmi_conv_desc* d, cvmi_stream_t stream);
 
+/* ---- fused C3k2 block (ultralytics C3k2.forward with c3k = False, n = 1; YOLO11 model.2 / .4 / .16 at scale n):
+ *   [a|b] = SiLU(cv1 x) (1x1, c1 -> 2c; only when fuse_cv1, else x IS the [a|b] tensor of 2c channels),
+ *   t = SiLU(m.cv1 (*) b) (3x3, c -> h), m = b + SiLU(m.cv2 (*) t) (3x3, h -> c; `shortcut`), y = SiLU(cv2 [a|b|m]) (1x1, 3c -> c2).
+ * One launch, intermediates in LDS.  Weights / biases are cvmi_conv2d-packed ([Npad >= 128][kpad], BN folded).
+ * cvmi_c3k2_supported() tells which (c1, c, h, c2) configurations are built (fp16 only). */
+typedef struct {
+  const void* x; void* y;
+  const void *w0, *w1, *w2, *w3;
+  const float *b0, *b1, *b2, *b3;
+  int x_ld, y_ld, kpad0, kpad1, kpad2, kpad3;
+  int B, H, W, c1, c, h, c2;
+  int fuse_cv1, shortcut, dtype;
+} cvmi_c3k2_desc;
+int cvmi_c3k2_supported(int c1, int c, int h, int c2, int fuse_cv1, int dtype);
+int cvmi_c3k2(const cvmi_c3k2_desc* d, cvmi_stream_t stream);
+
 /* ---- depthwise 3x3 stride-1 conv + bias + act (YOLO Detect cls branch, C2PSA pe) -------------
  * w: [9][C] (tap-major), bias [C] f32.  Replaces ultralytics DWConv inside YOLO.predict. */
 int cvmi_dwconv3x3(const void* x, int x_ld, const void* w, const float* bias, const void* res,

@@ -274,6 +274,8 @@ def test_gemm_256_tile_counted_dma_pipeline(M, N, K, out_f32, act):
     ref = x @ w.t() + b
     if act == _lib.ACT_GELU:
         ref = torch.nn.functional.gelu(ref)
+    elif act == _lib.ACT_RELU:
+        ref = torch.relu(ref)
     if res is not None:
         ref = ref + res
     xb = Buf(1, 1, M, K, F16); xb.t.copy_(x.view(1, 1, M, K).half())

@@ -196,3 +196,28 @@ def test_predict_boundary_matches_oracle_pipeline():
     a = [b["persistent_uid"] for b in non_max_suppression_by_confidence(got_d, 0.6)]
     b = [b["persistent_uid"] for b in onms.nms_by_confidence(ref_d, 0.6)]
     assert a == b
+
+
+@pytest.mark.parametrize("hw", [(96, 160), (160, 224)])
+def test_c3k2_fused_blocks_match_unfused_launch_chain(hw):
+    """model.2 / .4 (cv1 folded in) and model.16 as ONE launch each (c3k2_fused.hip) vs the 4-launch chain on the same
+    weights: the fused kernel rounds to fp16 exactly where the chain stores fp16, so the features agree to fp16 noise."""
+    nc, B = 62, 2
+    H, W = hw
+    params = SyntheticParams(seed=11, nc=nc)
+    wt = Yolo11Weights("n", nc, params, F16)
+    x = torch.rand(B, 3, H, W, generator=torch.Generator().manual_seed(1))
+    outs = []
+    for fuse in (True, False):
+        plan = Yolo11Plan(wt, B, H, W, torch.cuda.Stream(), fuse_c3k2=fuse)
+        labels = [op[0] for op in plan.plan.ops]
+        assert ("model.2" in labels) == fuse and ("model.16.fused" in labels) == fuse and ("model.2.cv2" in labels) != fuse
+        plan.set_input_nchw(x)
+        torch.cuda.synchronize()
+        plan.plan.run_eager()
+        torch.cuda.synchronize()
+        outs.append(([v.tensor().float().cpu() for v in plan.feats], plan.pred.cpu()))
+    for a, b_ in zip(outs[0][0], outs[1][0]):
+        torch.testing.assert_close(a, b_, rtol=4e-3, atol=4e-3)
+    torch.testing.assert_close(outs[0][1][:, 4:], outs[1][1][:, 4:], rtol=0, atol=4e-3)
+    torch.testing.assert_close(outs[0][1][:, :4], outs[1][1][:, :4], rtol=4e-3, atol=0.25)
