@@ -208,12 +208,14 @@ __global__ __launch_bounds__(256) void attn_f16_kernel(const AttnArgs p) {
     }
     mx = fmaxf(mx, __shfl_xor(mx, 32));
     const float m_new = fmaxf(m_run, mx);
-    const float alpha = exp2f((m_run - m_new) * c);
+    // raw v_exp_f32: arguments are <= 0, so exp2f's denormal-range rescue (5 extra instructions per value) buys nothing
+    const float mc = m_new * c;
+    const float alpha = __builtin_amdgcn_exp2f(fmaf(m_run, c, -mc));
     float psum = 0.f;
     f16x8 pf[2];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const float pv = exp2f((sacc[r] - m_new) * c);
+      const float pv = __builtin_amdgcn_exp2f(fmaf(sacc[r], c, -mc));
       psum += pv;
       pf[r >> 3][r & 7] = (f16)pv;
     }
