@@ -25,6 +25,7 @@ struct AttnArgs {
   int win, grid_h, grid_w, q_pool;
   int qtiles;      // ceil(Nq / 32)
   int items;       // B * heads * qtiles
+  FastDiv div_win; // window mode: key -> (row, column) inside the window without a hardware division
 };
 
 // element offset of token t of batch entry b (window mode: b enumerates windows of an image grid)
@@ -133,6 +134,26 @@ __global__ __launch_bounds__(256) void attn_f16_kernel(const AttnArgs p) {
   constexpr int KN = (32 * (DQKP / 8) + GS - 1) / GS, VN = (32 * (DVP / 8) + GS - 1) / GS;
   u32x4 kreg[KN], vreg[VN];
   bool kok[KN], vok[VN];
+  // Loader addressing, hoisted: everything that depends only on the loader's (batch entry, head) is computed once --
+  // tok_off() costs five integer divisions, i.e. > 100 VALU instructions per 16-byte chunk if left in the key loop.
+  const char *kbase, *vbase;
+  {
+    long long korg, vorg;
+    if (p.win > 0) {
+      const long long pix0 = tok_off(lb, 0, 1, 1, p.win, p.grid_h, p.grid_w);      // window origin, in pixels
+      korg = pix0 * p.k_st; vorg = pix0 * p.v_st;
+    } else {
+      korg = (long long)lb * p.k_sb; vorg = (long long)lb * p.v_sb;
+    }
+    kbase = p.k + (korg + (long long)lhd * p.k_sh) * 2;
+    vbase = p.v + (vorg + (long long)lhd * p.v_sh) * 2;
+  }
+  const int kst = (int)p.k_st, vst = (int)p.v_st;
+  auto key_pix = [&](int key) -> int {                     // pixel offset of a key token from the window origin
+    if (p.win <= 0) return key;
+    const int ty = (int)p.div_win.div((unsigned)key);
+    return ty * p.grid_w + (key - ty * p.win);
+  };
   auto fetch = [&](int kt) {
 #pragma unroll
     for (int i = 0; i < KN; ++i) {
@@ -140,8 +161,8 @@ __global__ __launch_bounds__(256) void attn_f16_kernel(const AttnArgs p) {
       const int row = idx / (DQKP / 8), ch = idx - row * (DQKP / 8);
       const int key = kt * 32 + row;
       const bool ok = idx < 32 * (DQKP / 8) && key < p.Nk && ch * 8 < p.dqk;
-      const long long off = tok_off(lb, ok ? key : 0, p.k_sb, p.k_st, p.win, p.grid_h, p.grid_w) + (long long)lhd * p.k_sh + (ok ? ch * 8 : 0);
-      kreg[i] = *reinterpret_cast<const u32x4*>(p.k + off * 2);
+      const int off = ok ? key_pix(key) * kst + ch * 8 : 0;
+      kreg[i] = *reinterpret_cast<const u32x4*>(kbase + (long long)off * 2);
       kok[i] = ok;
     }
 #pragma unroll
@@ -150,8 +171,8 @@ __global__ __launch_bounds__(256) void attn_f16_kernel(const AttnArgs p) {
       const int ch = idx / 32, key_l = idx - ch * 32;       // consecutive threads -> consecutive keys
       const int key = kt * 32 + key_l;
       const bool ok = idx < 32 * (DVP / 8) && key < p.Nk && ch * 8 < p.dv;
-      const long long off = tok_off(lb, ok ? key : 0, p.v_sb, p.v_st, p.win, p.grid_h, p.grid_w) + (long long)lhd * p.v_sh + (ok ? ch * 8 : 0);
-      vreg[i] = *reinterpret_cast<const u32x4*>(p.v + off * 2);
+      const int off = ok ? key_pix(key) * vst + ch * 8 : 0;
+      vreg[i] = *reinterpret_cast<const u32x4*>(vbase + (long long)off * 2);
       vok[i] = ok;
     }
   };
@@ -384,6 +405,7 @@ extern "C" int cvmi_attention(const cvmi_attn_desc* d, cvmi_stream_t stream_) {
   a.B = d->B; a.heads = d->heads; a.Nq = d->Nq; a.Nk = d->Nk; a.dqk = d->dqk; a.dv = d->dv; a.scale = d->scale;
   a.win = d->win; a.grid_h = d->grid_h; a.grid_w = d->grid_w; a.q_pool = d->q_pool;
   a.qtiles = (d->Nq + 31) / 32;
+  a.div_win.init(d->win > 0 ? (unsigned)d->win : 1u);
   a.items = d->B * d->heads * a.qtiles;
   if (d->win > 0) {
     CVMI_CHECK(d->grid_h % d->win == 0 && d->grid_w % d->win == 0, "attention: grid %dx%d not divisible by window %d", d->grid_h, d->grid_w, d->win);
@@ -403,6 +425,8 @@ extern "C" int cvmi_attention(const cvmi_attn_desc* d, cvmi_stream_t stream_) {
     return 0;
   }
   CVMI_CHECK(d->dqk % 8 == 0 && d->dv % 8 == 0, "attention(f16): head dims must be multiples of 8");
+  CVMI_CHECK(d->k_st > 0 && d->v_st > 0 && d->k_st < (1 << 16) && d->v_st < (1 << 16) && (long long)d->Nk * d->grid_w < (1 << 15) + (long long)d->Nk,
+             "attention(f16): token strides must be below 65536 elements");
   const long long strides[] = {d->q_sb, d->q_sh, d->q_st, d->k_sb, d->k_sh, d->k_st, d->v_sb, d->v_sh, d->v_st, d->o_sb, d->o_sh, d->o_st};
   for (long long s : strides) CVMI_CHECK(s % 4 == 0, "attention(f16): strides must be multiples of 4 elements");
   CVMI_CHECK(d->q_st % 8 == 0 && d->k_st % 8 == 0 && d->v_st % 8 == 0 && d->q_sh % 8 == 0 && d->k_sh % 8 == 0 && d->v_sh % 8 == 0 &&
