@@ -154,6 +154,27 @@ __global__ __launch_bounds__(256) void attn_f16_kernel(const AttnArgs p) {
     const int ty = (int)p.div_win.div((unsigned)key);
     return ty * p.grid_w + (key - ty * p.win);
   };
+  // 32 consecutive keys advance the pixel offset by a constant when 32 is a whole number of window rows (or no window):
+  // the per-chunk offsets are then "offset at tile 0 + kt * stride" (wave-uniform choice; windows 14 / 7 take the general path)
+  // (shared-tile kernels only: the per-wave-tile kernels run 1-2 key tiles and cannot spare the registers)
+  const bool linear = GS == 256 && (p.win <= 0 || (32 % p.win) == 0);
+  const int tile_pix = p.win <= 0 ? 32 : (32 / (p.win > 0 ? p.win : 1)) * p.grid_w;
+  constexpr int KNL = GS == 256 ? KN : 1, VNL = GS == 256 ? VN : 1;
+  int koff0[KNL], voff0[VNL];
+  if constexpr (GS == 256) {
+#pragma unroll
+    for (int i = 0; i < KN; ++i) {
+      const int idx = gt + i * GS;
+      const int row = idx / (DQKP / 8), ch = idx - row * (DQKP / 8);
+      koff0[i] = key_pix(row) * kst + ch * 8;
+    }
+#pragma unroll
+    for (int i = 0; i < VN; ++i) {
+      const int idx = gt + i * GS;
+      const int ch = idx / 32, key_l = idx - ch * 32;
+      voff0[i] = key_pix(key_l) * vst + ch * 8;
+    }
+  }
   auto fetch = [&](int kt) {
 #pragma unroll
     for (int i = 0; i < KN; ++i) {
@@ -161,8 +182,8 @@ __global__ __launch_bounds__(256) void attn_f16_kernel(const AttnArgs p) {
       const int row = idx / (DQKP / 8), ch = idx - row * (DQKP / 8);
       const int key = kt * 32 + row;
       const bool ok = idx < 32 * (DQKP / 8) && key < p.Nk && ch * 8 < p.dqk;
-      const int off = ok ? key_pix(key) * kst + ch * 8 : 0;
-      kreg[i] = *reinterpret_cast<const u32x4*>(kbase + (long long)off * 2);
+      const int off = linear ? koff0[GS == 256 ? i : 0] + kt * tile_pix * kst : key_pix(key) * kst + ch * 8;
+      kreg[i] = *reinterpret_cast<const u32x4*>(kbase + (long long)(ok ? off : 0) * 2);
       kok[i] = ok;
     }
 #pragma unroll
@@ -171,8 +192,8 @@ __global__ __launch_bounds__(256) void attn_f16_kernel(const AttnArgs p) {
       const int ch = idx / 32, key_l = idx - ch * 32;       // consecutive threads -> consecutive keys
       const int key = kt * 32 + key_l;
       const bool ok = idx < 32 * (DVP / 8) && key < p.Nk && ch * 8 < p.dv;
-      const int off = ok ? key_pix(key) * vst + ch * 8 : 0;
-      vreg[i] = *reinterpret_cast<const u32x4*>(vbase + (long long)off * 2);
+      const int off = linear ? voff0[GS == 256 ? i : 0] + kt * tile_pix * vst : key_pix(key) * vst + ch * 8;
+      vreg[i] = *reinterpret_cast<const u32x4*>(vbase + (long long)(ok ? off : 0) * 2);
       vok[i] = ok;
     }
   };
@@ -220,13 +241,16 @@ __global__ __launch_bounds__(256) void attn_f16_kernel(const AttnArgs p) {
       sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, __builtin_bit_cast(f16x8, qf[s]), sacc, 0, 0, 0);
     }
     // mask keys past Nk, running max
-    float mx = -INFINITY;
+    if (kt * 32 + 32 > p.Nk) {                    // ragged last tile only (wave-uniform)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      if (key >= p.Nk) sacc[r] = -INFINITY;
-      mx = fmaxf(mx, sacc[r]);
+      for (int r = 0; r < 16; ++r) {
+        const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (key >= p.Nk) sacc[r] = -INFINITY;
+      }
     }
+    float mx = sacc[0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sacc[r]);
     mx = fmaxf(mx, __shfl_xor(mx, 32));
     const float m_new = fmaxf(m_run, mx);
     // raw v_exp_f32: arguments are <= 0, so exp2f's denormal-range rescue (5 extra instructions per value) buys nothing
@@ -242,11 +266,14 @@ __global__ __launch_bounds__(256) void attn_f16_kernel(const AttnArgs p) {
     }
     psum += __shfl_xor(psum, 32);
     l_run = l_run * alpha + psum;
+    const float m_prev = m_run;
     m_run = m_new;
+    if (__any(m_new != m_prev)) {                 // alpha == 1 in every lane otherwise (wave-uniform branch)
 #pragma unroll
-    for (int t = 0; t < DT; ++t)
+      for (int t = 0; t < DT; ++t)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) oacc[t][r] *= alpha;
+        for (int r = 0; r < 16; ++r) oacc[t][r] *= alpha;
+    }
     // ---- O^T += V^T P^T ---------------------------------------------------------------------------
 #pragma unroll
     for (int t = 0; t < DT; ++t) {
