@@ -14,6 +14,7 @@
 // its own item (many small windows).
 // f32 (parity mode): plain VALU kernel, one wave per query.
 #include "common.hpp"
+#include <stdlib.h>
 
 namespace {
 
@@ -319,6 +320,261 @@ __global__ __launch_bounds__(256) void attn_f16_kernel(const AttnArgs p) {
   }
 }
 
+// ---- long-sequence variant: 64-key tiles, V kept row-major and transposed by the LDS read --------------------------
+// Same products and online softmax as attn_f16_kernel<.., 256> (workgroup = 4 q-tiles of one (b, h) sharing the K / V
+// tile), but (1) a tile holds 64 keys, so the two barriers, the staging bookkeeping and the accumulator rescale are
+// paid once per 24 MFMAs instead of once per 12, and (2) V is written to LDS as it comes from HBM ([key][d], 16-byte
+// stores) and the V^T operand is gathered by ds_read_b64_tr_b16 (per 16-lane group: a 4-key x 16-d block delivered
+// column-major), which removes the 8 scalar 2-byte LDS stores per staged chunk the transposed image needed.
+// V row stride: a 32-lane half reads 4 consecutive key rows x 64 bytes, conflict-free when (stride mod 256) is 64 or 192.
+typedef short s16x4 __attribute__((__vector_size__(4 * sizeof(short))));
+template <int DQKP, int DVP>
+__global__ __launch_bounds__(256, 2) void attn64_kernel(const AttnArgs p) {
+  constexpr int KROW = DQKP * 2 + 16;
+  constexpr int VRS = DVP * 2 + (((DVP * 2) % 256 == 64 || (DVP * 2) % 256 == 192) ? 0 : 64);
+  constexpr int KTILE = 64 * KROW;
+  constexpr int QS = DQKP / 16, DT = DVP / 32;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const Ks = smem;
+  char* const Vs = smem + KTILE;
+
+  const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+  const int lr = lane & 31, lh = lane >> 5;
+  const int qgroups = (p.qtiles + 3) / 4;
+  const int item = blockIdx.x / qgroups;                 // (b, h) of the workgroup
+  const int qt = (blockIdx.x - item * qgroups) * 4 + wv;
+  const bool live = qt < p.qtiles;
+  const int b = item / p.heads, h = item - b * p.heads;
+  const int qwin = p.q_pool ? p.win / 2 : p.win;
+
+  const int qi = qt * 32 + lr;
+  const bool q_ok = live && qi < p.Nq;
+  u32x4 qf[QS];
+#pragma unroll
+  for (int s = 0; s < QS; ++s) {
+    const int d0 = 16 * s + 8 * lh;
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (q_ok && d0 < p.dqk) {
+      if (!p.q_pool) {
+        const long long off = tok_off(b, qi, p.q_sb, p.q_st, p.win, p.grid_h, p.grid_w) + (long long)h * p.q_sh + d0;
+        v = *reinterpret_cast<const u32x4*>(p.q + off * 2);
+      } else {
+        const int py = qi / qwin, px = qi - py * qwin;
+        f16x8 m;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) m[e] = (f16)(-65504.f);
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+          for (int dx = 0; dx < 2; ++dx) {
+            const int t = (2 * py + dy) * p.win + 2 * px + dx;
+            const long long off = tok_off(b, t, p.q_sb, p.q_st, p.win, p.grid_h, p.grid_w) + (long long)h * p.q_sh + d0;
+            const f16x8 x = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(p.q + off * 2));
+#pragma unroll
+            for (int e = 0; e < 8; ++e) m[e] = x[e] > m[e] ? x[e] : m[e];
+          }
+        v = __builtin_bit_cast(u32x4, m);
+      }
+    }
+    qf[s] = v;
+  }
+
+  f32x16 oacc[DT];
+#pragma unroll
+  for (int t = 0; t < DT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[t][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+  const float c = p.scale * 1.44269504088896340736f;
+
+  // loader addressing (see attn_f16_kernel): bases once, per-chunk offsets at tile 0, a constant stride per 64-key tile
+  const char *kbase, *vbase;
+  {
+    long long korg, vorg;
+    if (p.win > 0) {
+      const long long pix0 = tok_off(b, 0, 1, 1, p.win, p.grid_h, p.grid_w);
+      korg = pix0 * p.k_st; vorg = pix0 * p.v_st;
+    } else {
+      korg = (long long)b * p.k_sb; vorg = (long long)b * p.v_sb;
+    }
+    kbase = p.k + (korg + (long long)h * p.k_sh) * 2;
+    vbase = p.v + (vorg + (long long)h * p.v_sh) * 2;
+  }
+  const int kst = (int)p.k_st, vst = (int)p.v_st;
+  auto key_pix = [&](int key) -> int {
+    if (p.win <= 0) return key;
+    const int ty = (int)p.div_win.div((unsigned)key);
+    return ty * p.grid_w + (key - ty * p.win);
+  };
+  const bool linear = p.win <= 0 || (64 % p.win) == 0;
+  const int tile_pix = p.win <= 0 ? 64 : (64 / (p.win > 0 ? p.win : 1)) * p.grid_w;
+  constexpr int KCH = DQKP / 8, VCH = DVP / 8;
+  constexpr int KN = 64 * KCH / 256, VN = 64 * VCH / 256;
+  static_assert(64 * KCH % 256 == 0 && 64 * VCH % 256 == 0, "tile chunks must divide over 256 threads");
+  int koff0[KN], voff0[VN];
+#pragma unroll
+  for (int i = 0; i < KN; ++i) {
+    const int idx = tid + i * 256, row = idx / KCH, ch = idx - row * KCH;
+    koff0[i] = key_pix(row) * kst + ch * 8;
+  }
+#pragma unroll
+  for (int i = 0; i < VN; ++i) {
+    const int idx = tid + i * 256, row = idx / VCH, ch = idx - row * VCH;
+    voff0[i] = key_pix(row) * vst + ch * 8;
+  }
+  u32x4 kreg[KN], vreg[VN];
+  unsigned okmask = 0;                                    // bit i: K chunk i valid; bit 8 + i: V chunk i valid
+  auto fetch = [&](int kt) {
+    okmask = 0;
+#pragma unroll
+    for (int i = 0; i < KN; ++i) {
+      const int idx = tid + i * 256, row = idx / KCH, ch = idx - row * KCH;
+      const int key = kt * 64 + row;
+      const bool ok = key < p.Nk && ch * 8 < p.dqk;
+      const int off = linear ? koff0[i] + kt * tile_pix * kst : key_pix(key) * kst + ch * 8;
+      kreg[i] = *reinterpret_cast<const u32x4*>(kbase + (long long)(ok ? off : 0) * 2);
+      okmask |= ok ? 1u << i : 0u;
+    }
+#pragma unroll
+    for (int i = 0; i < VN; ++i) {
+      const int idx = tid + i * 256, row = idx / VCH, ch = idx - row * VCH;
+      const int key = kt * 64 + row;
+      const bool ok = key < p.Nk && ch * 8 < p.dv;
+      const int off = linear ? voff0[i] + kt * tile_pix * vst : key_pix(key) * vst + ch * 8;
+      vreg[i] = *reinterpret_cast<const u32x4*>(vbase + (long long)(ok ? off : 0) * 2);
+      okmask |= ok ? 1u << (8 + i) : 0u;
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int i = 0; i < KN; ++i) {
+      const int idx = tid + i * 256, row = idx / KCH, ch = idx - row * KCH;
+      *reinterpret_cast<u32x4*>(Ks + row * KROW + ch * 16) = (okmask >> i) & 1u ? kreg[i] : u32x4{0u, 0u, 0u, 0u};
+    }
+#pragma unroll
+    for (int i = 0; i < VN; ++i) {
+      const int idx = tid + i * 256, row = idx / VCH, ch = idx - row * VCH;
+      *reinterpret_cast<u32x4*>(Vs + row * VRS + ch * 16) = (okmask >> (8 + i)) & 1u ? vreg[i] : u32x4{0u, 0u, 0u, 0u};
+    }
+  };
+  // V^T fragment gather: group g = lane / 16 holds d columns 16 (g & 1) .., keys 4 lh .. (the S^T accumulator's key order:
+  // k-slot 8 lh + j of a 16-key step is key 4 lh + (j & 3) + 8 (j >> 2)); lane 4 q + pp of the group addresses block row q,
+  // columns 4 pp .. 4 pp + 3
+  const int li = lane & 15;
+  const char* const vt = Vs + (4 * lh + (li >> 2)) * VRS + (16 * (lr >> 4) + 4 * (li & 3)) * 2;
+  const char* const kq = Ks + lr * KROW + lh * 16;
+
+  const int nkt = (p.Nk + 63) / 64;
+  fetch(0);
+  commit();
+  __syncthreads();
+  for (int kt = 0; kt < nkt; ++kt) {
+    if (kt + 1 < nkt) fetch(kt + 1);
+    // ---- S^T: 64 keys x 32 queries
+    f32x16 sacc[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sacc[u][r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < QS; ++s)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const f16x8 kf = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(kq + u * 32 * KROW + s * 32));
+        sacc[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, __builtin_bit_cast(f16x8, qf[s]), sacc[u], 0, 0, 0);
+      }
+    if (kt * 64 + 64 > p.Nk) {                             // ragged last tile only (wave-uniform)
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = kt * 64 + u * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (key >= p.Nk) sacc[u][r] = -INFINITY;
+        }
+    }
+    float mx = fmaxf(sacc[0][0], sacc[1][0]);
+#pragma unroll
+    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, fmaxf(sacc[0][r], sacc[1][r]));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float m_new = fmaxf(m_run, mx);
+    const float mc = m_new * c;
+    const float alpha = __builtin_amdgcn_exp2f(fmaf(m_run, c, -mc));
+    float psum = 0.f;
+    f16x8 pf[2][2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float pv = __builtin_amdgcn_exp2f(fmaf(sacc[u][r], c, -mc));
+        psum += pv;
+        pf[u][r >> 3][r & 7] = (f16)pv;
+      }
+    psum += __shfl_xor(psum, 32);
+    l_run = l_run * alpha + psum;
+    const float m_prev = m_run;
+    m_run = m_new;
+    if (__any(m_new != m_prev)) {
+#pragma unroll
+      for (int t = 0; t < DT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[t][r] *= alpha;
+    }
+    // ---- O^T += V^T P^T
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int t = 0; t < DT; ++t) {
+          const char* a0 = vt + (u * 32 + s * 16) * VRS + t * 64;
+          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0));
+          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0 + 8 * VRS));
+          const u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
+          const u32x4 vv = {l2[0], l2[1], h2[0], h2[1]};
+          oacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, vv), pf[u][s], oacc[t], 0, 0, 0);
+        }
+    __syncthreads();
+    if (kt + 1 < nkt) commit();
+    __syncthreads();
+  }
+
+  if (q_ok) {
+    const float inv = 1.f / l_run;
+    long long obase;
+    if (p.win > 0) {
+      const int ow = p.q_pool ? p.win / 2 : p.win, ogh = p.q_pool ? p.grid_h / 2 : p.grid_h, ogw = p.q_pool ? p.grid_w / 2 : p.grid_w;
+      obase = tok_off(b, qi, p.o_sb, p.o_st, ow, ogh, ogw);
+    } else {
+      obase = (long long)b * p.o_sb + (long long)qi * p.o_st;
+    }
+    obase += (long long)h * p.o_sh;
+#pragma unroll
+    for (int t = 0; t < DT; ++t)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d0 = t * 32 + 8 * g + 4 * lh;
+        if (d0 < p.dv) {
+          f16x4 ov;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) ov[e] = (f16)(oacc[t][4 * g + e] * inv);
+          *reinterpret_cast<f16x4*>(p.o + (obase + d0) * 2) = ov;
+        }
+      }
+  }
+}
+
+template <int DQKP, int DVP>
+int launch_attn64(const AttnArgs& a, hipStream_t stream) {
+  constexpr int KROW = DQKP * 2 + 16;
+  constexpr int VRS = DVP * 2 + (((DVP * 2) % 256 == 64 || (DVP * 2) % 256 == 192) ? 0 : 64);
+  constexpr size_t lds = (size_t)64 * (KROW + VRS);
+  const long long blocks = (long long)a.B * a.heads * ((a.qtiles + 3) / 4);
+  CVMI_CHECK(blocks > 0 && blocks < (1ll << 31), "attention: bad grid");
+  hipLaunchKernelGGL((attn64_kernel<DQKP, DVP>), dim3((unsigned)blocks), dim3(256), lds, stream, a);
+  CVMI_LAUNCH_CHECK();
+  return 0;
+}
+
 // ---- f32 parity kernel: one wave per query; lanes = keys for S, lanes = d for the PV sum ----------
 __global__ __launch_bounds__(256) void attn_f32_kernel(const AttnArgs p) {
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -415,7 +671,8 @@ int launch_f16(const AttnArgs& a, hipStream_t stream) {
 template <int DQKP, int DVP>
 int launch_f16_gs(const AttnArgs& a, hipStream_t stream) {
   // share K/V tiles across the workgroup when each (batch, head) has >= 4 query tiles
-  if (a.qtiles >= 4) return launch_f16<DQKP, DVP, 256>(a, stream);
+  static const int use64 = getenv("CVMI_ATTN64") ? atoi(getenv("CVMI_ATTN64")) : 1;      // tuning experiments only
+  if (a.qtiles >= 4) return use64 ? launch_attn64<DQKP, DVP>(a, stream) : launch_f16<DQKP, DVP, 256>(a, stream);
   return launch_f16<DQKP, DVP, 64>(a, stream);
 }
 
