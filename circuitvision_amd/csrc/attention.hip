@@ -328,8 +328,9 @@ __global__ __launch_bounds__(256) void attn_f16_kernel(const AttnArgs p) {
 // column-major), which removes the 8 scalar 2-byte LDS stores per staged chunk the transposed image needed.
 // V row stride: a 32-lane half reads 4 consecutive key rows x 64 bytes, conflict-free when (stride mod 256) is 64 or 192.
 typedef short s16x4 __attribute__((__vector_size__(4 * sizeof(short))));
-template <int DQKP, int DVP>
-__global__ __launch_bounds__(256, 2) void attn64_kernel(const AttnArgs p) {
+template <int DQKP, int DVP, int NW>
+__global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn64_kernel(const AttnArgs p) {
+  constexpr int NTH = NW * 64;                            // NW = 8: one K / V tile serves 256 queries
   constexpr int KROW = DQKP * 2 + 16;
   constexpr int VRS = DVP * 2 + (((DVP * 2) % 256 == 64 || (DVP * 2) % 256 == 192) ? 0 : 64);
   constexpr int KTILE = 64 * KROW;
@@ -340,9 +341,9 @@ __global__ __launch_bounds__(256, 2) void attn64_kernel(const AttnArgs p) {
 
   const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
   const int lr = lane & 31, lh = lane >> 5;
-  const int qgroups = (p.qtiles + 3) / 4;
+  const int qgroups = (p.qtiles + NW - 1) / NW;
   const int item = blockIdx.x / qgroups;                 // (b, h) of the workgroup
-  const int qt = (blockIdx.x - item * qgroups) * 4 + wv;
+  const int qt = (blockIdx.x - item * qgroups) * NW + wv;
   const bool live = qt < p.qtiles;
   const int b = item / p.heads, h = item - b * p.heads;
   const int qwin = p.q_pool ? p.win / 2 : p.win;
@@ -409,18 +410,17 @@ __global__ __launch_bounds__(256, 2) void attn64_kernel(const AttnArgs p) {
   const bool linear = p.win <= 0 || (64 % p.win) == 0;
   const int tile_pix = p.win <= 0 ? 64 : (64 / (p.win > 0 ? p.win : 1)) * p.grid_w;
   constexpr int KCH = DQKP / 8, VCH = DVP / 8;
-  constexpr int KN = 64 * KCH / 256, VN = 64 * VCH / 256;
-  static_assert(64 * KCH % 256 == 0 && 64 * VCH % 256 == 0, "tile chunks must divide over 256 threads");
+  constexpr int KN = (64 * KCH + NTH - 1) / NTH, VN = (64 * VCH + NTH - 1) / NTH;
   int koff0[KN], voff0[VN];
 #pragma unroll
   for (int i = 0; i < KN; ++i) {
-    const int idx = tid + i * 256, row = idx / KCH, ch = idx - row * KCH;
-    koff0[i] = key_pix(row) * kst + ch * 8;
+    const int idx = tid + i * NTH, row = idx / KCH, ch = idx - row * KCH;
+    koff0[i] = key_pix(row < 64 ? row : 0) * kst + ch * 8;
   }
 #pragma unroll
   for (int i = 0; i < VN; ++i) {
-    const int idx = tid + i * 256, row = idx / VCH, ch = idx - row * VCH;
-    voff0[i] = key_pix(row) * vst + ch * 8;
+    const int idx = tid + i * NTH, row = idx / VCH, ch = idx - row * VCH;
+    voff0[i] = key_pix(row < 64 ? row : 0) * vst + ch * 8;
   }
   u32x4 kreg[KN], vreg[VN];
   unsigned okmask = 0;                                    // bit i: K chunk i valid; bit 8 + i: V chunk i valid
@@ -428,18 +428,18 @@ __global__ __launch_bounds__(256, 2) void attn64_kernel(const AttnArgs p) {
     okmask = 0;
 #pragma unroll
     for (int i = 0; i < KN; ++i) {
-      const int idx = tid + i * 256, row = idx / KCH, ch = idx - row * KCH;
+      const int idx = tid + i * NTH, row = idx / KCH, ch = idx - row * KCH;
       const int key = kt * 64 + row;
-      const bool ok = key < p.Nk && ch * 8 < p.dqk;
+      const bool ok = idx < 64 * KCH && key < p.Nk && ch * 8 < p.dqk;
       const int off = linear ? koff0[i] + kt * tile_pix * kst : key_pix(key) * kst + ch * 8;
       kreg[i] = *reinterpret_cast<const u32x4*>(kbase + (long long)(ok ? off : 0) * 2);
       okmask |= ok ? 1u << i : 0u;
     }
 #pragma unroll
     for (int i = 0; i < VN; ++i) {
-      const int idx = tid + i * 256, row = idx / VCH, ch = idx - row * VCH;
+      const int idx = tid + i * NTH, row = idx / VCH, ch = idx - row * VCH;
       const int key = kt * 64 + row;
-      const bool ok = key < p.Nk && ch * 8 < p.dv;
+      const bool ok = idx < 64 * VCH && key < p.Nk && ch * 8 < p.dv;
       const int off = linear ? voff0[i] + kt * tile_pix * vst : key_pix(key) * vst + ch * 8;
       vreg[i] = *reinterpret_cast<const u32x4*>(vbase + (long long)(ok ? off : 0) * 2);
       okmask |= ok ? 1u << (8 + i) : 0u;
@@ -448,13 +448,13 @@ __global__ __launch_bounds__(256, 2) void attn64_kernel(const AttnArgs p) {
   auto commit = [&]() {
 #pragma unroll
     for (int i = 0; i < KN; ++i) {
-      const int idx = tid + i * 256, row = idx / KCH, ch = idx - row * KCH;
-      *reinterpret_cast<u32x4*>(Ks + row * KROW + ch * 16) = (okmask >> i) & 1u ? kreg[i] : u32x4{0u, 0u, 0u, 0u};
+      const int idx = tid + i * NTH, row = idx / KCH, ch = idx - row * KCH;
+      if (idx < 64 * KCH) *reinterpret_cast<u32x4*>(Ks + row * KROW + ch * 16) = (okmask >> i) & 1u ? kreg[i] : u32x4{0u, 0u, 0u, 0u};
     }
 #pragma unroll
     for (int i = 0; i < VN; ++i) {
-      const int idx = tid + i * 256, row = idx / VCH, ch = idx - row * VCH;
-      *reinterpret_cast<u32x4*>(Vs + row * VRS + ch * 16) = (okmask >> (8 + i)) & 1u ? vreg[i] : u32x4{0u, 0u, 0u, 0u};
+      const int idx = tid + i * NTH, row = idx / VCH, ch = idx - row * VCH;
+      if (idx < 64 * VCH) *reinterpret_cast<u32x4*>(Vs + row * VRS + ch * 16) = (okmask >> (8 + i)) & 1u ? vreg[i] : u32x4{0u, 0u, 0u, 0u};
     }
   };
   // V^T fragment gather: group g = lane / 16 holds d columns 16 (g & 1) .., keys 4 lh .. (the S^T accumulator's key order:
@@ -563,14 +563,14 @@ __global__ __launch_bounds__(256, 2) void attn64_kernel(const AttnArgs p) {
   }
 }
 
-template <int DQKP, int DVP>
+template <int DQKP, int DVP, int NW>
 int launch_attn64(const AttnArgs& a, hipStream_t stream) {
   constexpr int KROW = DQKP * 2 + 16;
   constexpr int VRS = DVP * 2 + (((DVP * 2) % 256 == 64 || (DVP * 2) % 256 == 192) ? 0 : 64);
   constexpr size_t lds = (size_t)64 * (KROW + VRS);
-  const long long blocks = (long long)a.B * a.heads * ((a.qtiles + 3) / 4);
+  const long long blocks = (long long)a.B * a.heads * ((a.qtiles + NW - 1) / NW);
   CVMI_CHECK(blocks > 0 && blocks < (1ll << 31), "attention: bad grid");
-  hipLaunchKernelGGL((attn64_kernel<DQKP, DVP>), dim3((unsigned)blocks), dim3(256), lds, stream, a);
+  hipLaunchKernelGGL((attn64_kernel<DQKP, DVP, NW>), dim3((unsigned)blocks), dim3(NW * 64), lds, stream, a);
   CVMI_LAUNCH_CHECK();
   return 0;
 }
@@ -671,8 +671,9 @@ int launch_f16(const AttnArgs& a, hipStream_t stream) {
 template <int DQKP, int DVP>
 int launch_f16_gs(const AttnArgs& a, hipStream_t stream) {
   // share K/V tiles across the workgroup when each (batch, head) has >= 4 query tiles
-  static const int use64 = getenv("CVMI_ATTN64") ? atoi(getenv("CVMI_ATTN64")) : 1;      // tuning experiments only
-  if (a.qtiles >= 4) return use64 ? launch_attn64<DQKP, DVP>(a, stream) : launch_f16<DQKP, DVP, 256>(a, stream);
+  static const int use64 = getenv("CVMI_ATTN64") ? atoi(getenv("CVMI_ATTN64")) : 2;      // tuning experiments only: 0 old, 1 four waves, 2 eight
+  if (a.qtiles >= 8 && use64 == 2) return launch_attn64<DQKP, DVP, 8>(a, stream);
+  if (a.qtiles >= 4) return use64 ? launch_attn64<DQKP, DVP, 4>(a, stream) : launch_f16<DQKP, DVP, 256>(a, stream);
   return launch_f16<DQKP, DVP, 64>(a, stream);
 }
 
