@@ -120,6 +120,23 @@ __device__ __forceinline__ void gemm_epilogue(const ConvKArgs& p, f32x16 (&acc)[
   const int lr = lane & 31, lh = lane >> 5;
   const int ohow = p.OH * p.OW;
   char* const Ct = smem;
+  // Residual prefetch (full-width tiles, no scatter): the tile's residual chunks are requested before the accumulators
+  // go through LDS, so their latency overlaps the transposition instead of being paid once per store-loop iteration
+  // (loads cannot be hoisted over the stores by the compiler: res and y may be the same buffer).
+  constexpr int NCH_ = BN / OVEC, NIT = (BM * NCH_) / NT;
+  const bool res_pf = p.res != nullptr && p.shuf_c == 0 && n0 + BN <= p.N && (BM * NCH_) % NT == 0 && NIT <= 16;
+  u32x4 rv[NIT > 0 && NIT <= 16 ? NIT : 1];
+  if (res_pf) {
+#pragma unroll
+    for (int it = 0; it < (NIT <= 16 ? NIT : 0); ++it) {
+      const int idx = tid + it * NT;
+      const int row = idx / NCH_, ch = idx - row * NCH_;
+      int m = m0 + row;
+      m = m < p.M ? m : p.M - 1;
+      const size_t rpix = p.res_mod > 0 ? (size_t)(m % p.res_mod) : (size_t)m;
+      rv[it] = *reinterpret_cast<const u32x4*>(p.res + (rpix * p.res_ld + n0 + ch * OVEC) * OES);
+    }
+  }
   with_act<FAST>(p.act_after_res ? CVMI_ACT_NONE : p.act, [&](auto actf) {
 #pragma unroll
     for (int i = 0; i < TN; ++i) {
@@ -147,6 +164,27 @@ __device__ __forceinline__ void gemm_epilogue(const ConvKArgs& p, f32x16 (&acc)[
   });
   __syncthreads();
   constexpr int NCH = BN / OVEC;                  // 16-byte chunks per output row
+  if (res_pf) {
+#pragma unroll
+    for (int it = 0; it < (NIT <= 16 ? NIT : 0); ++it) {
+      const int idx = tid + it * NT;
+      const int row = idx / NCH, ch = idx - row * NCH;
+      const int m = m0 + row;
+      if (m < p.M) {
+        float a[OVEC], r[OVEC];
+        unpack16<TO>(*reinterpret_cast<const u32x4*>(Ct + row * CROWB + ch * 16), a);
+        unpack16<TO>(rv[it], r);
+#pragma unroll
+        for (int e = 0; e < OVEC; ++e) a[e] += r[e];
+        if (p.act_after_res) {
+#pragma unroll
+          for (int e = 0; e < OVEC; ++e) a[e] = act_apply<FAST>(a[e], p.act);
+        }
+        *reinterpret_cast<u32x4*>(p.y + ((size_t)m * p.y_ld + n0 + ch * OVEC) * OES) = pack16<TO>(a);
+      }
+    }
+    return;
+  }
   for (int idx = tid; idx < BM * NCH; idx += NT) {
     const int row = idx / NCH, ch = idx - row * NCH;
     const int m = m0 + row, n = n0 + ch * OVEC;
