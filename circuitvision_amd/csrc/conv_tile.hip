@@ -294,9 +294,11 @@ int launch_tile_t(TileArgs& a, int B, int KS, int S, hipStream_t stream) {
 int cvmi_conv_tile_try(const cvmi_conv_desc* d, hipStream_t stream) {
   if (d->c1 != 0 || d->up0 != 0 || d->scalar_gather || d->out_f32 || d->res_mod || d->act_after_res || d->shuffle_cout) return -1;
   if (d->KH != d->KW || !((d->KH == 3 && (d->stride == 1 || d->stride == 2)) || (d->KH == 2 && d->stride == 1))) return -1;
-  // measured on YOLO11-n B=32: the tile kernel wins for short K (one or two channel chunks); deeper layers are
-  // MFMA-bound and the LDS-tiled GEMM pipeline of igemm.hip is the better fit
-  if (d->c0 > (d->stride == 1 ? 64 : 32) || d->N > 128) return -1;
+  // measured on YOLO11-n B=32: the tile kernel wins up to 128 input channels at stride 1 and 64 at stride 2; deeper
+  // layers are MFMA-bound and the LDS-tiled GEMM pipeline of igemm.hip is the better fit
+  static const int s2max = getenv("CVMI_TILE_S2MAX") ? atoi(getenv("CVMI_TILE_S2MAX")) : 64;       // tuning experiments only
+  static const int s1max = getenv("CVMI_TILE_S1MAX") ? atoi(getenv("CVMI_TILE_S1MAX")) : 128;
+  if (d->c0 > (d->stride == 1 ? s1max : s2max) || d->N > 128) return -1;
   const int es = d->dtype == CVMI_F16 ? 2 : 4;
   if (d->c0 % (16 / es) != 0) return -1;
   TileArgs a;
