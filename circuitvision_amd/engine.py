@@ -152,10 +152,9 @@ class Plan:
         """Issue the ops for capture: lane 0 on the plan's stream, other lanes on side streams between fork/join."""
         active = {}
         for (label, kind, thunk, _, _), lane in zip(self.ops, self.lanes):
-            if lane == -1:                                   # fork
-                self._fork_ev = torch.cuda.Event()
+            if lane == -1:                                   # fork point: lanes that START after it wait for it;
+                self._fork_ev = torch.cuda.Event()           # lanes forked earlier keep running until the join
                 self._fork_ev.record(self.stream)
-                active = {}
             elif lane == -2:                                 # join
                 for st in active.values():
                     ev = torch.cuda.Event()

@@ -328,13 +328,19 @@ class Yolo11Plan:
         p5 = self._c2psa("model.10", x, c, rep(2))
         # head
         h13 = self.c3k2("model.13", [(p5, 1), (p4, 0)], ch(512), rep(2), ca)
+        # Each Detect level is forked onto side lanes as soon as its feature map exists, so the long 80 x 80 chains run
+        # beside model.17 .. model.22 (small grids that leave most CUs idle) instead of after them.
+        self._det_boxes, self._det_cls = [], []
         h16 = self.c3k2("model.16", [(h13, 1), (p3, 0)], ch(256), rep(2), ca)
+        self._detect_level(0, h16)
         y = self.buf(H // 16, W // 16, ch(256)).view()
         self.cv("model.17", h16, y, 3, 2)
         h19 = self.c3k2("model.19", [(y, 0), (h13, 0)], ch(512), rep(2), ca)
+        self._detect_level(1, h19)
         y = self.buf(H // 32, W // 32, ch(512)).view()
         self.cv("model.20", h19, y, 3, 2)
         h22 = self.c3k2("model.22", [(y, 0), (p5, 0)], ch(1024), rep(2), True)
+        self._detect_level(2, h22)
         self.feats = (h16, h19, h22)
         self._detect([h16, h19, h22], with_nms)
 
@@ -374,35 +380,40 @@ class Yolo11Plan:
         self.cv(f"{name}.cv2", Y.view(), out)
         return out
 
+    def _detect_level(self, i, f):
+        """Detect branches of level i (box: 3x3, 3x3, 1x1; cls: dw3x3 + 1x1 twice, 1x1) on two side lanes."""
+        wt = self.wt
+        nc, c2, c3 = wt.nc, wt.det_c2, wt.det_c3
+        ncp = (nc + 7) // 8 * 8
+        self.plan.fork()
+        self.plan.lane(2 * i + 1)
+        t1 = self.buf(f.H, f.W, c2).view()
+        t2 = self.buf(f.H, f.W, c2).view()
+        bx = self.buf(f.H, f.W, 64).view()
+        self.cv(f"model.23.cv2.{i}.0", f, t1, 3, kind="head")
+        self.cv(f"model.23.cv2.{i}.1", t1, t2, 3, kind="head")
+        self.cv(f"model.23.cv2.{i}.2", t2, bx, act=ACT_NONE, kind="head")
+        self.plan.lane(2 * i + 2)
+        d1 = self.buf(f.H, f.W, f.c).view()
+        op_dwconv(self.plan, f"model.23.cv3.{i}.0.0", wt.packed[f"model.23.cv3.{i}.0.0"], f, d1, act=ACT_SILU)
+        u1 = self.buf(f.H, f.W, c3).view()
+        self.cv(f"model.23.cv3.{i}.0.1", d1, u1, kind="head")
+        d2 = self.buf(f.H, f.W, c3).view()
+        op_dwconv(self.plan, f"model.23.cv3.{i}.1.0", wt.packed[f"model.23.cv3.{i}.1.0"], u1, d2, act=ACT_SILU)
+        u2 = self.buf(f.H, f.W, c3).view()
+        self.cv(f"model.23.cv3.{i}.1.1", d2, u2, kind="head")
+        cl = Buf(self.B, f.H, f.W, ncp, self.dt, self.dev, zero=True)
+        self.act_bytes += cl.nbytes
+        self.cv(f"model.23.cv3.{i}.2", u2, cl.view(0, nc), act=ACT_NONE, kind="head")
+        self._det_boxes.append(bx)
+        self._det_cls.append(cl)
+        self.plan.lane(0)
+
     def _detect(self, feats, with_nms):
         import ctypes as C
         wt, lib = self.wt, _lib.load()
-        nc, c2, c3 = wt.nc, wt.det_c2, wt.det_c3
-        ncp = (nc + 7) // 8 * 8
-        boxes, clss = [], []
-        self.plan.fork()                       # 3 levels x {box, cls}: six independent chains
-        for i, f in enumerate(feats):
-            self.plan.lane(2 * i)
-            t1 = self.buf(f.H, f.W, c2).view()
-            t2 = self.buf(f.H, f.W, c2).view()
-            bx = self.buf(f.H, f.W, 64).view()
-            self.cv(f"model.23.cv2.{i}.0", f, t1, 3, kind="head")
-            self.cv(f"model.23.cv2.{i}.1", t1, t2, 3, kind="head")
-            self.cv(f"model.23.cv2.{i}.2", t2, bx, act=ACT_NONE, kind="head")
-            self.plan.lane(2 * i + 1)
-            d1 = self.buf(f.H, f.W, f.c).view()
-            op_dwconv(self.plan, f"model.23.cv3.{i}.0.0", wt.packed[f"model.23.cv3.{i}.0.0"], f, d1, act=ACT_SILU)
-            u1 = self.buf(f.H, f.W, c3).view()
-            self.cv(f"model.23.cv3.{i}.0.1", d1, u1, kind="head")
-            d2 = self.buf(f.H, f.W, c3).view()
-            op_dwconv(self.plan, f"model.23.cv3.{i}.1.0", wt.packed[f"model.23.cv3.{i}.1.0"], u1, d2, act=ACT_SILU)
-            u2 = self.buf(f.H, f.W, c3).view()
-            self.cv(f"model.23.cv3.{i}.1.1", d2, u2, kind="head")
-            cl = Buf(self.B, f.H, f.W, ncp, self.dt, self.dev, zero=True)
-            self.act_bytes += cl.nbytes
-            self.cv(f"model.23.cv3.{i}.2", u2, cl.view(0, nc), act=ACT_NONE, kind="head")
-            boxes.append(bx)
-            clss.append(cl)
+        nc = wt.nc
+        boxes, clss = self._det_boxes, self._det_cls
         self.plan.join()
         self.box_bufs, self.cls_bufs = boxes, clss
         A = sum(f.H * f.W for f in feats)
