@@ -733,6 +733,260 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(const ConvKArgs p) {
   }
 }
 
+// ---- 256 x 192 tile variant of gemm256_kernel (N = 576 = 3 x 192: Hiera-L stage-3 proj / fc2) -------------------------
+// 8 waves as 4 (pixel quarters) x 2 (channel halves; the two staggered groups), wave tile 64 px x 96 ch = 2 x 3 MFMA
+// tiles.  A K-tile is three phases of 8 MFMAs:  1: W c0, X p0 p1 -> (c0;p0,p1)   2: W c1 -> (c1;..)   3: W c2 -> (c2;..).
+// DMA units per K-tile (56 KiB): X0, X1 (128 pixel rows each, 2 instructions per lane), WC0, WC1, WC2 (the 32-row channel
+// block k of both halves, 1 instruction per lane), issued one phase after their region's last read:
+//     phase (t,1): WC2(t+1)      (t,2): X0(t+2), WC0(t+2)      (t,3): X1(t+2), WC1(t+2)
+// and one counted wait per K-tile, vmcnt(6) in phase 3 (all but the six instructions of phases 2 and 3, i.e. all of tile
+// t+1, has landed).  Hazard argument as for gemm256_kernel (reads retired before a phase's first barrier).
+template <typename TO>
+__global__ __launch_bounds__(512, 1) void gemm256x192_kernel(const ConvKArgs p) {
+  using T = f16;
+  constexpr int BM = 256, BN = 192, BKB = 128;
+  constexpr int STAGE = (BM + BN) * BKB;                  // 56 KiB
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  int wg = blockIdx.x;
+  {
+    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = wg & 7, j = wg >> 3;
+    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+  }
+  const int bn = wg % p.nb_n, bm = wg / p.nb_n;
+  const int m0 = bm * BM, n0 = bn * BN;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int wp = wv & 3, wh = wv >> 2;                    // pixel quarter, channel half (= stagger group; wv and wv + 4 share a SIMD)
+  const int lr = lane & 31, lh = lane >> 5;
+
+  // DMA: unit 0 X0, 1 X1 (pieces 2 wv, 2 wv + 1 of 16), 2..4 WC0..WC2 (piece wv of 8: half wv >> 2, 8-row group wv & 3)
+  const char* src[7];
+  int dst[7];
+#pragma unroll
+  for (int u = 0; u < 7; ++u) {
+    int row0;
+    if (u < 4) row0 = (u >> 1) * 128 + (wv * 2 + (u & 1)) * 8;                    // u = 0,1: X0; 2,3: X1
+    else row0 = BM + (wv >> 2) * 96 + (u - 4) * 32 + (wv & 3) * 8;               // u = 4,5,6: WC0..2
+    const int row = row0 + (lane >> 3);
+    const int slot = (lane & 7) ^ ((row >> 1) & 7);
+    if (row < BM) {
+      int m = m0 + row;
+      m = m < p.M ? m : p.M - 1;
+      src[u] = p.x0 + ((size_t)m * p.x0_ld + slot * 8) * 2;
+    } else {
+      int n = n0 + row - BM;
+      n = n < p.N ? n : p.N - 1;
+      src[u] = p.w + ((size_t)n * p.Kpad + slot * 8) * 2;
+    }
+    dst[u] = row0 * BKB;
+  }
+#define G192_ISSUE1(u, stage, kt)                                                                                        \
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[u] + (size_t)(kt) * BKB),         \
+                                   (__attribute__((address_space(3))) void*)(smem + (stage) * STAGE + dst[u]), 16, 0, 0)
+#define G192_X0(stage, kt) do { G192_ISSUE1(0, stage, kt); G192_ISSUE1(1, stage, kt); } while (0)
+#define G192_X1(stage, kt) do { G192_ISSUE1(2, stage, kt); G192_ISSUE1(3, stage, kt); } while (0)
+#define G192_WC(k, stage, kt) G192_ISSUE1(4 + (k), stage, kt)
+
+  f32x16 acc[3][2];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int sw = (lr >> 1) & 7;
+  int ko[4];
+#pragma unroll
+  for (int s2 = 0; s2 < 4; ++s2) ko[s2] = ((2 * s2 + lh) ^ sw) << 4;
+  const int xbase = (wp * 64 + lr) * BKB, wbase = (BM + wh * 96 + lr) * BKB;
+
+  const int nk = p.K / 64;
+  G192_X0(0, 0); G192_WC(0, 0, 0); G192_X1(0, 0); G192_WC(1, 0, 0); G192_WC(2, 0, 0);
+  if (nk > 1) {
+    G192_X0(1, 1); G192_WC(0, 1, 1); G192_X1(1, 1); G192_WC(1, 1, 1);
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __builtin_amdgcn_s_barrier();
+  if (wh == 1) __builtin_amdgcn_s_barrier();
+
+  u32x4 xf[2][4], wf[4];
+#define G192_READ_X(j)                                                                                                   \
+  _Pragma("unroll") for (int s2 = 0; s2 < 4; ++s2)                                                                       \
+      xf[j][s2] = *reinterpret_cast<const u32x4*>(st + xbase + (j) * 32 * BKB + ko[s2])
+#define G192_READ_W(i)                                                                                                   \
+  _Pragma("unroll") for (int s2 = 0; s2 < 4; ++s2)                                                                       \
+      wf[s2] = *reinterpret_cast<const u32x4*>(st + wbase + (i) * 32 * BKB + ko[s2])
+#define G192_SYNC_IN()                                                                                                   \
+  do {                                                                                                                   \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                   \
+    __builtin_amdgcn_sched_barrier(0);                                                                                   \
+    __builtin_amdgcn_s_barrier();                                                                                        \
+    __builtin_amdgcn_sched_barrier(0);                                                                                   \
+    __builtin_amdgcn_s_setprio(1);                                                                                       \
+  } while (0)
+#define G192_SYNC_OUT()                                                                                                  \
+  do {                                                                                                                   \
+    __builtin_amdgcn_s_setprio(0);                                                                                       \
+    __builtin_amdgcn_sched_barrier(0);                                                                                   \
+    __builtin_amdgcn_s_barrier();                                                                                        \
+    __builtin_amdgcn_sched_barrier(0);                                                                                   \
+  } while (0)
+#define G192_MMA(i)                                                                                                      \
+  asm volatile("" : "+v"(wf[0]), "+v"(wf[1]), "+v"(wf[2]), "+v"(wf[3]));                                                 \
+  _Pragma("unroll") for (int s2 = 0; s2 < 4; ++s2) {                                                                     \
+    Mma<T>::run(wf[s2], xf[0][s2], acc[i][0]);                                                                           \
+    Mma<T>::run(wf[s2], xf[1][s2], acc[i][1]);                                                                           \
+  }                                                                                                                      \
+  asm volatile("" : "+v"(acc[i][0]), "+v"(acc[i][1]))
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const int b = kt & 1;
+    const char* st = smem + b * STAGE;
+    const bool more1 = kt + 1 < nk, more2 = kt + 2 < nk;
+    // ---- phase 1
+    G192_READ_W(0);
+    G192_READ_X(0);
+    G192_READ_X(1);
+    if (more1) G192_WC(2, b ^ 1, kt + 1);
+    G192_SYNC_IN();
+    G192_MMA(0);
+    G192_SYNC_OUT();
+    // ---- phase 2
+    G192_READ_W(1);
+    if (more2) { G192_X0(b, kt + 2); G192_WC(0, b, kt + 2); }
+    G192_SYNC_IN();
+    G192_MMA(1);
+    G192_SYNC_OUT();
+    // ---- phase 3
+    G192_READ_W(2);
+    if (more2) {
+      G192_X1(b, kt + 2); G192_WC(1, b, kt + 2);
+      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    } else if (more1) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    G192_SYNC_IN();
+    G192_MMA(2);
+    G192_SYNC_OUT();
+  }
+  if (wh == 0) __builtin_amdgcn_s_barrier();
+#undef G192_ISSUE1
+#undef G192_X0
+#undef G192_X1
+#undef G192_WC
+#undef G192_READ_X
+#undef G192_READ_W
+#undef G192_SYNC_IN
+#undef G192_SYNC_OUT
+#undef G192_MMA
+
+  // ---- epilogue: bias + act -> LDS tile -> 16-byte stores (+ residual prefetched before the transposition);
+  //      f32 output goes in two 96-column passes (one per channel half)
+  constexpr int OES = sizeof(TO), OVEC = 16 / OES;
+  constexpr int NPASS = OES == 4 ? 2 : 1, CW = BN / NPASS;
+  constexpr int CROWB = CW * OES + 16;
+  constexpr int NCH = CW / OVEC;
+  constexpr int NIT = BM * NCH / 512;                     // 12 (both output types)
+  static_assert(BM * NCH % 512 == 0, "store loop must divide evenly");
+  char* const Ct = smem;
+#pragma unroll
+  for (int pass = 0; pass < NPASS; ++pass) {
+    const bool full = n0 + pass * CW + CW <= p.N;
+    u32x4 rv[NIT];
+    if (p.res && full) {
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int idx = tid + it * 512, row = idx / NCH, ch = idx - row * NCH;
+        int m = m0 + row;
+        m = m < p.M ? m : p.M - 1;
+        const size_t rpix = p.res_mod > 0 ? (size_t)(m % p.res_mod) : (size_t)m;
+        rv[it] = *reinterpret_cast<const u32x4*>(p.res + (rpix * p.res_ld + n0 + pass * CW + ch * OVEC) * OES);
+      }
+    }
+    if (NPASS == 1 || wh == pass) {
+      const int cbase = NPASS == 1 ? wh * 96 : 0;
+      with_act<true>(p.act_after_res ? CVMI_ACT_NONE : p.act, [&](auto actf) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int nl = cbase + i * 32 + 8 * q + 4 * lh;
+            const int n = n0 + pass * CW + nl;
+            f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+            if (n < p.N) bv = *reinterpret_cast<const f32x4*>(p.bias + n);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+              const int ml = wp * 64 + j * 32 + lr;
+              float v[4];
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = actf(acc[i][j][4 * q + e] + bv[e]);
+              char* d = Ct + ml * CROWB + nl * OES;
+              if constexpr (OES == 2) {
+                f16x4 hv = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
+                *reinterpret_cast<f16x4*>(d) = hv;
+              } else {
+                f32x4 fv = {v[0], v[1], v[2], v[3]};
+                *reinterpret_cast<f32x4*>(d) = fv;
+              }
+            }
+          }
+        }
+      });
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int idx = tid + it * 512, row = idx / NCH, ch = idx - row * NCH;
+      const int m = m0 + row, n = n0 + pass * CW + ch * OVEC;
+      if (m >= p.M || n >= p.N) continue;
+      u32x4 cv = *reinterpret_cast<const u32x4*>(Ct + row * CROWB + ch * 16);
+      if (p.res || p.act_after_res) {
+        float a[OVEC];
+        unpack16<TO>(cv, a);
+        if (p.res) {
+          float r[OVEC];
+          if (full) {
+            unpack16<TO>(rv[it], r);
+          } else {
+            const size_t rpix = p.res_mod > 0 ? (size_t)(m % p.res_mod) : (size_t)m;
+            unpack16<TO>(*reinterpret_cast<const u32x4*>(p.res + (rpix * p.res_ld + n) * OES), r);
+          }
+#pragma unroll
+          for (int e = 0; e < OVEC; ++e) a[e] += r[e];
+        }
+        if (p.act_after_res) {
+#pragma unroll
+          for (int e = 0; e < OVEC; ++e) a[e] = act_apply<true>(a[e], p.act);
+        }
+        cv = pack16<TO>(a);
+      }
+      *reinterpret_cast<u32x4*>(p.y + ((size_t)m * p.y_ld + n) * OES) = cv;
+    }
+    if (pass + 1 < NPASS) __syncthreads();
+  }
+}
+
+template <typename TO>
+int launch_g256x192(ConvKArgs& a, hipStream_t stream) {
+  constexpr int lds = 2 * (256 + 192) * 128;
+  constexpr int epi = 256 * ((sizeof(TO) == 4 ? 96 : 192) * (int)sizeof(TO) + 16);
+  constexpr int bytes = lds > epi ? lds : epi;
+  static bool attr_done = false;
+  if (!attr_done) {
+    CVMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256x192_kernel<TO>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    attr_done = true;
+  }
+  a.nb_n = cdiv(a.N, 192);
+  const long long blocks = (long long)cdiv(a.M, 256) * a.nb_n;
+  CVMI_CHECK(blocks > 0 && blocks < (1ll << 31), "conv2d: bad grid %lld", blocks);
+  hipLaunchKernelGGL((gemm256x192_kernel<TO>), dim3((unsigned)blocks), dim3(512), bytes, stream, a);
+  CVMI_LAUNCH_CHECK();
+  return 0;
+}
+
 template <typename TO>
 int launch_g256(ConvKArgs& a, hipStream_t stream, int stagger) {
   constexpr int lds = 2 * 512 * 128;                     // two stages; the epilogue tile (256 x 528 B) is larger: 135168
@@ -802,6 +1056,12 @@ int launch_typed(ConvKArgs& a, hipStream_t stream) {
       const long long tiles = (long long)cdiv(M, 256) * cdiv(N, 256);
       const double col_eff = (double)N / (cdiv(N, 256) * 256), wave_eff = (double)tiles / (double)(cdiv(tiles, 256) * 256);
       if (tiles >= 256 && ((col_eff >= 0.8 && wave_eff >= 0.8) || use_g256 >= 3)) return launch_g256<TO>(a, stream, use_g256 != 2);
+      // N a multiple of 192 that the 256-wide tiling wastes (576 = 3 x 192)
+      static const int use_g192 = getenv("CVMI_G192") ? atoi(getenv("CVMI_G192")) : 1;
+      const long long tiles192 = (long long)cdiv(M, 256) * cdiv(N, 192);
+      // (measured: K = 2304 309 -> 226 us; at K = 576 the 128 x 64 kernel's two workgroups per CU hide the f32 + residual epilogue better)
+      if (use_g192 && N % 192 == 0 && a.K >= 1024 && tiles192 >= 256 && (double)tiles192 / (double)(cdiv(tiles192, 256) * 256) >= 0.8)
+        return launch_g256x192<TO>(a, stream);
     }
   }
   if (use_glds && a.plain && (a.K * (int)sizeof(T)) % 128 == 0 && a.K * (int)sizeof(T) >= 256 && N >= 96 &&
