@@ -262,9 +262,8 @@ def test_graph_capture_replays_identically():
     (8192, 2048, 128 * 5, True, _lib.ACT_NONE),   # f32 output + residual: two-pass epilogue
     (25600, 1160, 320, True, _lib.ACT_NONE),      # ragged N (last column tile 136 / 256 valid), f32 + residual, 5 K-tiles
     (25600, 1160, 256, False, _lib.ACT_RELU),     # ragged N, f16 output
-    (65536, 576, 576, True, _lib.ACT_NONE),       # 256 x 192 tiles (N = 3 x 192): Hiera stage-3 proj, f32 + residual, 9 K-tiles
-    (65536, 384, 256, False, _lib.ACT_GELU),      # 256 x 192 tiles, f16 output, 4 K-tiles
-    (65536, 576, 64 * 6, True, _lib.ACT_NONE),    # 256 x 192 tiles, even number of K-tiles
+    (65536, 576, 1152, True, _lib.ACT_NONE),      # 256 x 192 tiles (N = 3 x 192, deep K): f32 + residual, 18 K-tiles
+    (65536, 384, 1088, False, _lib.ACT_GELU),     # 256 x 192 tiles, f16 output, odd number of K-tiles (17)
 ])
 def test_gemm_256_tile_counted_dma_pipeline(M, N, K, out_f32, act):
     """gemm256_kernel (8 waves, DMA in flight across barriers, staggered wave groups): values vs an fp32 matmul of the
