@@ -534,8 +534,9 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(const ConvKArgs p) {
   const int lr = lane & 31, lh = lane >> 5;
 
   // DMA sources / LDS destinations: half-tile h (0 XA, 1 WA, 2 WB, 3 XB) = 16 pieces of 8 rows, 2 per wave
+  const int nk = (p.K + 63) / 64, krem = p.K & 63;
   const char* src[4][2];
-  int dst[4][2];
+  int dst[4][2], adj[4][2];
 #pragma unroll
   for (int h = 0; h < 4; ++h)
 #pragma unroll
@@ -545,10 +546,15 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(const ConvKArgs p) {
                                           : BM + (q >> 2) * 64 + (h == 2 ? 32 : 0) + (q & 3) * 8;
       const int row = row0 + (lane >> 3);
       const int slot = (lane & 7) ^ ((row >> 1) & 7);
+      adj[h][i] = 0;
       if (row < BM) {
         int m = m0 + row;
         m = m < p.M ? m : p.M - 1;
         src[h][i] = p.x0 + ((size_t)m * p.x0_ld + slot * 8) * 2;
+        // K not a multiple of 64: in the LAST K-tile the chunks at columns >= K would leave the pixel row (and, for the
+        // last row, the tensor); they re-read the previous tile's chunk instead -- any finite value will do, the weight
+        // columns [K, Kpad) are zero
+        if (krem && slot * 8 >= krem) adj[h][i] = -BKB;
       } else {
         int n = n0 + row - BM;
         n = n < p.N ? n : p.N - 1;
@@ -558,9 +564,10 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(const ConvKArgs p) {
     }
 #define G256_ISSUE(h, stage, kt)                                                                                         \
   do {                                                                                                                   \
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[h][0] + (size_t)(kt) * BKB),   \
+    const long long last_ = (kt) == nk - 1 ? 1 : 0;                                                                      \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[h][0] + (long long)(kt) * BKB + last_ * adj[h][0]), \
                                      (__attribute__((address_space(3))) void*)(smem + (stage) * STAGE + dst[h][0]), 16, 0, 0); \
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[h][1] + (size_t)(kt) * BKB),   \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[h][1] + (long long)(kt) * BKB + last_ * adj[h][1]), \
                                      (__attribute__((address_space(3))) void*)(smem + (stage) * STAGE + dst[h][1]), 16, 0, 0); \
   } while (0)
 
@@ -579,7 +586,6 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(const ConvKArgs p) {
   for (int s2 = 0; s2 < 4; ++s2) ko[s2] = ((2 * s2 + lh) ^ sw) << 4;
   const int xbase = (wr * 128 + lr) * BKB, wbase = (BM + wc * 64 + lr) * BKB;
 
-  const int nk = p.K / 64;
   // prologue: all of tile 0, and XA WA WB of tile 1
   G256_ISSUE(0, 0, 0); G256_ISSUE(1, 0, 0); G256_ISSUE(2, 0, 0); G256_ISSUE(3, 0, 0);
   if (nk > 1) {
@@ -760,8 +766,9 @@ __global__ __launch_bounds__(512, 1) void gemm256x192_kernel(const ConvKArgs p) 
   const int lr = lane & 31, lh = lane >> 5;
 
   // DMA: unit 0 X0, 1 X1 (pieces 2 wv, 2 wv + 1 of 16), 2..4 WC0..WC2 (piece wv of 8: half wv >> 2, 8-row group wv & 3)
+  const int nk = (p.K + 63) / 64, krem = p.K & 63;
   const char* src[7];
-  int dst[7];
+  int dst[7], adj[7];
 #pragma unroll
   for (int u = 0; u < 7; ++u) {
     int row0;
@@ -769,10 +776,12 @@ __global__ __launch_bounds__(512, 1) void gemm256x192_kernel(const ConvKArgs p) 
     else row0 = BM + (wv >> 2) * 96 + (u - 4) * 32 + (wv & 3) * 8;               // u = 4,5,6: WC0..2
     const int row = row0 + (lane >> 3);
     const int slot = (lane & 7) ^ ((row >> 1) & 7);
+    adj[u] = 0;
     if (row < BM) {
       int m = m0 + row;
       m = m < p.M ? m : p.M - 1;
       src[u] = p.x0 + ((size_t)m * p.x0_ld + slot * 8) * 2;
+      if (krem && slot * 8 >= krem) adj[u] = -BKB;          // see gemm256_kernel
     } else {
       int n = n0 + row - BM;
       n = n < p.N ? n : p.N - 1;
@@ -781,7 +790,7 @@ __global__ __launch_bounds__(512, 1) void gemm256x192_kernel(const ConvKArgs p) 
     dst[u] = row0 * BKB;
   }
 #define G192_ISSUE1(u, stage, kt)                                                                                        \
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[u] + (size_t)(kt) * BKB),         \
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[u] + (long long)(kt) * BKB + ((kt) == nk - 1 ? (long long)adj[u] : 0ll)), \
                                    (__attribute__((address_space(3))) void*)(smem + (stage) * STAGE + dst[u]), 16, 0, 0)
 #define G192_X0(stage, kt) do { G192_ISSUE1(0, stage, kt); G192_ISSUE1(1, stage, kt); } while (0)
 #define G192_X1(stage, kt) do { G192_ISSUE1(2, stage, kt); G192_ISSUE1(3, stage, kt); } while (0)
@@ -801,7 +810,6 @@ __global__ __launch_bounds__(512, 1) void gemm256x192_kernel(const ConvKArgs p) 
   for (int s2 = 0; s2 < 4; ++s2) ko[s2] = ((2 * s2 + lh) ^ sw) << 4;
   const int xbase = (wp * 64 + lr) * BKB, wbase = (BM + wh * 96 + lr) * BKB;
 
-  const int nk = p.K / 64;
   G192_X0(0, 0); G192_WC(0, 0, 0); G192_X1(0, 0); G192_WC(1, 0, 0); G192_WC(2, 0, 0);
   if (nk > 1) {
     G192_X0(1, 1); G192_WC(0, 1, 1); G192_X1(1, 1); G192_WC(1, 1, 1);
@@ -1052,7 +1060,7 @@ int launch_typed(ConvKArgs& a, hipStream_t stream) {
     // big plain f16 GEMMs: >= one 256^2 tile per CU and little column-tile waste (N = 576 -> 3 tiles, 75 % used)
     // measured on Hiera-L shapes: wins when >= 80 % of the column tiles and of the last round of 256 tiles is used
     // (N = 576 -> 75 % of 3 column tiles: ties / loses against the 128-row kernels below)
-    if (use_g256 && a.plain && a.K % 64 == 0 && a.K >= 256 && N % 8 == 0 && N >= 512 && a.shuf_c == 0) {
+    if (use_g256 && a.plain && a.K % 8 == 0 && a.K >= 256 && a.Kpad % 64 == 0 && N % 8 == 0 && N >= 512 && a.shuf_c == 0) {
       const long long tiles = (long long)cdiv(M, 256) * cdiv(N, 256);
       const double col_eff = (double)N / (cdiv(N, 256) * 256), wave_eff = (double)tiles / (double)(cdiv(tiles, 256) * 256);
       if (tiles >= 256 && ((col_eff >= 0.8 && wave_eff >= 0.8) || use_g256 >= 3)) return launch_g256<TO>(a, stream, use_g256 != 2);
