@@ -1060,7 +1060,9 @@ int launch_typed(ConvKArgs& a, hipStream_t stream) {
     // big plain f16 GEMMs: >= one 256^2 tile per CU and little column-tile waste (N = 576 -> 3 tiles, 75 % used)
     // measured on Hiera-L shapes: wins when >= 80 % of the column tiles and of the last round of 256 tiles is used
     // (N = 576 -> 75 % of 3 column tiles: ties / loses against the 128-row kernels below)
-    if (use_g256 && a.plain && a.K % 8 == 0 && a.K >= 256 && a.Kpad % 64 == 0 && N % 8 == 0 && N >= 512 && a.shuf_c == 0) {
+    static const int g256_mink = getenv("CVMI_G256_MINK") ? atoi(getenv("CVMI_G256_MINK")) : 128;     // tuning experiments only
+    static const int g256_minn = getenv("CVMI_G256_MINN") ? atoi(getenv("CVMI_G256_MINN")) : 384;
+    if (use_g256 && a.plain && a.K % 8 == 0 && a.K >= g256_mink && a.Kpad % 64 == 0 && N % 8 == 0 && N >= g256_minn && a.shuf_c == 0) {
       const long long tiles = (long long)cdiv(M, 256) * cdiv(N, 256);
       const double col_eff = (double)N / (cdiv(N, 256) * 256), wave_eff = (double)tiles / (double)(cdiv(tiles, 256) * 256);
       if (tiles >= 256 && ((col_eff >= 0.8 && wave_eff >= 0.8) || use_g256 >= 3)) return launch_g256<TO>(a, stream, use_g256 != 2);
@@ -1068,7 +1070,8 @@ int launch_typed(ConvKArgs& a, hipStream_t stream) {
       static const int use_g192 = getenv("CVMI_G192") ? atoi(getenv("CVMI_G192")) : 1;
       const long long tiles192 = (long long)cdiv(M, 256) * cdiv(N, 192);
       // (measured: K = 2304 309 -> 226 us; at K = 576 the 128 x 64 kernel's two workgroups per CU hide the f32 + residual epilogue better)
-      if (use_g192 && N % 192 == 0 && a.K >= 1024 && tiles192 >= 256 && (double)tiles192 / (double)(cdiv(tiles192, 256) * 256) >= 0.8)
+      static const int g192_mink = getenv("CVMI_G192_MINK") ? atoi(getenv("CVMI_G192_MINK")) : 1024;   // tuning experiments only
+      if (use_g192 && N % 192 == 0 && a.K >= g192_mink && tiles192 >= 256 && (double)tiles192 / (double)(cdiv(tiles192, 256) * 256) >= 0.8)
         return launch_g256x192<TO>(a, stream);
     }
   }
