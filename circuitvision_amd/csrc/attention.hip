@@ -575,6 +575,137 @@ int launch_attn64(const AttnArgs& a, hipStream_t stream) {
   return 0;
 }
 
+// ---- 16-token windows (Hiera stage 2, and the q-pooled stage 2 -> 3 transition): VALU kernel ----------------------------
+// A 4 x 4 window gives the MFMA kernels 16 keys x 16 (or 4 pooled) queries per 32 x 32 tile: >= 75 % padding, and the
+// per-item cost (window addressing, staging, barriers) dominates -- 22 TFLOP/s.  The arithmetic is tiny (37 kMAC per
+// window-head), so here ONE THREAD owns one (window, head, query): its q row lives in registers, the item's K and V rows
+// are staged in LDS (a wave serves 4 items, all lanes load), scores are 36 v_dot2_f32_f16 per key, the softmax is a
+// two-pass over 16 registers, and the output row accumulates in 72 fp32 registers.  No cross-lane traffic at all.
+template <int NQ, int DCH>                                  // NQ queries per item (16, or 4 when q-pooled); DCH = head_dim / 8
+__global__ __launch_bounds__(128) void attn_win16_kernel(const AttnArgs p) {
+  constexpr int NK = 16, IPW = 4, D = DCH * 8, ROW = D * 2;        // row bytes (unpadded: every read is a broadcast)
+  constexpr int ITEM_B = NK * ROW;
+  __shared__ __attribute__((aligned(16))) char lds[2 * 2 * IPW * ITEM_B];          // 2 waves x (K, V) x 4 items x 2304 B = 36 KiB
+  const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+  char* const Kl = lds + wv * 2 * IPW * ITEM_B;
+  char* const Vl = Kl + IPW * ITEM_B;
+  const int nitems = p.B * p.heads;
+  const int item0 = (blockIdx.x * 2 + wv) * IPW;                   // first item of this wave
+  // ---- per-lane item for the compute phase: lane = ti * NQ + tq, ti < IPW
+  const int ti = lane / NQ, tq = lane - ti * NQ;
+  const bool active = ti < IPW && item0 + ti < nitems;
+  const int my_item = item0 + (ti < IPW ? ti : 0);
+  const int itc = my_item < nitems ? my_item : nitems - 1;
+  const int b = itc / p.heads, h = itc - b * p.heads;
+  const long long pix0 = tok_off(b, 0, 1, 1, p.win, p.grid_h, p.grid_w);        // window origin (pixels) of my item
+  // ---- stage K and V of the wave's 4 items: chunk id -> (item, key, 16-byte chunk); origins come from the lane that owns the item
+  constexpr int NCHUNK = IPW * NK * DCH, NLD = (NCHUNK + 63) / 64;
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+    u32x4 r[NLD];
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int id = lane + i * 64;
+      const int ci = id / (NK * DCH), rem = id - ci * (NK * DCH);
+      const int key = rem / DCH, ch = rem - key * DCH;
+      const long long o0 = __shfl(pix0, (ci < IPW ? ci : 0) * NQ);
+      const int hh = __shfl(h, (ci < IPW ? ci : 0) * NQ);
+      const bool ok = id < NCHUNK && item0 + ci < nitems;
+      const int ky = key >> 2, kx = key & 3;                          // 4 x 4 window
+      const long long st = m == 0 ? p.k_st : p.v_st, sh = m == 0 ? p.k_sh : p.v_sh;
+      const long long off = (o0 + (long long)ky * p.grid_w + kx) * st + (long long)hh * sh + ch * 8;
+      const char* base = m == 0 ? p.k : p.v;
+      r[i] = *reinterpret_cast<const u32x4*>(base + (ok ? off : 0) * 2);
+    }
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int id = lane + i * 64;
+      if (id < NCHUNK) *reinterpret_cast<u32x4*>((m == 0 ? Kl : Vl) + id * 16) = r[i];
+    }
+  }
+  // ---- my query row (2 x 2 max-pool of the projected q tokens when q_pool)
+  u32x4 qv[DCH];
+  {
+    const int qw = p.q_pool ? 2 : 4;                                  // query grid inside the window
+    const int py = tq / qw, px = tq - py * qw;
+#pragma unroll
+    for (int c = 0; c < DCH; ++c) {
+      if (!p.q_pool) {
+        const long long off = (pix0 + (long long)py * p.grid_w + px) * p.q_st + (long long)h * p.q_sh + c * 8;
+        qv[c] = *reinterpret_cast<const u32x4*>(p.q + (active ? off : 0) * 2);
+      } else {
+        f16x8 m;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) m[e] = (f16)(-65504.f);
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+          for (int dx = 0; dx < 2; ++dx) {
+            const long long off = (pix0 + (long long)(2 * py + dy) * p.grid_w + 2 * px + dx) * p.q_st + (long long)h * p.q_sh + c * 8;
+            const f16x8 x = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(p.q + (active ? off : 0) * 2));
+#pragma unroll
+            for (int e = 0; e < 8; ++e) m[e] = x[e] > m[e] ? x[e] : m[e];
+          }
+        qv[c] = __builtin_bit_cast(u32x4, m);
+      }
+    }
+  }
+  __syncthreads();
+  typedef f16 f16x2 __attribute__((ext_vector_type(2)));
+  const char* const kr = Kl + (ti < IPW ? ti : 0) * ITEM_B;
+  const char* const vr = Vl + (ti < IPW ? ti : 0) * ITEM_B;
+  // ---- scores
+  float sc[NK];
+  const float c2 = p.scale * 1.44269504088896340736f;
+  float mx = -INFINITY;
+#pragma unroll
+  for (int k = 0; k < NK; ++k) {
+    float acc = 0.f;
+#pragma unroll
+    for (int c = 0; c < DCH; ++c) {
+      const f16x8 kh = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(kr + k * ROW + c * 16));
+      const f16x8 qh = __builtin_bit_cast(f16x8, qv[c]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const f16x2 a2 = {qh[2 * e], qh[2 * e + 1]}, b2 = {kh[2 * e], kh[2 * e + 1]};
+        acc = __builtin_amdgcn_fdot2(a2, b2, acc, false);
+      }
+    }
+    sc[k] = acc * c2;
+    mx = fmaxf(mx, sc[k]);
+  }
+  float l = 0.f;
+#pragma unroll
+  for (int k = 0; k < NK; ++k) { sc[k] = __builtin_amdgcn_exp2f(sc[k] - mx); l += sc[k]; }
+  // P is rounded to fp16 before the PV product, as the MFMA kernels (and a torch fp16 pipeline) do
+  // ---- output row
+  float o[D];
+#pragma unroll
+  for (int d = 0; d < D; ++d) o[d] = 0.f;
+#pragma unroll
+  for (int k = 0; k < NK; ++k) {
+    const float pk = (float)(f16)sc[k];
+#pragma unroll
+    for (int c = 0; c < DCH; ++c) {
+      const f16x8 vv = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(vr + k * ROW + c * 16));
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[c * 8 + e] = fmaf(pk, (float)vv[e], o[c * 8 + e]);
+    }
+  }
+  if (active) {
+    const float inv = 1.f / l;
+    const int ow = p.q_pool ? 2 : 4, ogw = p.q_pool ? p.grid_w / 2 : p.grid_w, ogh = p.q_pool ? p.grid_h / 2 : p.grid_h;
+    const long long obase = tok_off(b, tq, p.o_sb, p.o_st, ow, ogh, ogw) + (long long)h * p.o_sh;
+#pragma unroll
+    for (int c = 0; c < DCH; ++c) {
+      f16x8 ov;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) ov[e] = (f16)(o[c * 8 + e] * inv);
+      *reinterpret_cast<u32x4*>(p.o + (obase + c * 8) * 2) = __builtin_bit_cast(u32x4, ov);
+    }
+  }
+}
+
 // ---- f32 parity kernel: one wave per query; lanes = keys for S, lanes = d for the PV sum ----------
 __global__ __launch_bounds__(256) void attn_f32_kernel(const AttnArgs p) {
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -717,6 +848,17 @@ extern "C" int cvmi_attention(const cvmi_attn_desc* d, cvmi_stream_t stream_) {
   CVMI_CHECK(d->q_st % 8 == 0 && d->k_st % 8 == 0 && d->v_st % 8 == 0 && d->q_sh % 8 == 0 && d->k_sh % 8 == 0 && d->v_sh % 8 == 0 &&
              d->q_sb % 8 == 0 && d->k_sb % 8 == 0 && d->v_sb % 8 == 0, "attention(f16): q/k/v strides must be multiples of 8 elements");
   CVMI_CHECK((((uintptr_t)d->q | (uintptr_t)d->k | (uintptr_t)d->v) & 15) == 0 && ((uintptr_t)d->o & 7) == 0, "attention(f16): misaligned pointer");
+  // 4 x 4 windows of Hiera's head_dim 72: the per-thread VALU kernel
+  static const int use_win16 = getenv("CVMI_ATTN_WIN16") ? atoi(getenv("CVMI_ATTN_WIN16")) : 1;           // tuning experiments only
+  if (use_win16 && d->win == 4 && d->Nk == 16 && d->dqk == 72 && d->dv == 72 && (d->Nq == 16 || (d->q_pool && d->Nq == 4)) &&
+      ((uintptr_t)d->o & 15) == 0 && d->o_st % 8 == 0 && d->o_sh % 8 == 0) {
+    const long long items = (long long)d->B * d->heads;
+    const unsigned blocks = (unsigned)((items + 7) / 8);
+    if (d->Nq == 16) hipLaunchKernelGGL((attn_win16_kernel<16, 9>), dim3(blocks), dim3(128), 0, stream, a);
+    else hipLaunchKernelGGL((attn_win16_kernel<4, 9>), dim3(blocks), dim3(128), 0, stream, a);
+    CVMI_LAUNCH_CHECK();
+    return 0;
+  }
   if (d->dqk <= 32 && d->dv <= 32) return launch_f16_gs<32, 32>(a, stream);
   if (d->dqk <= 32 && d->dv <= 64) return launch_f16_gs<32, 64>(a, stream);
   if (d->dqk <= 64 && d->dv <= 64) return launch_f16_gs<64, 64>(a, stream);

@@ -200,12 +200,14 @@ def test_attention(dtype, shape):
 
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("q_pool", [0, 1])
-def test_attention_window_mode(dtype, q_pool):
-    """Hiera windowed attention straight off the NHWC token grid (+ 2x2 q max-pool)."""
+@pytest.mark.parametrize("win", [8, 4, 16])
+def test_attention_window_mode(dtype, q_pool, win):
+    """Hiera windowed attention straight off the NHWC token grid (+ 2x2 q max-pool).  win = 4 takes the per-thread
+    16-token kernel (fp16), win = 16 the 64-key-tile kernel, win = 8 the per-wave-tile kernel."""
     from circuitvision_amd.engine import TORCH_DTYPE
     td = TORCH_DTYPE[dtype]
     g = torch.Generator().manual_seed(13)
-    imgs, gh, gw, win, heads, hd = 2, 16, 24, 8, 2, 72
+    imgs, gh, gw, heads, hd = 2, 16, 48 if win == 16 else 24, 3 if win == 4 else 2, 72
     C_ = heads * hd
     qkv = quant(torch.randn(imgs, gh, gw, 3 * C_, generator=g), dtype)
     # reference: partition windows
