@@ -485,3 +485,36 @@ def test_wrapper_graph_replay_with_new_images():
         torch.testing.assert_close(lo.cpu(), rlo, rtol=1e-3, atol=1e-3)
         torch.testing.assert_close(iou.cpu(), riou, rtol=1e-3, atol=1e-3)
         torch.testing.assert_close(hi.cpu(), rhi, rtol=1e-3, atol=1e-3)
+
+
+def test_sam2_hiera_l_baseline_size_permutation_and_replay_properties():
+    """BASELINE configs[2] at full size (SAM 2.1 Hiera-L, 16 x 1024 x 1024, fp16 / f32 streams, captured graph):
+    permuting the batch permutes every output bit-exactly (per-image independence of every kernel, including the
+    counted-DMA GEMMs, the 64-key-tile / 16-token-window attention kernels and the stability counters); replays are
+    bit-identical; all outputs finite; iou predictions inside (0, 1)."""
+    from circuitvision_amd.sam2 import HIERA_L, LORA_TARGETS_REFERENCE, Sam2Plan, Sam2Weights, SamSyntheticParams
+    from synth import circuit_image
+    lib = _lib.load()
+    B = 16
+    wt = Sam2Weights(SamSyntheticParams(seed=0, lora_targets=LORA_TARGETS_REFERENCE), HIERA_L, 1024, F16)
+    st = torch.cuda.Stream()
+    sp = Sam2Plan(wt, B, st)
+    xs = torch.empty(B, 1024, 1024, 3, dtype=torch.float16, device="cuda")
+    for b in range(B):
+        img = torch.from_numpy(circuit_image(600 + 20 * b, 800, seed=40 + b)).cuda()
+        _lib.check(lib.cvmi_sam2_transform(img.data_ptr(), img.shape[0], img.shape[1], xs[b].data_ptr(), 1024, F16, None), "transform")
+    torch.cuda.synchronize()
+    perm = torch.randperm(B, generator=torch.Generator().manual_seed(5)).cuda()
+    outs = []
+    for inp in (xs, xs[perm], xs):
+        sp.x_in.t.copy_(inp)
+        torch.cuda.synchronize()
+        sp.plan.run()
+        torch.cuda.synchronize()
+        outs.append((sp.low_res.clone(), sp.iou.clone(), sp.high_res.clone(), sp.sel.clone()))
+    (l0, i0, h0, s0), (l1, i1, h1, s1), (l2, i2, h2, s2) = outs
+    assert torch.equal(l0, l2) and torch.equal(i0, i2) and torch.equal(h0, h2)
+    assert torch.equal(l0[perm], l1) and torch.equal(i0[perm], i1) and torch.equal(h0[perm], h1) and torch.equal(s0[perm], s1)
+    assert torch.isfinite(l0).all() and torch.isfinite(h0).all()
+    assert float(i0.min()) > 0.0 and float(i0.max()) < 1.0
+    assert float((l0[0] - l0[1]).abs().max()) > 1e-3               # different images do give different masks

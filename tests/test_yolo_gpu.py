@@ -221,3 +221,44 @@ def test_c3k2_fused_blocks_match_unfused_launch_chain(hw):
         torch.testing.assert_close(a, b_, rtol=4e-3, atol=4e-3)
     torch.testing.assert_close(outs[0][1][:, 4:], outs[1][1][:, 4:], rtol=0, atol=4e-3)
     torch.testing.assert_close(outs[0][1][:, :4], outs[1][1][:, :4], rtol=4e-3, atol=0.25)
+
+
+def test_yolo11n_baseline_size_permutation_and_replay_properties():
+    """BASELINE configs[1] at full size (YOLO11-n, 32 x 640 x 640, fp16, captured graph): size-independent properties.
+    (1) permuting the images of the batch permutes every output bit-exactly (no cross-image coupling anywhere, incl. the
+    fused blocks' tile scheduling and the side-lane head); (2) graph replays are bit-identical; (3) NMS is idempotent:
+    re-running the oracle NMS on the kept detections keeps all of them."""
+    nc, B, H, W = 62, 32, 640, 640
+    params = SyntheticParams(seed=21, nc=nc)
+    wt = Yolo11Weights("n", nc, params, F16)
+    imgs = np.stack([circuit_image(H, W, seed=500 + i) for i in range(B)])
+    x = torch.from_numpy(imgs).permute(0, 3, 1, 2).float().div(255)
+    perm = torch.randperm(B, generator=torch.Generator().manual_seed(3))
+    plan = Yolo11Plan(wt, B, H, W, torch.cuda.Stream(), conf=0.05)          # random weights: lower the threshold so that NMS has work
+    outs = []
+    for inp in (x, x[perm], x):
+        plan.set_input_nchw(inp)
+        torch.cuda.synchronize()
+        plan.plan.run()
+        torch.cuda.synchronize()
+        outs.append((plan.pred.clone(), plan.det.clone(), plan.det_count.clone(), [f.tensor().clone() for f in plan.feats]))
+    (p0, d0, c0, f0), (p1, d1, c1, f1), (p2, d2, c2, f2) = outs
+    assert torch.equal(p0, p2) and torch.equal(d0, d2) and torch.equal(c0, c2)                     # replay
+    assert torch.equal(p0[perm], p1) and torch.equal(c0[perm], c1) and torch.equal(d0[perm], d1)   # permutation
+    for a, b_ in zip(f0, f1):
+        assert torch.equal(a[perm], b_)
+    assert torch.isfinite(p0).all()
+    # (3) NMS at the full 32 x (4 + 62) x 8400 size on the stress tensor (random weights give no confident boxes):
+    # permutation-equivariant, and idempotent -- the kept boxes of an image survive a second NMS unchanged
+    pred = nms_stress_pred(B, nc, (H, W), seed=9)
+    det, idx, cnt = _gpu_nms(pred)
+    detp, idxp, cntp = _gpu_nms(pred[perm])
+    assert torch.equal(cnt[perm], cntp) and torch.equal(det[perm], detp) and torch.equal(idx[perm], idxp)
+    assert int(cnt.min()) > 0
+    for b in range(0, B, 5):
+        n = int(cnt[b])
+        d = det[b, :n]
+        ref_det, ref_idx = onms.yolo_nms(pred[b:b + 1], 0.25, 0.7, 300, return_indices=True)
+        assert torch.equal(d, ref_det[0]) and torch.equal(idx[b, :n].long(), ref_idx[0])
+        keep = onms.torchvision_nms(d[:, :4] + d[:, 5:6] * 7680.0, d[:, 4], 0.7)
+        assert len(keep) == n
