@@ -13,13 +13,14 @@ __device__ __forceinline__ float wave_sum(float v) {
 
 // ---- LayerNorm: a row is shared by G lanes (G = 4..64, chosen so that C/VEC chunks fill G * NCH slots tightly),
 //      64/G rows per wave; the row stays in registers between the mean and the variance pass.
-template <typename TI, typename TO, int NCH>
+template <typename TI, typename TO, int NCH, int WD>
 __global__ __launch_bounds__(256) void layernorm_kernel(const TI* __restrict__ x, int x_ld, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, TO* __restrict__ y, int y_ld, long long rows, int C,
                                                        float eps, int act, int G, int pw, int pwp, int phw, int phpwp) {
   // pw > 0: rows are pixels of [*, H, W] images (phw = H*W, pw = W) and are written into a zero-padded
   // [*, Hp, Wp] grid (phpwp = Hp*Wp, pwp = Wp) -- Hiera's pad-to-window-multiple, applied after the norm
-  constexpr int VI = Elem<TI>::VEC;
+  // WD = 16-byte input chunks per slot: 2 for f32 -> f16, so that a slot's 8 outputs leave as ONE 16-byte store
+  constexpr int VI = Elem<TI>::VEC, SV = VI * WD;
   const int lane = threadIdx.x & 63;
   const int rpw = 64 / G;
   const long long row_raw = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * rpw + lane / G;
@@ -27,15 +28,16 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const TI* __restrict__ x
   const long long row = row_ok ? row_raw : rows - 1;
   const int g = lane % G;
   const TI* xr = x + row * x_ld;
-  float v[NCH][VI];
+  float v[NCH][SV];
   float s = 0.f;
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
-    const int c = (i * G + g) * VI;
+    const int c = (i * G + g) * SV;
     if (c < C) {
-      unpack16<TI>(*reinterpret_cast<const u32x4*>(xr + c), v[i]);
 #pragma unroll
-      for (int e = 0; e < VI; ++e) s += v[i][e];
+      for (int w = 0; w < WD; ++w) unpack16<TI>(*reinterpret_cast<const u32x4*>(xr + c + w * VI), v[i] + w * VI);
+#pragma unroll
+      for (int e = 0; e < SV; ++e) s += v[i][e];
     }
   }
   for (int off = G >> 1; off > 0; off >>= 1) s += __shfl_xor(s, off);
@@ -43,10 +45,10 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const TI* __restrict__ x
   float q = 0.f;
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
-    const int c = (i * G + g) * VI;
+    const int c = (i * G + g) * SV;
     if (c < C) {
 #pragma unroll
-      for (int e = 0; e < VI; ++e) { const float d = v[i][e] - mean; q += d * d; }
+      for (int e = 0; e < SV; ++e) { const float d = v[i][e] - mean; q += d * d; }
     }
   }
   for (int off = G >> 1; off > 0; off >>= 1) q += __shfl_xor(q, off);
@@ -61,24 +63,21 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const TI* __restrict__ x
   TO* yr = y + orow * y_ld;
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
-    const int c = (i * G + g) * VI;
+    const int c = (i * G + g) * SV;
     if (c < C) {
-      struct alignas(sizeof(TO) * VI) Pack { TO v[VI]; } pk;
-      float gm[VI], bt[VI];
-      if constexpr (VI == 4) {
-        *reinterpret_cast<f32x4*>(gm) = *reinterpret_cast<const f32x4*>(gamma + c);
-        *reinterpret_cast<f32x4*>(bt) = *reinterpret_cast<const f32x4*>(beta + c);
+      struct alignas(sizeof(TO) * SV > 16 ? 16 : sizeof(TO) * SV) Pack { TO v[SV]; } pk;
+      float gm[SV], bt[SV];
+#pragma unroll
+      for (int h = 0; h < SV / 4; ++h) {
+        *reinterpret_cast<f32x4*>(gm + 4 * h) = *reinterpret_cast<const f32x4*>(gamma + c + 4 * h);
+        *reinterpret_cast<f32x4*>(bt + 4 * h) = *reinterpret_cast<const f32x4*>(beta + c + 4 * h);
+      }
+      if (act == CVMI_ACT_NONE) {                       // wave-uniform: no per-element activation switch on the common path
+#pragma unroll
+        for (int e = 0; e < SV; ++e) pk.v[e] = (TO)((v[i][e] - mean) * rstd * gm[e] + bt[e]);
       } else {
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          *reinterpret_cast<f32x4*>(gm + 4 * h) = *reinterpret_cast<const f32x4*>(gamma + c + 4 * h);
-          *reinterpret_cast<f32x4*>(bt + 4 * h) = *reinterpret_cast<const f32x4*>(beta + c + 4 * h);
-        }
-      }
-#pragma unroll
-      for (int e = 0; e < VI; ++e) {
-        const float o = (v[i][e] - mean) * rstd * gm[e] + bt[e];
-        pk.v[e] = (TO)act_apply<false>(o, act);
+        for (int e = 0; e < SV; ++e) pk.v[e] = (TO)act_apply<false>((v[i][e] - mean) * rstd * gm[e] + bt[e], act);
       }
       *reinterpret_cast<Pack*>(yr + c) = pk;
     }
@@ -465,12 +464,15 @@ template <typename TI, typename TO>
 int launch_ln(const void* x, int x_ld, const float* gamma, const float* beta, void* y, int y_ld, long long rows, int C, float eps, int act,
               int pw, int pwp, int phw, int phpwp, hipStream_t stream) {
   constexpr int VI = Elem<TI>::VEC;
-  const int chunks = C / VI;
-  // lanes per row: the tightest fit of `chunks` into G * NCH slots with NCH in {1,2,3,5,8}
-  int bestG = 64, bestN = 8, bestWaste = 1 << 30;
-  const int ncand[5] = {1, 2, 3, 5, 8};
+  // f32 -> f16 with C a multiple of 8: slots of 8 channels (two 16-byte loads, one 16-byte store)
+  constexpr bool CAN_WIDE = sizeof(TI) == 4 && sizeof(TO) == 2;
+  const bool wide = CAN_WIDE && C % 8 == 0 && y_ld % 8 == 0;
+  const int chunks = C / (wide ? 2 * VI : VI);
+  // lanes per row: the tightest fit of `chunks` into G * NCH slots with NCH in {1,2,3,5,8,9}
+  int bestG = 64, bestN = 9, bestWaste = 1 << 30;
+  const int ncand[6] = {1, 2, 3, 5, 8, 9};
   for (int G = 4; G <= 64; G <<= 1)
-    for (int k = 0; k < 5; ++k) {
+    for (int k = 0; k < 6; ++k) {
       const int n = ncand[k];
       if (G * n < chunks) continue;
       const int waste = G * n - chunks;
@@ -480,14 +482,22 @@ int launch_ln(const void* x, int x_ld, const float* gamma, const float* beta, vo
   CVMI_CHECK(bestG * bestN >= chunks, "layernorm: C=%d too wide", C);
   const int rpw = 64 / bestG;
   const dim3 g((unsigned)((rows + 4 * rpw - 1) / (4 * rpw))), b(256);
-#define CVMI_LN(N) hipLaunchKernelGGL((layernorm_kernel<TI, TO, N>), g, b, 0, stream, (const TI*)x, x_ld, gamma, beta, (TO*)y, y_ld, rows, C, eps, act, bestG, pw, pwp, phw, phpwp)
-  switch (bestN) {
-    case 1: CVMI_LN(1); break;
-    case 2: CVMI_LN(2); break;
-    case 3: CVMI_LN(3); break;
-    case 5: CVMI_LN(5); break;
-    default: CVMI_LN(8); break;
+#define CVMI_LN(N, W) hipLaunchKernelGGL((layernorm_kernel<TI, TO, N, W>), g, b, 0, stream, (const TI*)x, x_ld, gamma, beta, (TO*)y, y_ld, rows, C, eps, act, bestG, pw, pwp, phw, phpwp)
+#define CVMI_LN_SW(W)                                                                                                    \
+  switch (bestN) {                                                                                                       \
+    case 1: CVMI_LN(1, W); break;                                                                                        \
+    case 2: CVMI_LN(2, W); break;                                                                                        \
+    case 3: CVMI_LN(3, W); break;                                                                                        \
+    case 5: CVMI_LN(5, W); break;                                                                                        \
+    case 8: CVMI_LN(8, W); break;                                                                                        \
+    default: CVMI_LN(9, W); break;                                                                                       \
   }
+  if constexpr (CAN_WIDE) {
+    if (wide) { CVMI_LN_SW(2) } else { CVMI_LN_SW(1) }
+  } else {
+    CVMI_LN_SW(1)
+  }
+#undef CVMI_LN_SW
 #undef CVMI_LN
   CVMI_LAUNCH_CHECK();
   return 0;
