@@ -303,6 +303,9 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8 ? 4 : (BM * BN >= 128 *
   }
 
   struct Stage { u32x4 a[A_IT]; u32x4 b[B_IT]; bool m[A_IT]; };
+  // fast gather: every K-tile lies inside one tap of one source (channel counts are multiples of the tile depth)
+  const bool fastg = !PLAIN && !p.scalar_gather && p.ctot % BK == 0 && p.c0 % BK == 0;
+  int g_ky = 0, g_kx = 0, g_cb = 0;                          // wave-uniform state of the NEXT tile load_tile() will fetch (tiles are fetched in order)
   auto load_tile = [&](Stage& st, int kt) {
     const int k = kt * BK + cchunk * VEC;
 #pragma unroll
@@ -311,9 +314,26 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8 ? 4 : (BM * BN >= 128 *
         const bool ok = a_ok[i] && k < p.K;                       // branch-free (see gather_chunk)
         st.a[i] = *reinterpret_cast<const u32x4*>(a_ptr[i] + (ok ? (size_t)kt * BKB : (size_t)0) - (ok ? 0 : cchunk * 16));
         st.m[i] = ok;
+      } else if (fastg) {
+        // K-tile inside one (tap, source): the tap / channel bookkeeping is wave-uniform scalar state advanced per tile,
+        // the per-lane part is "window origin + tap -> pixel offset" (a dozen instructions instead of gather_chunk's ~45)
+        const bool s0 = g_cb < p.c0;
+        const char* base = s0 ? p.x0 : p.x1;
+        const int ld = s0 ? p.x0_ld : p.x1_ld, up = s0 ? p.up0 : p.up1;
+        const int cofs = (s0 ? g_cb : g_cb - p.c0) + cchunk * VEC;
+        const int iy = a_iy0[i] + g_ky, ix = a_ix0[i] + g_kx;
+        const bool ok = a_ok[i] && kt * BK < p.K && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+        const int iyc = ok ? iy : 0, ixc = ok ? ix : 0;
+        const size_t pix = ((size_t)a_b[i] * (p.H >> up) + (iyc >> up)) * (size_t)(p.W >> up) + (ixc >> up);
+        st.a[i] = *reinterpret_cast<const u32x4*>(base + (pix * ld + (ok ? cofs : 0)) * ES);
+        st.m[i] = ok;
       } else {
         st.a[i] = gather_chunk<T>(p, k, a_b[i], a_iy0[i], a_ix0[i], a_ok[i], st.m[i]);
       }
+    }
+    if (!PLAIN && fastg) {                                  // advance (tap, channel base) to the next K-tile
+      g_cb += BK;
+      if (g_cb >= p.ctot) { g_cb = 0; if (++g_kx == p.KW) { g_kx = 0; ++g_ky; } }
     }
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) st.b[i] = *reinterpret_cast<const u32x4*>(b_ptr[i] + (size_t)kt * BKB);   // rows clamped: always valid
