@@ -575,6 +575,189 @@ int launch_attn64(const AttnArgs& a, hipStream_t stream) {
   return 0;
 }
 
+// ---- 256-key windows of head_dim 72 (Hiera stage 3, 16 x 16): K and V of the whole window resident in LDS --------------
+// A (window, head) has only four 64-key tiles; with tile-by-tile staging the Q / first-tile latency, eight barriers and the
+// staging bookkeeping cost more than the 88 MFMAs.  Here every wave DMAs its share of the window's K and V rows
+// (global_load_lds, 16 B per lane, per-lane source = window token row, LDS image = unpadded 144-byte rows: a 16-lane
+// group of ds_read_b128 at that stride touches all 64 banks once) and after ONE barrier runs the four key tiles back to
+// back with no further synchronisation.  Row reads that run past column 72 (5th k-step, third 32-wide d tile) fetch the
+// next row's finite data against zero Q columns / unstored output rows.  4 waves = 128 queries per workgroup; 72 KiB of
+// LDS, two workgroups per CU.
+__global__ __launch_bounds__(256, 2) void attn_res256_kernel(const AttnArgs p) {
+  constexpr int ROW = 144, NK = 256, QS = 5, DT = 3, CH = 9;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const Ks = smem;
+  char* const Vs = smem + NK * ROW;
+  const int tid = threadIdx.x, wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int lr = lane & 31, lh = lane >> 5;
+  const int qgroups = (p.qtiles + 3) / 4;
+  const int item = blockIdx.x / qgroups;
+  const int qt = (blockIdx.x - item * qgroups) * 4 + wv;
+  const bool live = qt < p.qtiles;
+  const int b = item / p.heads, h = item - b * p.heads;
+  const int qwin = p.q_pool ? p.win / 2 : p.win;
+
+  // ---- DMA the window's K and V: chunk L -> (key row L / 9, 16-byte chunk L % 9); 36 wave-instructions per matrix
+  {
+    long long korg, vorg;
+    if (p.win > 0) {
+      const long long pix0 = tok_off(b, 0, 1, 1, p.win, p.grid_h, p.grid_w);
+      korg = pix0 * p.k_st; vorg = pix0 * p.v_st;
+    } else {
+      korg = (long long)b * p.k_sb; vorg = (long long)b * p.v_sb;
+    }
+    const char* kbase = p.k + (korg + (long long)h * p.k_sh) * 2;
+    const char* vbase = p.v + (vorg + (long long)h * p.v_sh) * 2;
+#pragma unroll
+    for (int j = 0; j < 9; ++j) {
+      const int L = (j * 4 + wv) * 64 + lane;
+      const int row = L / CH, ch = L - row * CH;
+      int pix = row;
+      if (p.win > 0) { const int ty = (int)p.div_win.div((unsigned)row); pix = ty * p.grid_w + (row - ty * p.win); }
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kbase + ((long long)pix * p.k_st + ch * 8) * 2),
+                                       (__attribute__((address_space(3))) void*)(Ks + (j * 4 + wv) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vbase + ((long long)pix * p.v_st + ch * 8) * 2),
+                                       (__attribute__((address_space(3))) void*)(Vs + (j * 4 + wv) * 1024), 16, 0, 0);
+    }
+  }
+  // ---- Q fragments while the DMA flies
+  const int qi = qt * 32 + lr;
+  const bool q_ok = live && qi < p.Nq;
+  u32x4 qf[QS];
+#pragma unroll
+  for (int s = 0; s < QS; ++s) {
+    const int d0 = 16 * s + 8 * lh;
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (q_ok && d0 < p.dqk) {
+      if (!p.q_pool) {
+        const long long off = tok_off(b, qi, p.q_sb, p.q_st, p.win, p.grid_h, p.grid_w) + (long long)h * p.q_sh + d0;
+        v = *reinterpret_cast<const u32x4*>(p.q + off * 2);
+      } else {
+        const int py = qi / qwin, px = qi - py * qwin;
+        f16x8 m;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) m[e] = (f16)(-65504.f);
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+          for (int dx = 0; dx < 2; ++dx) {
+            const int t = (2 * py + dy) * p.win + 2 * px + dx;
+            const long long off = tok_off(b, t, p.q_sb, p.q_st, p.win, p.grid_h, p.grid_w) + (long long)h * p.q_sh + d0;
+            const f16x8 x = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(p.q + off * 2));
+#pragma unroll
+            for (int e = 0; e < 8; ++e) m[e] = x[e] > m[e] ? x[e] : m[e];
+          }
+        v = __builtin_bit_cast(u32x4, m);
+      }
+    }
+    qf[s] = v;
+  }
+  f32x16 oacc[DT];
+#pragma unroll
+  for (int t = 0; t < DT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[t][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+  const float c = p.scale * 1.44269504088896340736f;
+  const int li = lane & 15;
+  const char* const vt = Vs + (4 * lh + (li >> 2)) * ROW + (16 * (lr >> 4) + 4 * (li & 3)) * 2;
+  const char* const kq = Ks + lr * ROW + lh * 16;
+  __syncthreads();                                          // drains every wave's DMA (vmcnt(0)) and publishes the window
+
+#pragma unroll 1
+  for (int kc = 0; kc < NK / 64; ++kc) {
+    f32x16 sacc[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sacc[u][r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < QS; ++s)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const f16x8 kf = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(kq + (kc * 64 + u * 32) * ROW + s * 32));
+        sacc[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, __builtin_bit_cast(f16x8, qf[s]), sacc[u], 0, 0, 0);
+      }
+    float mx = fmaxf(sacc[0][0], sacc[1][0]);
+#pragma unroll
+    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, fmaxf(sacc[0][r], sacc[1][r]));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float m_new = fmaxf(m_run, mx);
+    const float mc = m_new * c;
+    const float alpha = __builtin_amdgcn_exp2f(fmaf(m_run, c, -mc));
+    float psum = 0.f;
+    f16x8 pf[2][2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float pv = __builtin_amdgcn_exp2f(fmaf(sacc[u][r], c, -mc));
+        psum += pv;
+        pf[u][r >> 3][r & 7] = (f16)pv;
+      }
+    psum += __shfl_xor(psum, 32);
+    l_run = l_run * alpha + psum;
+    const float m_prev = m_run;
+    m_run = m_new;
+    if (__any(m_new != m_prev)) {
+#pragma unroll
+      for (int t = 0; t < DT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[t][r] *= alpha;
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int t = 0; t < DT; ++t) {
+          const char* a0 = vt + (kc * 64 + u * 32 + s * 16) * ROW + t * 64;
+          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0));
+          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0 + 8 * ROW));
+          const u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
+          const u32x4 vv = {l2[0], l2[1], h2[0], h2[1]};
+          oacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, vv), pf[u][s], oacc[t], 0, 0, 0);
+        }
+  }
+  if (q_ok) {
+    const float inv = 1.f / l_run;
+    long long obase;
+    if (p.win > 0) {
+      const int ow = p.q_pool ? p.win / 2 : p.win, ogh = p.q_pool ? p.grid_h / 2 : p.grid_h, ogw = p.q_pool ? p.grid_w / 2 : p.grid_w;
+      obase = tok_off(b, qi, p.o_sb, p.o_st, ow, ogh, ogw);
+    } else {
+      obase = (long long)b * p.o_sb + (long long)qi * p.o_st;
+    }
+    obase += (long long)h * p.o_sh;
+#pragma unroll
+    for (int t = 0; t < DT; ++t)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d0 = t * 32 + 8 * g + 4 * lh;
+        if (d0 < p.dv) {
+          f16x4 ov;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) ov[e] = (f16)(oacc[t][4 * g + e] * inv);
+          *reinterpret_cast<f16x4*>(p.o + (obase + d0) * 2) = ov;
+        }
+      }
+  }
+}
+
+int launch_res256(const AttnArgs& a, hipStream_t stream) {
+  constexpr int lds = 2 * 256 * 144 + 256;                 // + slack: the last rows' over-reads stay inside the allocation
+  static bool attr_done = false;
+  if (!attr_done) {
+    CVMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_res256_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    attr_done = true;
+  }
+  const long long blocks = (long long)a.B * a.heads * ((a.qtiles + 3) / 4);
+  CVMI_CHECK(blocks > 0 && blocks < (1ll << 31), "attention: bad grid");
+  hipLaunchKernelGGL(attn_res256_kernel, dim3((unsigned)blocks), dim3(256), lds, stream, a);
+  CVMI_LAUNCH_CHECK();
+  return 0;
+}
+
 // ---- 16-token windows (Hiera stage 2, and the q-pooled stage 2 -> 3 transition): VALU kernel ----------------------------
 // A 4 x 4 window gives the MFMA kernels 16 keys x 16 (or 4 pooled) queries per 32 x 32 tile: >= 75 % padding, and the
 // per-item cost (window addressing, staging, barriers) dominates -- 22 TFLOP/s.  The arithmetic is tiny (37 kMAC per
@@ -859,6 +1042,8 @@ extern "C" int cvmi_attention(const cvmi_attn_desc* d, cvmi_stream_t stream_) {
     CVMI_LAUNCH_CHECK();
     return 0;
   }
+  static const int use_res256 = getenv("CVMI_ATTN_RES256") ? atoi(getenv("CVMI_ATTN_RES256")) : 1;      // tuning experiments only
+  if (use_res256 && d->Nk == 256 && d->dqk == 72 && d->dv == 72 && d->k_st % 8 == 0 && d->v_st % 8 == 0) return launch_res256(a, stream);
   if (d->dqk <= 32 && d->dv <= 32) return launch_f16_gs<32, 32>(a, stream);
   if (d->dqk <= 32 && d->dv <= 64) return launch_f16_gs<32, 64>(a, stream);
   if (d->dqk <= 64 && d->dv <= 64) return launch_f16_gs<64, 64>(a, stream);
