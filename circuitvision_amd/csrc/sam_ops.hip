@@ -167,6 +167,35 @@ __global__ __launch_bounds__(256) void repeat_images_kernel(const u32x4* __restr
   }
 }
 
+// ---- extent of a binary mask: min / max x, y over the non-zero pixels of each plane ----------------------------------
+// (circuit_analyzer.py:364-370: cv2.findContours(EXTERNAL) + boundingRect over all contour points == the bounding
+// rectangle of the non-zero pixels)
+__global__ __launch_bounds__(256) void mask_extent_kernel(const uint8_t* __restrict__ m, int H, int W, int* __restrict__ ext) {
+  const int n = blockIdx.y;
+  const uint8_t* pl = m + (size_t)n * H * W;
+  int x0 = W, y0 = H, x1 = -1, y1 = -1;
+  const long long total = (long long)H * W;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    if (pl[i]) {
+      const int y = (int)(i / W), x = (int)(i - (long long)y * W);
+      x0 = x < x0 ? x : x0; x1 = x > x1 ? x : x1; y0 = y < y0 ? y : y0; y1 = y > y1 ? y : y1;
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    x0 = min(x0, __shfl_xor(x0, off)); y0 = min(y0, __shfl_xor(y0, off));
+    x1 = max(x1, __shfl_xor(x1, off)); y1 = max(y1, __shfl_xor(y1, off));
+  }
+  if ((threadIdx.x & 63) == 0 && x1 >= 0) {
+    atomicMin(ext + n * 4 + 0, x0); atomicMin(ext + n * 4 + 1, y0);
+    atomicMax(ext + n * 4 + 2, x1); atomicMax(ext + n * 4 + 3, y1);
+  }
+}
+__global__ void mask_extent_init_kernel(int* ext, int N, int H, int W) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < N) { ext[i * 4] = W; ext[i * 4 + 1] = H; ext[i * 4 + 2] = -1; ext[i * 4 + 3] = -1; }
+}
+
 // ---- mask decoder tail ------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void zero_i32_kernel(int* __restrict__ p, int n) {
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = 0;
@@ -601,6 +630,15 @@ extern "C" int cvmi_bilinear_f32(const float* x, int N, int h, int w, float* y, 
   CVMI_CHECK(x && y && N > 0 && h > 0 && w > 0 && H > 0 && W > 0, "bilinear: bad arguments");
   hipLaunchKernelGGL(bilinear_kernel, dim3(grid_for((long long)H * W, 256, 1024), N), dim3(256), 0, (hipStream_t)stream_, x, h, w, y, H, W, mask_u8,
                      thresh, (float)h / (float)H, (float)w / (float)W);
+  CVMI_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int cvmi_mask_extent(const uint8_t* mask, int N, int H, int W, int* extent, cvmi_stream_t stream_) {
+  CVMI_CHECK(mask && extent && N > 0 && N <= 65535 && H > 0 && W > 0, "mask_extent: bad arguments");
+  hipStream_t s = (hipStream_t)stream_;
+  hipLaunchKernelGGL(mask_extent_init_kernel, dim3((N + 63) / 64), dim3(64), 0, s, extent, N, H, W);
+  hipLaunchKernelGGL(mask_extent_kernel, dim3(grid_for((long long)H * W, 256, 32), N), dim3(256), 0, s, mask, H, W, extent);
   CVMI_LAUNCH_CHECK();
   return 0;
 }

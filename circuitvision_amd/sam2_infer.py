@@ -196,6 +196,20 @@ class SAM2Transforms:
     def forward_batch(self, img_list):
         return torch.stack([self(img) for img in img_list], dim=0)
 
+    def mask_extent(self, mask_u8):
+        """Bounding boxes of binary masks [N,H,W] / [B,C,H,W] (u8 on the device): list of (x0, y0, x1, y1) or None per
+        plane, with the reference's convention (circuit_analyzer.py:364-370: boundingRect of the external contours)."""
+        require_gpu()
+        lib = _lib.load()
+        m = mask_u8.contiguous()
+        H, W = m.shape[-2:]
+        N = m.numel() // (H * W)
+        ext = torch.empty(N, 4, dtype=torch.int32, device=m.device)
+        torch.cuda.current_stream().synchronize()
+        _lib.check(lib.cvmi_mask_extent(m.data_ptr(), N, H, W, ext.data_ptr(), None), "mask_extent")
+        torch.cuda.synchronize()
+        return [None if x1 < 0 else (x0, y0, x1 + 1, y1 + 1) for x0, y0, x1, y1 in ext.cpu().tolist()]
+
     def postprocess_masks(self, masks, orig_hw, return_u8=False):
         require_gpu()
         lib = _lib.load()

@@ -223,6 +223,11 @@ int cvmi_select_mask(const float* masks, const int* areas, const float* iou, int
 int cvmi_bilinear_f32(const float* x, int N, int h, int w, float* y, int H, int W, uint8_t* mask_u8,
                       float thresh, cvmi_stream_t stream);
 
+/* Extent of N binary u8 planes [N,H,W]: extent[n] = {min x, min y, max x, max y} over the non-zero pixels, or
+ * {W, H, -1, -1} for an empty plane.  Replaces cv2.findContours(RETR_EXTERNAL) + cv2.boundingRect on the SAM 2 mask
+ * (circuit_analyzer.py:364-370): sam_extent_bbox = (min x, min y, max x + 1, max y + 1). */
+int cvmi_mask_extent(const uint8_t* mask, int N, int H, int W, int* extent, cvmi_stream_t stream);
+
 /* Fused 'bilinear upsample to HxW' + MultiKernelRefinement (sam2_infer.py:130-189, :263-272):
  * nk parallel convs (1 -> ic channels, odd kernels ks[], zero 'same' padding) + exact GELU + 1x1
  * combiner.  The ic*nk x H x W intermediate never leaves LDS/registers.

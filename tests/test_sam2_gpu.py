@@ -518,3 +518,24 @@ def test_sam2_hiera_l_baseline_size_permutation_and_replay_properties():
     assert torch.isfinite(l0).all() and torch.isfinite(h0).all()
     assert float(i0.min()) > 0.0 and float(i0.max()) < 1.0
     assert float((l0[0] - l0[1]).abs().max()) > 1e-3               # different images do give different masks
+
+
+def test_mask_extent_matches_bounding_rect_of_nonzero_pixels():
+    """GPU replacement of cv2.findContours(EXTERNAL) + boundingRect on the binary SAM 2 mask (circuit_analyzer.py:364-370):
+    (min x, min y, max x + 1, max y + 1) over the non-zero pixels, None for an empty mask; fused with postprocess_masks'
+    u8 output so only the u8 mask and four ints cross D2H."""
+    from circuitvision_amd.sam2_infer import SAM2Transforms
+    tr = SAM2Transforms(resolution=256, mask_threshold=0, max_hole_area=0, max_sprinkle_area=0)
+    g = torch.Generator().manual_seed(7)
+    logits = torch.randn(3, 1, 64, 64, generator=g) - 1.5
+    logits[1] = -5.0                                                  # empty after thresholding
+    logits[2, 0, 10:20, 30:50] += 8.0
+    out, u8 = tr.postprocess_masks(logits, (123, 77), return_u8=True)
+    ext = tr.mask_extent(u8)
+    ref_mask = (out.cpu() > 0)
+    assert torch.equal(u8.cpu() > 0, ref_mask)
+    for n in range(3):
+        ys, xs = torch.nonzero(ref_mask[n, 0], as_tuple=True)
+        want = None if ys.numel() == 0 else (int(xs.min()), int(ys.min()), int(xs.max()) + 1, int(ys.max()) + 1)
+        assert ext[n] == want, (n, ext[n], want)
+    assert ext[1] is None and ext[0] is not None
