@@ -350,6 +350,14 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn64_kernel(const 
 
   const int qi = qt * 32 + lr;
   const bool q_ok = live && qi < p.Nq;
+  // element offset of this lane's query token (pooled: of the top-left token of its 2 x 2 block), computed once
+  long long qoff0;
+  {
+    const int qc = q_ok ? qi : 0;
+    int t = qc;
+    if (p.q_pool) { const int py = qc / qwin, px = qc - py * qwin; t = (2 * py) * p.win + 2 * px; }
+    qoff0 = tok_off(b, t, p.q_sb, p.q_st, p.win, p.grid_h, p.grid_w) + (long long)h * p.q_sh;
+  }
   u32x4 qf[QS];
 #pragma unroll
   for (int s = 0; s < QS; ++s) {
@@ -357,10 +365,8 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn64_kernel(const 
     u32x4 v = {0u, 0u, 0u, 0u};
     if (q_ok && d0 < p.dqk) {
       if (!p.q_pool) {
-        const long long off = tok_off(b, qi, p.q_sb, p.q_st, p.win, p.grid_h, p.grid_w) + (long long)h * p.q_sh + d0;
-        v = *reinterpret_cast<const u32x4*>(p.q + off * 2);
+        v = *reinterpret_cast<const u32x4*>(p.q + (qoff0 + d0) * 2);
       } else {
-        const int py = qi / qwin, px = qi - py * qwin;
         f16x8 m;
 #pragma unroll
         for (int e = 0; e < 8; ++e) m[e] = (f16)(-65504.f);
@@ -368,8 +374,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn64_kernel(const 
         for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
           for (int dx = 0; dx < 2; ++dx) {
-            const int t = (2 * py + dy) * p.win + 2 * px + dx;
-            const long long off = tok_off(b, t, p.q_sb, p.q_st, p.win, p.grid_h, p.grid_w) + (long long)h * p.q_sh + d0;
+            const long long off = qoff0 + ((long long)dy * p.grid_w + dx) * p.q_st + d0;   // pooled: the 2 x 2 block's tokens are grid neighbours
             const f16x8 x = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(p.q + off * 2));
 #pragma unroll
             for (int e = 0; e < 8; ++e) m[e] = x[e] > m[e] ? x[e] : m[e];
@@ -623,6 +628,14 @@ __global__ __launch_bounds__(256, 2) void attn_res256_kernel(const AttnArgs p) {
   // ---- Q fragments while the DMA flies
   const int qi = qt * 32 + lr;
   const bool q_ok = live && qi < p.Nq;
+  // element offset of this lane's query token (pooled: of the top-left token of its 2 x 2 block), computed once
+  long long qoff0;
+  {
+    const int qc = q_ok ? qi : 0;
+    int t = qc;
+    if (p.q_pool) { const int py = qc / qwin, px = qc - py * qwin; t = (2 * py) * p.win + 2 * px; }
+    qoff0 = tok_off(b, t, p.q_sb, p.q_st, p.win, p.grid_h, p.grid_w) + (long long)h * p.q_sh;
+  }
   u32x4 qf[QS];
 #pragma unroll
   for (int s = 0; s < QS; ++s) {
@@ -630,10 +643,8 @@ __global__ __launch_bounds__(256, 2) void attn_res256_kernel(const AttnArgs p) {
     u32x4 v = {0u, 0u, 0u, 0u};
     if (q_ok && d0 < p.dqk) {
       if (!p.q_pool) {
-        const long long off = tok_off(b, qi, p.q_sb, p.q_st, p.win, p.grid_h, p.grid_w) + (long long)h * p.q_sh + d0;
-        v = *reinterpret_cast<const u32x4*>(p.q + off * 2);
+        v = *reinterpret_cast<const u32x4*>(p.q + (qoff0 + d0) * 2);
       } else {
-        const int py = qi / qwin, px = qi - py * qwin;
         f16x8 m;
 #pragma unroll
         for (int e = 0; e < 8; ++e) m[e] = (f16)(-65504.f);
@@ -641,8 +652,7 @@ __global__ __launch_bounds__(256, 2) void attn_res256_kernel(const AttnArgs p) {
         for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
           for (int dx = 0; dx < 2; ++dx) {
-            const int t = (2 * py + dy) * p.win + 2 * px + dx;
-            const long long off = tok_off(b, t, p.q_sb, p.q_st, p.win, p.grid_h, p.grid_w) + (long long)h * p.q_sh + d0;
+            const long long off = qoff0 + ((long long)dy * p.grid_w + dx) * p.q_st + d0;   // pooled: the 2 x 2 block's tokens are grid neighbours
             const f16x8 x = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(p.q + off * 2));
 #pragma unroll
             for (int e = 0; e < 8; ++e) m[e] = x[e] > m[e] ? x[e] : m[e];
