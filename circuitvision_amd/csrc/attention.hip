@@ -588,16 +588,17 @@ int launch_attn64(const AttnArgs& a, hipStream_t stream) {
 // back with no further synchronisation.  Row reads that run past column 72 (5th k-step, third 32-wide d tile) fetch the
 // next row's finite data against zero Q columns / unstored output rows.  4 waves = 128 queries per workgroup; 72 KiB of
 // LDS, two workgroups per CU.
-__global__ __launch_bounds__(256, 2) void attn_res256_kernel(const AttnArgs p) {
+template <int NW>
+__global__ __launch_bounds__(NW * 64, 2) void attn_res256_kernel(const AttnArgs p) {
   constexpr int ROW = 144, NK = 256, QS = 5, DT = 3, CH = 9;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const Ks = smem;
   char* const Vs = smem + NK * ROW;
   const int tid = threadIdx.x, wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int lr = lane & 31, lh = lane >> 5;
-  const int qgroups = (p.qtiles + 3) / 4;
+  const int qgroups = (p.qtiles + NW - 1) / NW;
   const int item = blockIdx.x / qgroups;
-  const int qt = (blockIdx.x - item * qgroups) * 4 + wv;
+  const int qt = (blockIdx.x - item * qgroups) * NW + wv;
   const bool live = qt < p.qtiles;
   const int b = item / p.heads, h = item - b * p.heads;
   const int qwin = p.q_pool ? p.win / 2 : p.win;
@@ -614,15 +615,16 @@ __global__ __launch_bounds__(256, 2) void attn_res256_kernel(const AttnArgs p) {
     const char* kbase = p.k + (korg + (long long)h * p.k_sh) * 2;
     const char* vbase = p.v + (vorg + (long long)h * p.v_sh) * 2;
 #pragma unroll
-    for (int j = 0; j < 9; ++j) {
-      const int L = (j * 4 + wv) * 64 + lane;
+    for (int j = 0; j < (36 + NW - 1) / NW; ++j) {
+      if (j * NW + wv >= 36) break;                           // 36 wave-instructions per matrix (wave-uniform)
+      const int L = (j * NW + wv) * 64 + lane;
       const int row = L / CH, ch = L - row * CH;
       int pix = row;
       if (p.win > 0) { const int ty = (int)p.div_win.div((unsigned)row); pix = ty * p.grid_w + (row - ty * p.win); }
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kbase + ((long long)pix * p.k_st + ch * 8) * 2),
-                                       (__attribute__((address_space(3))) void*)(Ks + (j * 4 + wv) * 1024), 16, 0, 0);
+                                       (__attribute__((address_space(3))) void*)(Ks + (j * NW + wv) * 1024), 16, 0, 0);
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vbase + ((long long)pix * p.v_st + ch * 8) * 2),
-                                       (__attribute__((address_space(3))) void*)(Vs + (j * 4 + wv) * 1024), 16, 0, 0);
+                                       (__attribute__((address_space(3))) void*)(Vs + (j * NW + wv) * 1024), 16, 0, 0);
     }
   }
   // ---- Q fragments while the DMA flies
@@ -754,16 +756,17 @@ __global__ __launch_bounds__(256, 2) void attn_res256_kernel(const AttnArgs p) {
   }
 }
 
+template <int NW>
 int launch_res256(const AttnArgs& a, hipStream_t stream) {
   constexpr int lds = 2 * 256 * 144 + 256;                 // + slack: the last rows' over-reads stay inside the allocation
   static bool attr_done = false;
   if (!attr_done) {
-    CVMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_res256_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    CVMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_res256_kernel<NW>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     attr_done = true;
   }
-  const long long blocks = (long long)a.B * a.heads * ((a.qtiles + 3) / 4);
+  const long long blocks = (long long)a.B * a.heads * ((a.qtiles + NW - 1) / NW);
   CVMI_CHECK(blocks > 0 && blocks < (1ll << 31), "attention: bad grid");
-  hipLaunchKernelGGL(attn_res256_kernel, dim3((unsigned)blocks), dim3(256), lds, stream, a);
+  hipLaunchKernelGGL(attn_res256_kernel<NW>, dim3((unsigned)blocks), dim3(NW * 64), lds, stream, a);
   CVMI_LAUNCH_CHECK();
   return 0;
 }
@@ -1052,8 +1055,9 @@ extern "C" int cvmi_attention(const cvmi_attn_desc* d, cvmi_stream_t stream_) {
     CVMI_LAUNCH_CHECK();
     return 0;
   }
-  static const int use_res256 = getenv("CVMI_ATTN_RES256") ? atoi(getenv("CVMI_ATTN_RES256")) : 1;      // tuning experiments only
-  if (use_res256 && d->Nk == 256 && d->dqk == 72 && d->dv == 72 && d->k_st % 8 == 0 && d->v_st % 8 == 0) return launch_res256(a, stream);
+  static const int use_res256 = getenv("CVMI_ATTN_RES256") ? atoi(getenv("CVMI_ATTN_RES256")) : 2;      // tuning experiments only: 0 off, 1 four waves, 2 eight waves (4 per SIMD at 125 VGPRs)
+  if (use_res256 && d->Nk == 256 && d->dqk == 72 && d->dv == 72 && d->k_st % 8 == 0 && d->v_st % 8 == 0)
+    return (use_res256 == 2 && a.qtiles >= 8) ? launch_res256<8>(a, stream) : launch_res256<4>(a, stream);
   if (d->dqk <= 32 && d->dv <= 32) return launch_f16_gs<32, 32>(a, stream);
   if (d->dqk <= 32 && d->dv <= 64) return launch_f16_gs<32, 64>(a, stream);
   if (d->dqk <= 64 && d->dv <= 64) return launch_f16_gs<64, 64>(a, stream);
