@@ -169,6 +169,8 @@ def _attn_ref(q, k, v, scale):
     (1, 8, 300, 38, 32, 32),       # decoder image->token
     (1, 2, 130, 257, 72, 72),      # ragged q and key tiles
     (5, 3, 16, 16, 72, 72),        # tiny windows, private K/V tiles
+    (2, 3, 600, 600, 72, 72),      # long sequence, head_dim 72: DMA-streamed 64-key tiles (ragged last tile, ragged q tiles)
+    (1, 2, 1024, 1024, 72, 72),    # same, whole tiles
 ])
 def test_attention(dtype, shape):
     B, Hh, Nq, Nk, dqk, dv = shape
