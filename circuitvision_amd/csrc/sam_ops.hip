@@ -167,6 +167,27 @@ __global__ __launch_bounds__(256) void repeat_images_kernel(const u32x4* __restr
   }
 }
 
+// ---- space-to-depth(4) of a 3-channel NHWC image: [B,H,W,3] -> [B,H/4,W/4,48], channel = (sy*4 + sx)*3 + c.
+//      Turns Hiera's 7x7 / stride-4 / 3-channel patch embedding (a per-element gather) into a 2x2 conv over 48 channels.
+template <typename T>
+__global__ __launch_bounds__(256) void s2d4_kernel(const T* __restrict__ x, T* __restrict__ y, long long blocks, int H, int W) {
+  // one thread per (block, sy): 4 pixels x 3 channels = 12 contiguous input elements -> 12 contiguous outputs
+  const long long total = blocks * 4;
+  const int bw = W / 4, bh = H / 4;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int sy = (int)(i & 3);
+    const long long blk = i >> 2;
+    const int bx = (int)(blk % bw);
+    const long long t = blk / bw;
+    const int by = (int)(t % bh);
+    const long long b = t / bh;
+    const T* src = x + ((b * H + by * 4 + sy) * W + bx * 4) * 3;
+    T* dst = y + blk * 48 + sy * 12;
+#pragma unroll
+    for (int e = 0; e < 12; ++e) dst[e] = src[e];
+  }
+}
+
 // ---- extent of a binary mask: min / max x, y over the non-zero pixels of each plane ----------------------------------
 // (circuit_analyzer.py:364-370: cv2.findContours(EXTERNAL) + boundingRect over all contour points == the bounding
 // rectangle of the non-zero pixels)
@@ -630,6 +651,17 @@ extern "C" int cvmi_bilinear_f32(const float* x, int N, int h, int w, float* y, 
   CVMI_CHECK(x && y && N > 0 && h > 0 && w > 0 && H > 0 && W > 0, "bilinear: bad arguments");
   hipLaunchKernelGGL(bilinear_kernel, dim3(grid_for((long long)H * W, 256, 1024), N), dim3(256), 0, (hipStream_t)stream_, x, h, w, y, H, W, mask_u8,
                      thresh, (float)h / (float)H, (float)w / (float)W);
+  CVMI_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int cvmi_space_to_depth4(const void* x, void* y, int B, int H, int W, int dtype, cvmi_stream_t stream_) {
+  CVMI_CHECK(x && y && B > 0 && H > 0 && W > 0 && H % 4 == 0 && W % 4 == 0, "space_to_depth4: bad shape");
+  CVMI_CHECK(dtype == CVMI_F16 || dtype == CVMI_F32, "space_to_depth4: bad dtype");
+  const long long blocks = (long long)B * (H / 4) * (W / 4);
+  const dim3 g(grid_for(blocks * 4)), b(256);
+  if (dtype == CVMI_F16) hipLaunchKernelGGL(s2d4_kernel<f16>, g, b, 0, (hipStream_t)stream_, (const f16*)x, (f16*)y, blocks, H, W);
+  else hipLaunchKernelGGL(s2d4_kernel<float>, g, b, 0, (hipStream_t)stream_, (const float*)x, (float*)y, blocks, H, W);
   CVMI_LAUNCH_CHECK();
   return 0;
 }

@@ -191,7 +191,16 @@ class Sam2Weights:
         h = self.hiera
         E, stages, ws = h["embed_dim"], h["stages"], h["window_spec"]
         T = "image_encoder.trunk"
-        self._pack("patch_embed", self.p.weight(f"{T}.patch_embed.proj", (E, 3, 7, 7)), self.p.bias(f"{T}.patch_embed.proj", E))
+        # PatchEmbed 7x7 / s4 / pad 3 on the space-to-depth(4) image: window row ky = 0..2 sits in block row -1 (sub-row
+        # ky + 1), ky = 3..6 in block row 0 (sub-row ky - 3); same for columns -> a 2x2 conv over 48 channels
+        w7 = self.p.weight(f"{T}.patch_embed.proj", (E, 3, 7, 7))
+        w2 = torch.zeros(E, 48, 2, 2)
+        m = {k: ((0, k + 1) if k < 3 else (1, k - 3)) for k in range(7)}
+        for ky in range(7):
+            for kx in range(7):
+                (ty, sy), (tx, sx) = m[ky], m[kx]
+                w2[:, (sy * 4 + sx) * 3:(sy * 4 + sx) * 3 + 3, ty, tx] = w7[:, :, ky, kx]
+        self._pack("patch_embed", w2, self.p.bias(f"{T}.patch_embed.proj", E))
         g = self.image_size // 4
         pos = TF.interpolate(self.p.tensor(f"{T}.pos_embed", (1, E, 7, 7)), size=(g, g), mode="bicubic")
         win = self.p.tensor(f"{T}.pos_embed_window", (1, E, ws[0], ws[0]))
@@ -406,8 +415,12 @@ class Sam2Plan:
         x = self.buf(g, g, E, F32)
         pos = wt.const["pos_embed"]
         self.plan.keep.append(pos)
-        op_conv(self.plan, "patch_embed", wt.pc["patch_embed"], [(self.x_in.view(), 0)], x.view(), stride=4, pad=3,
-                res=_ConstView(pos, E), res_mod=g * g, scalar_gather=True, kind="stem")
+        xs = Buf(B, g, g, 48, self.dt, self.dev)
+        lib = _lib.load()
+        op_call(self.plan, "s2d4", "stem", lib.cvmi_space_to_depth4, (self.x_in.t.data_ptr(), xs.t.data_ptr(), B, R, R, self.dt),
+                keep=(self.x_in, xs), bytes_=2 * self.x_in.nbytes)
+        op_conv(self.plan, "patch_embed", wt.pc["patch_embed"], [(xs.view(), 0)], x.view(), stride=1, pad=1, out_hw=(g, g),
+                res=_ConstView(pos, E), res_mod=g * g, kind="stem")
         H = W = g
         stage_out = []
         for i, blk in enumerate(wt.blocks):

@@ -187,6 +187,11 @@ int cvmi_layernorm(const void* x, int x_ld, int x_dtype, const float* gamma, con
 int cvmi_maxpool2x2(const void* x, int x_ld, void* y, int y_ld, int B, int H, int W, int C, int dtype,
                     cvmi_stream_t stream);
 
+/* Space-to-depth(4) of a 3-channel NHWC image: [B,H,W,3] -> [B,H/4,W/4,48], channel (sy*4 + sx)*3 + c.  With it Hiera's
+ * PatchEmbed (Conv2d 3 -> E, 7x7, stride 4, pad 3; sam2 hieradet.py) is a 2x2 / stride-1 conv over 48 channels
+ * (block taps -1, 0), i.e. a vectorised cvmi_conv2d instead of a per-element gather. */
+int cvmi_space_to_depth4(const void* x, void* y, int B, int H, int W, int dtype, cvmi_stream_t stream);
+
 /* rows x C copy with dtype conversion (f32 <-> f16). */
 int cvmi_cast(const void* x, int x_ld, int x_dtype, void* y, int y_ld, int y_dtype, long long rows, int C,
               cvmi_stream_t stream);
