@@ -273,7 +273,11 @@ def main():
             roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                         "kernel": "conv stack (igemm / conv_tile / dwconv / pool / attention launches) per step",
-                        "kernel_ms_per_step": round(stack_ms, 4), "algorithmic_bytes_per_step": int(algo_bytes)}
+                        "kernel_ms_per_step": round(stack_ms, 4), "algorithmic_bytes_per_step": int(algo_bytes),
+                        # the captured graph runs the Detect chains beside the neck, so the step is shorter than the sum of
+                        # its launches: the same bytes over the measured step time (decode + NMS included)
+                        "achieved_over_graph_step": round(algo_bytes / (ms_per_step * 1e-3) / 1e9, 1),
+                        "frac_over_graph_step": round(algo_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
         else:
             # m / l / x are MFMA-bound (87 GFLOP / image for l)
             fl = float(sum(acc[k][3] for k in stack_kinds if k in acc))
