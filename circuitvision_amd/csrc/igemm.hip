@@ -759,6 +759,251 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(const ConvKArgs p) {
   }
 }
 
+// ---- persistent form of gemm256_kernel for fp16 output without residual (Hiera qkv / fc1) ------------------------------
+// One workgroup per CU loops over its tiles (XCD-contiguous); the prologue DMA of tile i + 1 (14 instructions per lane into
+// the two stage buffers, which are dead once every wave has left the K-loop) is issued BEFORE the epilogue of tile i, so the
+// HBM / L2 latency of a tile's first K-tiles hides behind the previous tile's bias / activation / store work.  For that the
+// epilogue must not touch the stage buffers: each wave transposes its 128 x 64 sub-tile through a private 4 KiB scratch
+// (32 pixels x 64 channels per step, XOR-swizzled 16-byte chunks) -- no workgroup barrier, and no ordinary global load while
+// the DMA is in flight (hipcc would drain the queue at its use): the wave's 64 bias values are parked in its scratch at the
+// start of the tile.  K-loop, hazards and counted waits are those of gemm256_kernel (staggered groups).
+__global__ __launch_bounds__(512, 1) void gemm256p_kernel(const ConvKArgs p, int ntiles) {
+  using T = f16;
+  constexpr int BM = 256, BN = 256, BKB = 128;
+  constexpr int STAGE = (BM + BN) * BKB;                  // 64 KiB
+  constexpr int SCR_OFF = 2 * STAGE, SCR_WAVE = 2048, BIAS_OFF = SCR_OFF + 8 * SCR_WAVE;   // 32 px x 32 ch scratch + 64 bias floats per wave
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int wr = wv >> 2, wc = wv & 3;
+  const int lr = lane & 31, lh = lane >> 5;
+  char* const scr = smem + SCR_OFF + wv * SCR_WAVE;
+  char* const bsc = smem + BIAS_OFF + wv * 256;
+
+  // tiles of this workgroup: XCD x (= blockIdx & 7) owns a contiguous run; its workgroups stride through it
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, wpx = gridDim.x >> 3;
+  const int tq = ntiles >> 3, trm = ntiles & 7;
+  const int tbase = xcd * tq + (xcd < trm ? xcd : trm), tcnt = tq + (xcd < trm ? 1 : 0);
+
+  const int nk = (p.K + 63) / 64, krem = p.K & 63;
+  const char* src[4][2];
+  int dst[4][2], adj[4][2];
+#pragma unroll
+  for (int h = 0; h < 4; ++h)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int q = wv * 2 + i;
+      dst[h][i] = ((h == 0 || h == 3) ? (q >> 3) * 128 + (h == 3 ? 64 : 0) + (q & 7) * 8
+                                       : BM + (q >> 2) * 64 + (h == 2 ? 32 : 0) + (q & 3) * 8) * BKB;
+    }
+  auto setup = [&](int tile, int& m0, int& n0) {
+    const int bn = tile % p.nb_n, bm = tile / p.nb_n;
+    m0 = bm * BM; n0 = bn * BN;
+    int ln = lane;
+    asm volatile("" : "+v"(ln));                           // opaque: the per-lane row / slot terms are recomputed per tile, not hoisted (and spilled)
+#pragma unroll
+    for (int h = 0; h < 4; ++h)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int row = dst[h][i] / BKB + (ln >> 3);
+        const int slot_ = (ln & 7) ^ ((row >> 1) & 7);
+        adj[h][i] = 0;
+        if (row < BM) {
+          int m = m0 + row;
+          m = m < p.M ? m : p.M - 1;
+          src[h][i] = p.x0 + ((size_t)m * p.x0_ld + slot_ * 8) * 2;
+          if (krem && slot_ * 8 >= krem) adj[h][i] = -BKB;
+        } else {
+          int n = n0 + row - BM;
+          n = n < p.N ? n : p.N - 1;
+          src[h][i] = p.w + ((size_t)n * p.Kpad + slot_ * 8) * 2;
+        }
+      }
+  };
+#define G256_ISSUE(h, stage, kt)                                                                                         \
+  do {                                                                                                                   \
+    const long long last_ = (kt) == nk - 1 ? 1 : 0;                                                                      \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[h][0] + (long long)(kt) * BKB + last_ * adj[h][0]), \
+                                     (__attribute__((address_space(3))) void*)(smem + (stage) * STAGE + dst[h][0]), 16, 0, 0); \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[h][1] + (long long)(kt) * BKB + last_ * adj[h][1]), \
+                                     (__attribute__((address_space(3))) void*)(smem + (stage) * STAGE + dst[h][1]), 16, 0, 0); \
+  } while (0)
+#define G256_PROLOGUE()                                                                                                  \
+  do {                                                                                                                   \
+    G256_ISSUE(0, 0, 0); G256_ISSUE(1, 0, 0); G256_ISSUE(2, 0, 0); G256_ISSUE(3, 0, 0);                                  \
+    if (nk > 1) { G256_ISSUE(0, 1, 1); G256_ISSUE(1, 1, 1); G256_ISSUE(2, 1, 1); }                                       \
+  } while (0)
+
+  f32x16 acc[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const int sw = (lr >> 1) & 7;
+  int ko[4];
+#pragma unroll
+  for (int s2 = 0; s2 < 4; ++s2) ko[s2] = ((2 * s2 + lh) ^ sw) << 4;
+  const int xbase = (wr * 128 + lr) * BKB, wbase = (BM + wc * 64 + lr) * BKB;
+
+  u32x4 xf[2][4], wf[2][4];
+#define G256_READ_X(slot_, j)                                                                                            \
+  _Pragma("unroll") for (int s2 = 0; s2 < 4; ++s2)                                                                       \
+      xf[slot_][s2] = *reinterpret_cast<const u32x4*>(st + xbase + (j) * 32 * BKB + ko[s2])
+#define G256_READ_W(i)                                                                                                   \
+  _Pragma("unroll") for (int s2 = 0; s2 < 4; ++s2)                                                                       \
+      wf[i][s2] = *reinterpret_cast<const u32x4*>(st + wbase + (i) * 32 * BKB + ko[s2])
+#define G256_SYNC_IN()                                                                                                   \
+  do {                                                                                                                   \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                   \
+    __builtin_amdgcn_sched_barrier(0);                                                                                   \
+    __builtin_amdgcn_s_barrier();                                                                                        \
+    __builtin_amdgcn_sched_barrier(0);                                                                                   \
+    __builtin_amdgcn_s_setprio(1);                                                                                       \
+  } while (0)
+#define G256_SYNC_OUT()                                                                                                  \
+  do {                                                                                                                   \
+    __builtin_amdgcn_s_setprio(0);                                                                                       \
+    __builtin_amdgcn_sched_barrier(0);                                                                                   \
+    __builtin_amdgcn_s_barrier();                                                                                        \
+    __builtin_amdgcn_sched_barrier(0);                                                                                   \
+  } while (0)
+#define G256_MMA(i, j0)                                                                                                  \
+  asm volatile("" : "+v"(wf[i][0]), "+v"(wf[i][1]), "+v"(wf[i][2]), "+v"(wf[i][3]));                                     \
+  _Pragma("unroll") for (int s2 = 0; s2 < 4; ++s2) {                                                                     \
+    Mma<T>::run(wf[i][s2], xf[0][s2], acc[i][j0]);                                                                       \
+    Mma<T>::run(wf[i][s2], xf[1][s2], acc[i][(j0) + 1]);                                                                 \
+  }                                                                                                                      \
+  asm volatile("" : "+v"(acc[i][j0]), "+v"(acc[i][(j0) + 1]))
+
+  int m0 = 0, n0 = 0;
+  if (slot < tcnt) { setup(tbase + slot, m0, n0); G256_PROLOGUE(); }
+  for (int ti = slot; ti < tcnt; ti += wpx) {
+    const int cm0 = m0, cn0 = n0;
+    // ---- this wave's 64 bias values -> its scratch (drains the prologue DMA: it was issued an epilogue ago)
+    if (lane < 16) {
+      const int n = cn0 + wc * 64 + lane * 4;
+      f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+      if (n < p.N) bv = *reinterpret_cast<const f32x4*>(p.bias + n);
+      *reinterpret_cast<f32x4*>(bsc + lane * 16) = bv;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();
+
+    for (int kt = 0; kt < nk; ++kt) {
+      const int b = kt & 1;
+      const char* st = smem + b * STAGE;
+      const bool more1 = kt + 1 < nk, more2 = kt + 2 < nk;
+      G256_READ_W(0);
+      G256_READ_X(0, 0);
+      G256_READ_X(1, 1);
+      if (more1) G256_ISSUE(3, b ^ 1, kt + 1);
+      G256_SYNC_IN();
+      G256_MMA(0, 0);
+      G256_SYNC_OUT();
+      G256_READ_W(1);
+      if (more2) G256_ISSUE(0, b, kt + 2);
+      G256_SYNC_IN();
+      G256_MMA(1, 0);
+      G256_SYNC_OUT();
+      G256_READ_X(0, 2);
+      G256_READ_X(1, 3);
+      if (more2) G256_ISSUE(1, b, kt + 2);
+      G256_SYNC_IN();
+      G256_MMA(1, 2);
+      G256_SYNC_OUT();
+      if (more2) {
+        G256_ISSUE(2, b, kt + 2);
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      } else if (more1) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      G256_SYNC_IN();
+      G256_MMA(0, 2);
+      G256_SYNC_OUT();
+    }
+    if (wr == 0) __builtin_amdgcn_s_barrier();            // groups aligned: every wave has left the K-loop, both stages are dead
+
+    // ---- next tile's prologue flies during this tile's epilogue
+    if (ti + wpx < tcnt) { setup(tbase + ti + wpx, m0, n0); G256_PROLOGUE(); }
+
+    // ---- wave-private epilogue: 32 pixels x 32 channels per step through the scratch (64-byte rows, swizzled 16-byte chunks)
+    // (one base register per kind of access + immediate offsets: anything the compiler would spill here comes back through
+    //  a scratch load, whose vmcnt(0) drains the prologue in flight)
+    int le = lane;
+    asm volatile("" : "+v"(le));                           // opaque copy: the epilogue's address terms are built here, after the K-loop
+    const int lre = le & 31, lhe = le >> 5;
+    const unsigned ba_base = (unsigned)(BIAS_OFF + wv * 256 + lhe * 16);
+    const unsigned sa_base = (unsigned)(SCR_OFF + wv * SCR_WAVE + (le >> 2) * 64 + (((le & 3) ^ ((le >> 2) & 3)) << 4));
+    char* const wr_base = scr + lre * 64 + lhe * 8;
+    const int wsw = lre & 3;
+    with_act<true>(p.act, [&](auto actf) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          // the 4 x 4 bias values of this channel tile: four reads, ONE wait (each inline-asm read + wait is a full LDS round trip)
+          f32x4 b0, b1, b2, b3;
+          asm volatile("ds_read_b128 %0, %4 offset:%5\n\tds_read_b128 %1, %4 offset:%6\n\tds_read_b128 %2, %4 offset:%7\n\t"
+                       "ds_read_b128 %3, %4 offset:%8\n\ts_waitcnt lgkmcnt(0)"
+                       : "=&v"(b0), "=&v"(b1), "=&v"(b2), "=&v"(b3)
+                       : "v"(ba_base), "n"(i * 128), "n"(i * 128 + 32), "n"(i * 128 + 64), "n"(i * 128 + 96) : "memory");
+          __builtin_amdgcn_sched_barrier(0);
+          const f32x4 bq[4] = {b0, b1, b2, b3};
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            f16x4 hv;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) hv[e] = (f16)actf(acc[i][j][4 * q + e] + bq[q][e]);
+            *reinterpret_cast<f16x4*>(wr_base + ((q ^ wsw) << 4)) = hv;
+          }
+          u32x4 v0, v1;
+          asm volatile("s_waitcnt lgkmcnt(0)\n\tds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:1024\n\ts_waitcnt lgkmcnt(0)"
+                       : "=&v"(v0), "=&v"(v1) : "v"(sa_base) : "memory");
+          __builtin_amdgcn_sched_barrier(0);
+          const u32x4 vv[2] = {v0, v1};
+#pragma unroll
+          for (int it = 0; it < 2; ++it) {
+            const int c = it * 64 + le, row = c >> 2, ch = c & 3;
+            const int m = cm0 + wr * 128 + j * 32 + row, n = cn0 + wc * 64 + i * 32 + ch * 8;
+            if (m < p.M && n < p.N) *reinterpret_cast<u32x4*>(p.y + ((size_t)m * p.y_ld + n) * 2) = vv[it];
+          }
+        }
+    });
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  }
+#undef G256_ISSUE
+#undef G256_PROLOGUE
+#undef G256_READ_X
+#undef G256_READ_W
+#undef G256_SYNC_IN
+#undef G256_SYNC_OUT
+#undef G256_MMA
+}
+
+int launch_g256p(ConvKArgs& a, hipStream_t stream) {
+  constexpr int bytes = 2 * 512 * 128 + 8 * 2048 + 8 * 256;   // two stages + eight 2 KiB wave scratches + eight 64-float bias rows
+  static bool attr_done = false;
+  if (!attr_done) {
+    CVMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256p_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    attr_done = true;
+  }
+  a.nb_n = cdiv(a.N, 256);
+  const long long tiles = (long long)cdiv(a.M, 256) * a.nb_n;
+  CVMI_CHECK(tiles >= 8 && tiles < (1ll << 31), "conv2d: bad grid %lld", tiles);
+  const unsigned grid = tiles >= 256 ? 256u : (unsigned)(tiles / 8 * 8);
+  hipLaunchKernelGGL(gemm256p_kernel, dim3(grid), dim3(512), bytes, stream, a, (int)tiles);
+  CVMI_LAUNCH_CHECK();
+  return 0;
+}
+
 // ---- 256 x 192 tile variant of gemm256_kernel (N = 576 = 3 x 192: Hiera-L stage-3 proj / fc2) -------------------------
 // 8 waves as 4 (pixel quarters) x 2 (channel halves; the two staggered groups), wave tile 64 px x 96 ch = 2 x 3 MFMA
 // tiles.  A K-tile is three phases of 8 MFMAs:  1: W c0, X p0 p1 -> (c0;p0,p1)   2: W c1 -> (c1;..)   3: W c2 -> (c2;..).
@@ -1085,7 +1330,13 @@ int launch_typed(ConvKArgs& a, hipStream_t stream) {
     if (use_g256 && a.plain && a.K % 8 == 0 && a.K >= g256_mink && a.Kpad % 64 == 0 && N % 8 == 0 && N >= g256_minn && a.shuf_c == 0) {
       const long long tiles = (long long)cdiv(M, 256) * cdiv(N, 256);
       const double col_eff = (double)N / (cdiv(N, 256) * 256), wave_eff = (double)tiles / (double)(cdiv(tiles, 256) * 256);
-      if (tiles >= 256 && ((col_eff >= 0.8 && wave_eff >= 0.8) || use_g256 >= 3)) return launch_g256<TO>(a, stream, use_g256 != 2);
+      if (tiles >= 256 && ((col_eff >= 0.8 && wave_eff >= 0.8) || use_g256 >= 3)) {
+        static const int use_p = getenv("CVMI_G256P") ? atoi(getenv("CVMI_G256P")) : 1;             // tuning experiments only
+        if constexpr (sizeof(TO) == 2) {
+          if (use_p && !a.res && !a.act_after_res) return launch_g256p(a, stream);
+        }
+        return launch_g256<TO>(a, stream, use_g256 != 2);
+      }
       // N a multiple of 192 that the 256-wide tiling wastes (576 = 3 x 192)
       static const int use_g192 = getenv("CVMI_G192") ? atoi(getenv("CVMI_G192")) : 1;
       const long long tiles192 = (long long)cdiv(M, 256) * cdiv(N, 192);
