@@ -756,6 +756,191 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_res256_kernel(const AttnArgs 
   }
 }
 
+// ---- 64-key windows of head_dim 72 (Hiera stages 1 and 4, and the q-pooled stage transitions that keep 64 keys):
+//      two (window, head) items per workgroup, QT waves (= 32-query tiles) each, the item's K / V resident in LDS
+template <int QT>
+__global__ __launch_bounds__(QT * 128, 4) void attn_res64_kernel(const AttnArgs p) {
+  constexpr int NW = QT;                                    // waves per item
+  constexpr int ROW = 144, NK = 64, QS = 5, DT = 3, CH = 9;
+  constexpr int ITEM_B = 2 * NK * ROW + 64;                // K + V of one item (+ slack for the last rows' over-reads)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, wvg = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int sub = wvg / QT, wv = wvg - sub * QT;            // item within the workgroup, wave within the item
+  char* const Ks = smem + sub * ITEM_B;
+  char* const Vs = Ks + NK * ROW;
+  const int lr = lane & 31, lh = lane >> 5;
+  const int nitems = p.B * p.heads;
+  const int item_raw = blockIdx.x * 2 + sub;
+  const int item = item_raw < nitems ? item_raw : nitems - 1;
+  const int qt = wv;
+  const bool live = item_raw < nitems && qt < p.qtiles;
+  const int b = item / p.heads, h = item - b * p.heads;
+  const int qwin = p.q_pool ? p.win / 2 : p.win;
+
+  // ---- DMA the window's K and V: chunk L -> (key row L / 9, 16-byte chunk L % 9); 36 wave-instructions per matrix
+  {
+    long long korg, vorg;
+    if (p.win > 0) {
+      const long long pix0 = tok_off(b, 0, 1, 1, p.win, p.grid_h, p.grid_w);
+      korg = pix0 * p.k_st; vorg = pix0 * p.v_st;
+    } else {
+      korg = (long long)b * p.k_sb; vorg = (long long)b * p.v_sb;
+    }
+    const char* kbase = p.k + (korg + (long long)h * p.k_sh) * 2;
+    const char* vbase = p.v + (vorg + (long long)h * p.v_sh) * 2;
+#pragma unroll
+    for (int j = 0; j < (9 + NW - 1) / NW; ++j) {
+      if (j * NW + wv >= 9) break;                            // 9 wave-instructions per matrix (wave-uniform)
+      const int L = (j * NW + wv) * 64 + lane;
+      const int row = L / CH, ch = L - row * CH;
+      int pix = row;
+      if (p.win > 0) { const int ty = (int)p.div_win.div((unsigned)row); pix = ty * p.grid_w + (row - ty * p.win); }
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kbase + ((long long)pix * p.k_st + ch * 8) * 2),
+                                       (__attribute__((address_space(3))) void*)(Ks + (j * NW + wv) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vbase + ((long long)pix * p.v_st + ch * 8) * 2),
+                                       (__attribute__((address_space(3))) void*)(Vs + (j * NW + wv) * 1024), 16, 0, 0);
+    }
+  }
+  // ---- Q fragments while the DMA flies
+  const int qi = qt * 32 + lr;
+  const bool q_ok = live && qi < p.Nq;
+  // element offset of this lane's query token (pooled: of the top-left token of its 2 x 2 block), computed once
+  long long qoff0;
+  {
+    const int qc = q_ok ? qi : 0;
+    int t = qc;
+    if (p.q_pool) { const int py = qc / qwin, px = qc - py * qwin; t = (2 * py) * p.win + 2 * px; }
+    qoff0 = tok_off(b, t, p.q_sb, p.q_st, p.win, p.grid_h, p.grid_w) + (long long)h * p.q_sh;
+  }
+  u32x4 qf[QS];
+#pragma unroll
+  for (int s = 0; s < QS; ++s) {
+    const int d0 = 16 * s + 8 * lh;
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (q_ok && d0 < p.dqk) {
+      if (!p.q_pool) {
+        v = *reinterpret_cast<const u32x4*>(p.q + (qoff0 + d0) * 2);
+      } else {
+        f16x8 m;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) m[e] = (f16)(-65504.f);
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+          for (int dx = 0; dx < 2; ++dx) {
+            const long long off = qoff0 + ((long long)dy * p.grid_w + dx) * p.q_st + d0;   // pooled: the 2 x 2 block's tokens are grid neighbours
+            const f16x8 x = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(p.q + off * 2));
+#pragma unroll
+            for (int e = 0; e < 8; ++e) m[e] = x[e] > m[e] ? x[e] : m[e];
+          }
+        v = __builtin_bit_cast(u32x4, m);
+      }
+    }
+    qf[s] = v;
+  }
+  f32x16 oacc[DT];
+#pragma unroll
+  for (int t = 0; t < DT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[t][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+  const float c = p.scale * 1.44269504088896340736f;
+  const int li = lane & 15;
+  const char* const vt = Vs + (4 * lh + (li >> 2)) * ROW + (16 * (lr >> 4) + 4 * (li & 3)) * 2;
+  const char* const kq = Ks + lr * ROW + lh * 16;
+  __syncthreads();                                          // drains every wave's DMA (vmcnt(0)) and publishes the window
+
+  {
+    constexpr int kc = 0;
+    f32x16 sacc[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sacc[u][r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < QS; ++s)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const f16x8 kf = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(kq + (kc * 64 + u * 32) * ROW + s * 32));
+        sacc[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, __builtin_bit_cast(f16x8, qf[s]), sacc[u], 0, 0, 0);
+      }
+    float mx = fmaxf(sacc[0][0], sacc[1][0]);
+#pragma unroll
+    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, fmaxf(sacc[0][r], sacc[1][r]));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float m_new = fmaxf(m_run, mx);
+    const float mc = m_new * c;
+    const float alpha = __builtin_amdgcn_exp2f(fmaf(m_run, c, -mc));
+    float psum = 0.f;
+    f16x8 pf[2][2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float pv = __builtin_amdgcn_exp2f(fmaf(sacc[u][r], c, -mc));
+        psum += pv;
+        pf[u][r >> 3][r & 7] = (f16)pv;
+      }
+    psum += __shfl_xor(psum, 32);
+    l_run = l_run * alpha + psum;
+    const float m_prev = m_run;
+    m_run = m_new;
+    if (__any(m_new != m_prev)) {
+#pragma unroll
+      for (int t = 0; t < DT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[t][r] *= alpha;
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int t = 0; t < DT; ++t) {
+          const char* a0 = vt + (kc * 64 + u * 32 + s * 16) * ROW + t * 64;
+          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0));
+          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0 + 8 * ROW));
+          const u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
+          const u32x4 vv = {l2[0], l2[1], h2[0], h2[1]};
+          oacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, vv), pf[u][s], oacc[t], 0, 0, 0);
+        }
+  }
+  if (q_ok) {
+    const float inv = 1.f / l_run;
+    long long obase;
+    if (p.win > 0) {
+      const int ow = p.q_pool ? p.win / 2 : p.win, ogh = p.q_pool ? p.grid_h / 2 : p.grid_h, ogw = p.q_pool ? p.grid_w / 2 : p.grid_w;
+      obase = tok_off(b, qi, p.o_sb, p.o_st, ow, ogh, ogw);
+    } else {
+      obase = (long long)b * p.o_sb + (long long)qi * p.o_st;
+    }
+    obase += (long long)h * p.o_sh;
+#pragma unroll
+    for (int t = 0; t < DT; ++t)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d0 = t * 32 + 8 * g + 4 * lh;
+        if (d0 < p.dv) {
+          f16x4 ov;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) ov[e] = (f16)(oacc[t][4 * g + e] * inv);
+          *reinterpret_cast<f16x4*>(p.o + (obase + d0) * 2) = ov;
+        }
+      }
+  }
+}
+
+template <int QT>
+int launch_res64(const AttnArgs& a, hipStream_t stream) {
+  constexpr int lds = 2 * (2 * 64 * 144 + 64);
+  const long long blocks = ((long long)a.B * a.heads + 1) / 2;
+  CVMI_CHECK(blocks > 0 && blocks < (1ll << 31), "attention: bad grid");
+  hipLaunchKernelGGL(attn_res64_kernel<QT>, dim3((unsigned)blocks), dim3(QT * 128), lds, stream, a);
+  CVMI_LAUNCH_CHECK();
+  return 0;
+}
+
 // ---- long sequences of head_dim 72 (Hiera global attention): the same inner loop, K / V streamed through two 64-key
 //      LDS buffers by DMA (no staging registers: 4 waves per SIMD); one barrier per tile publishes tile t + 1 while it
 //      drains, issued a full tile of MFMAs earlier.  Rows past Nk re-read the last key (finite; their scores are masked).
@@ -1261,6 +1446,9 @@ extern "C" int cvmi_attention(const cvmi_attn_desc* d, cvmi_stream_t stream_) {
   static const int use_res256 = getenv("CVMI_ATTN_RES256") ? atoi(getenv("CVMI_ATTN_RES256")) : 2;      // tuning experiments only: 0 off, 1 four waves, 2 eight waves (4 per SIMD at 125 VGPRs)
   if (use_res256 && d->Nk == 256 && d->dqk == 72 && d->dv == 72 && d->k_st % 8 == 0 && d->v_st % 8 == 0)
     return (use_res256 == 2 && a.qtiles >= 8) ? launch_res256<8>(a, stream) : launch_res256<4>(a, stream);
+  static const int use_res64 = getenv("CVMI_ATTN_RES64") ? atoi(getenv("CVMI_ATTN_RES64")) : 1;          // tuning experiments only
+  if (use_res64 && d->Nk == 64 && d->dqk == 72 && d->dv == 72 && d->k_st % 8 == 0 && d->v_st % 8 == 0 && (a.qtiles == 1 || a.qtiles == 2))
+    return a.qtiles == 2 ? launch_res64<2>(a, stream) : launch_res64<1>(a, stream);
   static const int use_dma72 = getenv("CVMI_ATTN_DMA72") ? atoi(getenv("CVMI_ATTN_DMA72")) : 1;          // tuning experiments only
   if (use_dma72 && d->Nk >= 512 && a.qtiles >= 8 && d->dqk == 72 && d->dv == 72 && d->k_st % 8 == 0 && d->v_st % 8 == 0 && !d->q_pool)
     return launch_dma72<8>(a, stream);
