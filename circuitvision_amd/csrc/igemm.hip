@@ -437,15 +437,21 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_glds_kernel(const ConvKA
 
   // per-lane source pointers of this wave's pieces (k advances by one tile per iteration)
   const char* src[PIECES / NW];
+  int adj[PIECES / NW];
+  const int nk = (p.K + BK - 1) / BK, krem = p.K % BK;
 #pragma unroll
   for (int i = 0; i < PIECES / NW; ++i) {
     const int piece = wv * (PIECES / NW) + i;
     const int row = piece * 8 + (lane >> 3);                    // row inside the stage: [0, BM) = A, [BM, BM+BN) = W
     const int slot = (lane & 7) ^ ((row >> 1) & 7);             // logical 16-byte chunk that lands in physical slot lane & 7
+    adj[i] = 0;
     if (row < BM) {
       int m = m0 + row;
       m = m < p.M ? m : p.M - 1;                                // tail rows: any valid row (never stored)
       src[i] = p.x0 + ((size_t)m * p.x0_ld + slot * VEC) * ES;
+      // K not a multiple of the tile depth: the last tile's out-of-row chunks re-read the previous tile's chunk (finite data
+      // against the zero-padded weight columns [K, Kpad)), see gemm256_kernel
+      if (krem && slot * VEC >= krem) adj[i] = -BKB;
     } else {
       src[i] = p.w + ((size_t)(n0 + row - BM) * p.Kpad + slot * VEC) * ES;
     }
@@ -454,7 +460,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_glds_kernel(const ConvKA
 #pragma unroll
     for (int i = 0; i < PIECES / NW; ++i) {
       const int piece = wv * (PIECES / NW) + i;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + (size_t)kt * BKB),
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + (long long)kt * BKB + (kt == nk - 1 ? (long long)adj[i] : 0ll)),
                                        (__attribute__((address_space(3))) void*)(smem + stage * STAGE + piece * 1024), 16, 0, 0);
     }
   };
@@ -474,7 +480,6 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_glds_kernel(const ConvKA
 #pragma unroll
   for (int i = 0; i < TN; ++i) { const int row = BM + wn * WTN + i * 32 + lr; w_off[i] = row * BKB; w_sw[i] = (row >> 1) & 7; }
 
-  const int nk = p.K / BK;
   issue(0, 0);
   __syncthreads();
   for (int kt = 0; kt < nk; ++kt) {
@@ -1346,7 +1351,9 @@ int launch_typed(ConvKArgs& a, hipStream_t stream) {
         return launch_g256x192<TO>(a, stream);
     }
   }
-  if (use_glds && a.plain && (a.K * (int)sizeof(T)) % 128 == 0 && a.K * (int)sizeof(T) >= 256 && N >= 96 &&
+  // (K not a multiple of the 128-byte tile: only from K = 256 elements up -- at K = 144 the padded third tile costs more than the DMA saves)
+  if (use_glds && a.plain && a.K % (16 / (int)sizeof(T)) == 0 && (a.Kpad * (int)sizeof(T)) % 128 == 0 && a.K * (int)sizeof(T) >= 256 &&
+      ((a.K * (int)sizeof(T)) % 128 == 0 || a.K >= 256) && N >= 96 &&
       (long long)cdiv(M, 128) * cdiv(N, 128) >= 512) {                                 // large GEMMs only: small grids need the smaller tiles below
     if (use_glds == 2 || N <= 640) return launch_glds<T, TO, 128, 64, 2, 2>(a, stream);      // measured: wins up to N = 576
     return launch_glds<T, TO, 128, 128, 2, 2>(a, stream);

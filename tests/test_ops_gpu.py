@@ -268,6 +268,8 @@ def test_graph_capture_replays_identically():
     (25600, 1160, 256, False, _lib.ACT_RELU),     # ragged N, f16 output
     (8192, 2048, 288, False, _lib.ACT_NONE),      # K = 4.5 K-tiles: the last tile's out-of-row chunks re-read valid data (zero weights)
     (8192, 2048, 264, True, _lib.ACT_NONE),       # K % 64 = 8
+    (65536, 288, 288, True, _lib.ACT_NONE),       # 128 x 64 DMA kernel with a ragged K (Hiera stage-2 proj)
+    (65536, 144, 264, False, _lib.ACT_NONE),      # same kernel, f16 output, K % 64 = 8
     (65536, 576, 1160, True, _lib.ACT_NONE),      # 256 x 192 tiles with a ragged K
     (65536, 576, 1152, True, _lib.ACT_NONE),      # 256 x 192 tiles (N = 3 x 192, deep K): f32 + residual, 18 K-tiles
     (65536, 384, 1088, False, _lib.ACT_GELU),     # 256 x 192 tiles, f16 output, odd number of K-tiles (17)
