@@ -105,9 +105,9 @@ __device__ __forceinline__ u32x4 gather_chunk(const ConvKArgs& p, int k, int b, 
 
 // ---- shared epilogue: bias + act in registers -> LDS tile [BM][BN] (TO) -> coalesced 16-byte stores (+ residual,
 //      batch-broadcast residual, activation-after-residual, ConvTranspose scatter) -----------------------------------
-template <typename T, typename TO, int BM, int BN, int WM, int WN>
+template <typename T, typename TO, int BM, int BN, int WM, int WN, int KS = 1>
 __device__ __forceinline__ void gemm_epilogue(const ConvKArgs& p, f32x16 (&acc)[BN / WN / 32][BM / WM / 32], char* smem, int m0, int n0) {
-  constexpr int NT = WM * WN * 64;
+  constexpr int NT = WM * WN * 64 * KS;             // KS > 1 (intra-workgroup split-K): the first WM*WN waves hold the reduced tile, all waves store
   constexpr int WTM = BM / WM, WTN = BN / WN;
   constexpr int TM = WTM / 32, TN = WTN / 32;
   constexpr int OES = sizeof(TO);
@@ -137,6 +137,7 @@ __device__ __forceinline__ void gemm_epilogue(const ConvKArgs& p, f32x16 (&acc)[
       rv[it] = *reinterpret_cast<const u32x4*>(p.res + (rpix * p.res_ld + n0 + ch * OVEC) * OES);
     }
   }
+  if (KS == 1 || tid < WM * WN * 64)
   with_act<FAST>(p.act_after_res ? CVMI_ACT_NONE : p.act, [&](auto actf) {
 #pragma unroll
     for (int i = 0; i < TN; ++i) {
@@ -234,8 +235,12 @@ __device__ __forceinline__ void gemm_epilogue(const ConvKArgs& p, f32x16 (&acc)[
   }
 }
 
-template <typename T, typename TO, int BM, int BN, int WM, int WN, int BKB, bool PLAIN>
-__global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8 ? 4 : (BM * BN >= 128 * 128 ? 2 : 3))) void igemm_kernel(const ConvKArgs p) {
+// KS > 1: intra-workgroup split-K for grids that cannot fill the chip (M = B*20*20 or B*40*40 with a deep K): KS groups of
+// WM*WN waves walk disjoint K ranges of the same output tile in lock step, each with its own pair of LDS stages, so a CU
+// has KS times the loads in flight and the dependent global -> LDS -> MFMA chain is KS times shorter; the partial tiles
+// are summed through LDS in a fixed order (deterministic) before the common epilogue.
+template <typename T, typename TO, int BM, int BN, int WM, int WN, int BKB, bool PLAIN, int KS = 1>
+__global__ __launch_bounds__(WM * WN * 64 * KS, (KS > 1 ? 4 : WM * WN == 8 ? 4 : (BM * BN >= 128 * 128 ? 2 : 3))) void igemm_kernel(const ConvKArgs p) {
   // BKB = data bytes per LDS row per K-tile (64 or 128); PLAIN = 1x1 / stride 1 / one source: A is a plain
   // row-major matrix, so the per-tile gather arithmetic collapses to "row pointer + k"
   constexpr int ES = sizeof(T);
@@ -254,10 +259,11 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8 ? 4 : (BM * BN >= 128 *
   constexpr int CROWB = BN * OES + 16;    // epilogue tile row stride (bytes)
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* const As = smem;                          // pixels  [2][BM][ROWB]
-  char* const Bs = smem + 2 * BM * ROWB;          // weights [2][BN][ROWB]
+  const int kg = KS > 1 ? __builtin_amdgcn_readfirstlane((int)threadIdx.x / NT) : 0;     // K group of this wave
+  char* const As = smem + kg * (2 * (BM + BN) * ROWB);   // pixels  [2][BM][ROWB]
+  char* const Bs = As + 2 * BM * ROWB;                    // weights [2][BN][ROWB]
 
-  const int tid = threadIdx.x;
+  const int tid = KS > 1 ? (int)threadIdx.x % NT : (int)threadIdx.x;      // thread index inside the K group
   // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (private L2 each), so give every XCD a
   // CONTIGUOUS run of tiles -- the nb_n column tiles that share one pixel/row tile then hit the same L2 instead of
   // each XCD fetching that A tile again from the Infinity Cache (bijective for any grid size; speed only).
@@ -386,20 +392,66 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8 ? 4 : (BM * BN >= 128 *
 
   // register-staged double buffer: tile t+1 is loaded while tile t is computed, then written to the other LDS buffer
   // (a second register stage was measured: no gain at equal occupancy, and its registers cost a wave per SIMD)
-  const int nk = p.Kpad / BK;
-  Stage st;
-  load_tile(st, 0);
-  store_tile(st, 0);
-  __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
-    const int buf = kt & 1;
-    if (kt + 1 < nk) load_tile(st, kt + 1);
-    compute(buf);
-    if (kt + 1 < nk) store_tile(st, buf ^ 1);
+  const int nkt = p.Kpad / BK;
+  if constexpr (KS == 1) {
+    Stage st;
+    load_tile(st, 0);
+    store_tile(st, 0);
     __syncthreads();
+    for (int kt = 0; kt < nkt; ++kt) {
+      const int buf = kt & 1;
+      if (kt + 1 < nkt) load_tile(st, kt + 1);
+      compute(buf);
+      if (kt + 1 < nkt) store_tile(st, buf ^ 1);
+      __syncthreads();
+    }
+  } else {
+    const int nkg = (nkt + KS - 1) / KS;                      // K-tiles per group (the last group may have fewer)
+    const int kt0 = kg * nkg;
+    const int kend = kt0 + nkg < nkt ? kt0 + nkg : nkt;
+    if (!PLAIN && fastg) {                                    // (tap, channel base) of this group's first tile
+      const int k0 = kt0 * BK;
+      const int tap = k0 / p.ctot;
+      g_cb = k0 - tap * p.ctot;
+      g_ky = tap / p.KW;
+      g_kx = tap - g_ky * p.KW;
+    }
+    Stage st;
+    if (kt0 < kend) { load_tile(st, kt0); store_tile(st, 0); }
+    __syncthreads();
+    for (int i = 0; i < nkg; ++i) {                           // every group runs nkg rounds: the barriers are workgroup-wide
+      const int kt = kt0 + i, buf = i & 1;
+      if (kt + 1 < kend) load_tile(st, kt + 1);
+      if (kt < kend) compute(buf);
+      if (kt + 1 < kend) store_tile(st, buf ^ 1);
+      __syncthreads();
+    }
+    // fixed-order reduction of the partial tiles: groups 1.. park their accumulators (lane-contiguous), group 0 adds them
+    float* const red = reinterpret_cast<float*>(smem);
+    constexpr int REGS = TN * TM * 16;
+    if (kg > 0) {
+#pragma unroll
+      for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) red[((kg - 1) * REGS + (i * TM + j) * 16 + r) * NT + tid] = acc[i][j][r];
+    }
+    __syncthreads();
+    if (kg == 0) {
+#pragma unroll
+      for (int g = 1; g < KS; ++g)
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+#pragma unroll
+          for (int j = 0; j < TM; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] += red[((g - 1) * REGS + (i * TM + j) * 16 + r) * NT + tid];
+    }
+    __syncthreads();                                          // the epilogue tile overlays the parked partials
   }
 
-  gemm_epilogue<T, TO, BM, BN, WM, WN>(p, acc, smem, m0, n0);
+  gemm_epilogue<T, TO, BM, BN, WM, WN, KS>(p, acc, smem, m0, n0);
 }
 
 // ---- plain GEMM with direct-to-LDS staging -------------------------------------------------------------------
@@ -1285,29 +1337,62 @@ int launch_g256(ConvKArgs& a, hipStream_t stream, int stagger) {
   return 0;
 }
 
-template <typename T, typename TO, int BM, int BN, int WM, int WN, int BKB, bool PLAIN>
+template <typename T, typename TO, int BM, int BN, int WM, int WN, int BKB, bool PLAIN, int KS = 1>
 int launch_cfg2(ConvKArgs& a, hipStream_t stream) {
   constexpr int ROWB = BKB + 16;
-  constexpr size_t stage = (size_t)2 * (BM + BN) * ROWB;
+  constexpr size_t stage = (size_t)2 * (BM + BN) * ROWB * KS;
   constexpr size_t epi = (size_t)BM * (BN * sizeof(TO) + 16);
-  constexpr size_t lds = stage > epi ? stage : epi;
+  constexpr size_t red = (size_t)(KS - 1) * BM * BN * sizeof(float);
+  constexpr size_t lds0 = stage > epi ? stage : epi;
+  constexpr size_t lds = lds0 > red ? lds0 : red;
+  static_assert(lds <= 160 * 1024, "workgroup LDS");
   static bool attr_done = false;
   if (!attr_done && lds > 64 * 1024) {
-    CVMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<T, TO, BM, BN, WM, WN, BKB, PLAIN>),
+    CVMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<T, TO, BM, BN, WM, WN, BKB, PLAIN, KS>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_done = true;
   }
   a.nb_n = cdiv(a.N, BN);
   const long long blocks = (long long)cdiv(a.M, BM) * a.nb_n;
   CVMI_CHECK(blocks > 0 && blocks < (1ll << 31), "conv2d: bad grid %lld", blocks);
-  hipLaunchKernelGGL((igemm_kernel<T, TO, BM, BN, WM, WN, BKB, PLAIN>), dim3((unsigned)blocks), dim3(WM * WN * 64), lds, stream, a);
+  hipLaunchKernelGGL((igemm_kernel<T, TO, BM, BN, WM, WN, BKB, PLAIN, KS>), dim3((unsigned)blocks), dim3(WM * WN * 64 * KS), lds, stream, a);
   CVMI_LAUNCH_CHECK();
   return 0;
+}
+
+// Intra-workgroup split-K (igemm_kernel KS > 1) for the f16 64-row tiles: grids of at most two workgroups per CU with a
+// deep K are latency chains (one wave per SIMD, every K-tile a dependent global -> LDS -> MFMA round trip).
+template <typename T, typename TO, int BM, int BN, int WM, int WN>
+int launch_ksplit(ConvKArgs& a, hipStream_t stream, int ks) {
+  if constexpr (sizeof(T) == 2 && sizeof(TO) == 2 && BM == 64 && WM * WN == 4) {
+    const bool plain = a.plain != 0;
+    if (ks == 4) return plain ? launch_cfg2<T, TO, BM, BN, WM, WN, 64, true, 4>(a, stream) : launch_cfg2<T, TO, BM, BN, WM, WN, 64, false, 4>(a, stream);
+    if (ks == 2) return plain ? launch_cfg2<T, TO, BM, BN, WM, WN, 64, true, 2>(a, stream) : launch_cfg2<T, TO, BM, BN, WM, WN, 64, false, 2>(a, stream);
+  }
+  return -1;
 }
 
 template <typename T, typename TO, int BM, int BN, int WM, int WN>
 int launch_cfg(ConvKArgs& a, hipStream_t stream) {
   const bool plain = a.plain != 0;
+  if constexpr (sizeof(T) == 2 && sizeof(TO) == 2 && BM == 64 && WM * WN == 4) {
+    static const int ks_env = getenv("CVMI_KSPLIT") ? atoi(getenv("CVMI_KSPLIT")) : -1;        // tuning experiments only: 0 off, 2 / 4 forced
+    static const int ks4_mink = getenv("CVMI_KS4_MINK") ? atoi(getenv("CVMI_KS4_MINK")) : 32;
+    static const int ks2_mink = getenv("CVMI_KS2_MINK") ? atoi(getenv("CVMI_KS2_MINK")) : 12;
+    const long long blocks = (long long)cdiv(a.M, BM) * cdiv(a.N, BN);
+    const int nkt = a.Kpad / 32;                                                              // 64-byte K-tiles
+    // measured on the YOLO11-n B=32 layers (us, 1 / 2 / 4 groups): Detect cv2.2.0 (200 tiles of 64x64, 72 K-tiles) 51 / 34 / 28;
+    // model.20 (200 of 64x128, 36) 31 / 23 / 25; model.7 (400 of 64x128, 36) 33 / 27 / 39 (four groups of a 64x128 tile need
+    // 123 KB of LDS: one workgroup per CU); grids above two workgroups per CU lose (model.5: 47 / 52)
+    int ks = 1;
+    if (BN == 64 && blocks <= 256 && nkt >= ks4_mink) ks = 4;
+    else if (blocks <= 512 && nkt >= ks2_mink) ks = 2;
+    if (ks_env >= 0) ks = (ks_env == 2 || ks_env == 4) && nkt >= 2 * ks_env ? ks_env : 1;
+    if (ks > 1 && a.Kpad % 32 == 0) {
+      const int rc = launch_ksplit<T, TO, BM, BN, WM, WN>(a, stream, ks);
+      if (rc >= 0) return rc;
+    }
+  }
   // 128-byte K-tiles halve the barrier count; 64-byte tiles only when K is too short to fill one
   static const int force_bkb = getenv("CVMI_BKB") ? atoi(getenv("CVMI_BKB")) : 0;      // tuning experiments only
   // measured (tools/gemm_bench.py): 128-byte tiles pay for deep K (>= 2 KB per row: fewer barriers) and for rows
@@ -1351,10 +1436,11 @@ int launch_typed(ConvKArgs& a, hipStream_t stream) {
         return launch_g256x192<TO>(a, stream);
     }
   }
+  static const int glds_min_tiles = getenv("CVMI_GLDS_MINTILES") ? atoi(getenv("CVMI_GLDS_MINTILES")) : 512;   // tuning experiments only
   // (K not a multiple of the 128-byte tile: only from K = 256 elements up -- at K = 144 the padded third tile costs more than the DMA saves)
   if (use_glds && a.plain && a.K % (16 / (int)sizeof(T)) == 0 && (a.Kpad * (int)sizeof(T)) % 128 == 0 && a.K * (int)sizeof(T) >= 256 &&
       ((a.K * (int)sizeof(T)) % 128 == 0 || a.K >= 256) && N >= 96 &&
-      (long long)cdiv(M, 128) * cdiv(N, 128) >= 512) {                                 // large GEMMs only: small grids need the smaller tiles below
+      (long long)cdiv(M, 128) * cdiv(N, 128) >= glds_min_tiles) {                      // large GEMMs only: small grids need the smaller tiles below
     if (use_glds == 2 || N <= 640) return launch_glds<T, TO, 128, 64, 2, 2>(a, stream);      // measured: wins up to N = 576
     return launch_glds<T, TO, 128, 128, 2, 2>(a, stream);
   }

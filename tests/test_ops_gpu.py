@@ -70,6 +70,33 @@ def test_conv2d_direct_to_lds_gemm(dtype):
     _conv_case(dtype, 3, 128, 40, 40, 96, 1, 1, ACT_NONE)                   # exactly two tiles
 
 
+def test_conv2d_intra_workgroup_split_k():
+    """Small grids with a deep K (the 20x20 / 40x40 YOLO levels) split K over 2 or 4 wave groups of one workgroup."""
+    _conv_case(F16, 2, 256, 20, 20, 64, 3, 1, ACT_SILU)                   # Detect cv2 level 2: 72 K-tiles, 4 groups, N = 64 tile
+    _conv_case(F16, 2, 128, 40, 40, 256, 3, 2, ACT_SILU)                  # model.7: stride 2, 36 K-tiles, 64 x 128 tiles
+    _conv_case(F16, 1, 136, 19, 21, 72, 3, 1, ACT_RELU, res=True)         # K = 1224 -> 39 K-tiles (ragged last group), ragged M / N, slow gather, residual
+    _conv_case(F16, 3, 384, 20, 20, 128, 1, 1, ACT_SILU)                  # plain 1x1, 12 K-tiles: 2 groups
+    _conv_case(F16, 1, 1096, 10, 10, 40, 1, 1, ACT_NONE)                  # plain, 35 K-tiles over 4 groups (9,9,9,8), ragged N
+    # two sources (upsampled + skip) with a deep K: the fast gather restarts at each group's first tap
+    g = torch.Generator().manual_seed(11)
+    B, H, W = 2, 20, 20
+    a = quant(torch.randn(B, 256, H // 2, W // 2, generator=g), F16)
+    b = quant(torch.randn(B, 128, H, W, generator=g), F16)
+    w = quant(torch.randn(128, 384, 3, 3, generator=g) / 58, F16)
+    bias = torch.randn(128, generator=g)
+    ref = F.silu(F.conv2d(torch.cat((F.interpolate(a, scale_factor=2, mode="nearest"), b), 1), w, bias, padding=1))
+    ab, bb = to_buf(a, F16), to_buf(b, F16)
+    yb = Buf(B, H, W, 128, F16, zero=True)
+    outs = []
+    for _ in range(3):
+        plan = Plan(stream())
+        op_conv(plan, "t", PackedConv(w, bias, F16), [(ab.view(), 1), (bb.view(), 0)], yb.view(), act=ACT_SILU)
+        run(plan)
+        outs.append(yb.t.clone())
+    torch.testing.assert_close(from_view(yb.view()), ref, **TOL[F16])
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])   # fixed-order reduction: bit-identical reruns
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_conv2d_large_m_tiles(dtype):
     _conv_case(dtype, 2, 16, 264, 256, 16, 3, 2, ACT_SILU)      # M = 2*132*128 -> BM=256 config for N<=32? (M>=131072 not reached) still covers tails
