@@ -20,6 +20,7 @@ struct TileArgs {
   int Cin, H, W, OH, OW, N, Kpad, pad;
   int act;
   int tiles_x, tiles_y, nb_n;
+  int bias_off;                                    // LDS byte offset of the parked bias row
 };
 
 template <typename T> struct MmaT;
@@ -92,14 +93,17 @@ __global__ __launch_bounds__(256, (TH == 16 ? 2 : 3)) void conv_tile_kernel(cons
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const int nchunks = p.Cin / CC;
-  for (int cc = 0; cc < nchunks; ++cc) {
-    const int c0 = cc * CC;
-    if (cc) __syncthreads();                         // previous chunk fully consumed
-    // ---- stage the input patch (zero outside the image) and the weight slab [BN][taps][CC]: every global load of
-    //      the chunk is issued before the first LDS write, so the staging costs ONE memory round trip
-    constexpr int NP = (PH * PW * CCH + 255) / 256, NW = (BN * WCH + 255) / 256;
-    u32x4 pv[NP], wv_[NW];
-    bool pok[NP], wok[NW];                              // masks applied at LDS-write time (loads stay back to back)
+  // ---- staging: the input patch (zero outside the image) and the weight slab [BN][taps][CC] of a channel chunk; every
+  //      global load of the chunk is issued before the first LDS write (ONE memory round trip), and the NEXT chunk's
+  //      loads are issued before the MFMAs of the current one (register double buffer), so a small grid -- one workgroup
+  //      per CU at the 20x20 level -- does not pay a dependent round trip per chunk.  The bias row is fetched with the
+  //      first chunk and parked in LDS: the epilogue would otherwise start with one more dependent global load.
+  constexpr int NP = (PH * PW * CCH + 255) / 256, NW = (BN * WCH + 255) / 256;
+  u32x4 pv[NP], wv_[NW];
+  bool pok[NP], wok[NW];                              // masks applied at LDS-write time (loads stay back to back)
+  float* const bias_s = reinterpret_cast<float*>(smem + p.bias_off);
+  const float bias_v = tid < BN ? p.bias[n0 + tid] : 0.f;     // (bias is padded to the column tile)
+  auto load_chunk = [&](int c0) {
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
       const int id = tid + i * 256;
@@ -120,6 +124,8 @@ __global__ __launch_bounds__(256, (TH == 16 ? 2 : 3)) void conv_tile_kernel(cons
       wv_[i] = *reinterpret_cast<const u32x4*>(p.w + ((size_t)(n0 + (ok ? n : 0)) * p.Kpad + (ok ? tap * p.Cin + c0 + ch * VEC : 0)) * ES);
       wok[i] = ok;
     }
+  };
+  auto store_chunk = [&]() {
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
       const int id = tid + i * 256;
@@ -132,7 +138,14 @@ __global__ __launch_bounds__(256, (TH == 16 ? 2 : 3)) void conv_tile_kernel(cons
       const int n = id / WCH, r = id - n * WCH;
       if (id < BN * WCH) *reinterpret_cast<u32x4*>(wslab + n * WROW + r * 16) = wok[i] ? wv_[i] : u32x4{0u, 0u, 0u, 0u};
     }
+  };
+  load_chunk(0);
+  for (int cc = 0; cc < nchunks; ++cc) {
+    if (cc) __syncthreads();                         // previous chunk fully consumed
+    store_chunk();
+    if (cc == 0 && tid < BN) bias_s[tid] = bias_v;
     __syncthreads();
+    if (cc + 1 < nchunks) load_chunk((cc + 1) * CC);
     // ---- MFMA over taps x channel steps ---------------------------------------------------------------
     if constexpr (PAIR) {
 #pragma unroll
@@ -180,7 +193,7 @@ __global__ __launch_bounds__(256, (TH == 16 ? 2 : 3)) void conv_tile_kernel(cons
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int nl = wn * WTN + i * 32 + 8 * q + 4 * lh;
-        const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + n0 + nl);
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(bias_s + nl);
 #pragma unroll
         for (int j = 0; j < TM; ++j) {
           const int ml = wm * WTM + j * 32 + lr;
@@ -242,7 +255,9 @@ int launch_tile(TileArgs& a, int B, hipStream_t stream) {
   constexpr int WROW = WDATA + ((WDATA / 16) % 2 == 0 ? 16 : 32);
   constexpr size_t stage = (size_t)PH * PW * (CC * ES + 16) + (size_t)BN * WROW;
   constexpr size_t epi = (size_t)BMT * (BN * ES + 16);
-  constexpr size_t lds = stage > epi ? stage : epi;
+  constexpr size_t lds0 = ((stage > epi ? stage : epi) + 15) / 16 * 16;
+  constexpr size_t lds = lds0 + BN * sizeof(float);           // + the parked bias row
+  a.bias_off = (int)lds0;
   static bool attr_done = false;
   if (!attr_done && lds > 64 * 1024) {
     CVMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_tile_kernel<T, KS, S, CC, BN, WM, WN, TH>),

@@ -34,6 +34,7 @@ struct ConvKArgs {
   int res_mod, act_after_res, shuf_c, res_rep;
   int plain;
   int nb_n;
+  int bias_off;                          // igemm_kernel: LDS byte offset of the parked bias row
   FastDiv div_ctot, div_kw;
 };
 
@@ -106,7 +107,8 @@ __device__ __forceinline__ u32x4 gather_chunk(const ConvKArgs& p, int k, int b, 
 // ---- shared epilogue: bias + act in registers -> LDS tile [BM][BN] (TO) -> coalesced 16-byte stores (+ residual,
 //      batch-broadcast residual, activation-after-residual, ConvTranspose scatter) -----------------------------------
 template <typename T, typename TO, int BM, int BN, int WM, int WN, int KS = 1>
-__device__ __forceinline__ void gemm_epilogue(const ConvKArgs& p, f32x16 (&acc)[BN / WN / 32][BM / WM / 32], char* smem, int m0, int n0) {
+__device__ __forceinline__ void gemm_epilogue(const ConvKArgs& p, f32x16 (&acc)[BN / WN / 32][BM / WM / 32], char* smem, int m0, int n0,
+                                              const float* bias_lds = nullptr) {
   constexpr int NT = WM * WN * 64 * KS;             // KS > 1 (intra-workgroup split-K): the first WM*WN waves hold the reduced tile, all waves store
   constexpr int WTM = BM / WM, WTN = BN / WN;
   constexpr int TM = WTM / 32, TN = WTN / 32;
@@ -144,7 +146,8 @@ __device__ __forceinline__ void gemm_epilogue(const ConvKArgs& p, f32x16 (&acc)[
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int nl = wn * WTN + i * 32 + 8 * q + 4 * lh;      // 4 consecutive channels
-        const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + n0 + nl);
+        // (bias_lds: the tile's bias row parked in LDS by the caller -- no dependent global load after the K loop)
+        const f32x4 bv = bias_lds ? *reinterpret_cast<const f32x4*>(bias_lds + nl) : *reinterpret_cast<const f32x4*>(p.bias + n0 + nl);
 #pragma unroll
         for (int j = 0; j < TM; ++j) {
           const int ml = wm * WTM + j * 32 + lr;
@@ -393,10 +396,14 @@ __global__ __launch_bounds__(WM * WN * 64 * KS, (KS > 1 ? 4 : WM * WN == 8 ? 4 :
   // register-staged double buffer: tile t+1 is loaded while tile t is computed, then written to the other LDS buffer
   // (a second register stage was measured: no gain at equal occupancy, and its registers cost a wave per SIMD)
   const int nkt = p.Kpad / BK;
+  // the tile's bias row rides along with the first K-tile and is parked in LDS behind the stages / epilogue tile
+  float* const bias_s = reinterpret_cast<float*>(smem + p.bias_off);
+  const float bias_v = (int)threadIdx.x < BN ? p.bias[n0 + (int)threadIdx.x] : 0.f;      // (bias is padded to 128 columns)
   if constexpr (KS == 1) {
     Stage st;
     load_tile(st, 0);
     store_tile(st, 0);
+    if ((int)threadIdx.x < BN) bias_s[threadIdx.x] = bias_v;
     __syncthreads();
     for (int kt = 0; kt < nkt; ++kt) {
       const int buf = kt & 1;
@@ -418,6 +425,7 @@ __global__ __launch_bounds__(WM * WN * 64 * KS, (KS > 1 ? 4 : WM * WN == 8 ? 4 :
     }
     Stage st;
     if (kt0 < kend) { load_tile(st, kt0); store_tile(st, 0); }
+    if ((int)threadIdx.x < BN) bias_s[threadIdx.x] = bias_v;
     __syncthreads();
     for (int i = 0; i < nkg; ++i) {                           // every group runs nkg rounds: the barriers are workgroup-wide
       const int kt = kt0 + i, buf = i & 1;
@@ -451,7 +459,7 @@ __global__ __launch_bounds__(WM * WN * 64 * KS, (KS > 1 ? 4 : WM * WN == 8 ? 4 :
     __syncthreads();                                          // the epilogue tile overlays the parked partials
   }
 
-  gemm_epilogue<T, TO, BM, BN, WM, WN, KS>(p, acc, smem, m0, n0);
+  gemm_epilogue<T, TO, BM, BN, WM, WN, KS>(p, acc, smem, m0, n0, bias_s);
 }
 
 // ---- plain GEMM with direct-to-LDS staging -------------------------------------------------------------------
@@ -1344,8 +1352,10 @@ int launch_cfg2(ConvKArgs& a, hipStream_t stream) {
   constexpr size_t epi = (size_t)BM * (BN * sizeof(TO) + 16);
   constexpr size_t red = (size_t)(KS - 1) * BM * BN * sizeof(float);
   constexpr size_t lds0 = stage > epi ? stage : epi;
-  constexpr size_t lds = lds0 > red ? lds0 : red;
+  constexpr size_t lds1 = ((lds0 > red ? lds0 : red) + 15) / 16 * 16;
+  constexpr size_t lds = lds1 + BN * sizeof(float);           // + the parked bias row
   static_assert(lds <= 160 * 1024, "workgroup LDS");
+  a.bias_off = (int)lds1;
   static bool attr_done = false;
   if (!attr_done && lds > 64 * 1024) {
     CVMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<T, TO, BM, BN, WM, WN, BKB, PLAIN, KS>),
