@@ -40,6 +40,16 @@ class C3k2Desc(C.Structure):
     ]
 
 
+class DwPwDesc(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p), ("y", C.c_void_p), ("wd", C.c_void_p), ("bd", C.c_void_p),
+        ("w1", C.c_void_p), ("b1", C.c_void_p), ("w2", C.c_void_p), ("b2", C.c_void_p),
+        ("x_ld", C.c_int), ("y_ld", C.c_int), ("kpad1", C.c_int), ("kpad2", C.c_int),
+        ("B", C.c_int), ("H", C.c_int), ("W", C.c_int), ("C", C.c_int), ("N1", C.c_int), ("N2", C.c_int),
+        ("dtype", C.c_int),
+    ]
+
+
 class AttnDesc(C.Structure):
     _fields_ = [
         ("q", C.c_void_p), ("k", C.c_void_p), ("v", C.c_void_p), ("o", C.c_void_p),
@@ -66,6 +76,8 @@ SIGNATURES = {
     "cvmi_conv2d": (_i, [C.POINTER(ConvDesc), _vp]),
     "cvmi_c3k2_supported": (_i, [_i, _i, _i, _i, _i, _i]),
     "cvmi_c3k2": (_i, [C.POINTER(C3k2Desc), _vp]),
+    "cvmi_dwpw_supported": (_i, [_i, _i, _i, _i]),
+    "cvmi_dwpw": (_i, [C.POINTER(DwPwDesc), _vp]),
     "cvmi_dwconv3x3": (_i, [_vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "cvmi_sppf_pool": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp]),
     "cvmi_attention": (_i, [C.POINTER(AttnDesc), _vp]),

@@ -274,6 +274,31 @@ def op_c3k2(plan, label, src, dst, pc_cv1, pc_m1, pc_m2, pc_cv2, c, h, fuse_cv1,
     plan.add(label, "conv", thunk, px * (src.c + dst.c) * ESIZE[pc_cv2.dtype], flops)
 
 
+def dwpw_supported(C_, n1, n2, dtype):
+    return bool(_lib.load().cvmi_dwpw_supported(C_, n1, n2, dtype))
+
+
+def op_dwpw(plan, label, pd, pc1, src, dst, pc2=None):
+    """Fused DWConv3x3+SiLU -> Conv1x1+SiLU (-> Conv2d 1x1, no activation, when pc2 is given): one launch."""
+    lib = _lib.load()
+    assert src.c == pd.C == pc1.Cin and (src.B, src.H, src.W) == (dst.B, dst.H, dst.W)
+    assert dst.c == (pc2.N if pc2 is not None else pc1.N) and (pc2 is None or pc2.Cin == pc1.N)
+    d = _lib.DwPwDesc(x=src.ptr, y=dst.ptr, wd=pd.w.data_ptr(), bd=pd.bias.data_ptr(), w1=pc1.w.data_ptr(), b1=pc1.bias.data_ptr(),
+                      w2=pc2.w.data_ptr() if pc2 is not None else None, b2=pc2.bias.data_ptr() if pc2 is not None else None,
+                      x_ld=src.ld, y_ld=dst.ld, kpad1=pc1.Kpad, kpad2=pc2.Kpad if pc2 is not None else 0,
+                      B=src.B, H=src.H, W=src.W, C=pd.C, N1=pc1.N, N2=pc2.N if pc2 is not None else 0, dtype=pc1.dtype)
+    plan.keep.append((d, pd, pc1, pc2, src, dst))
+    sp0, fn = plan.sptr, lib.cvmi_dwpw
+
+    def thunk(sp=None):
+        sp = sp0 if sp is None else sp
+        _lib.check(fn(C.byref(d), sp), label)
+
+    px = src.B * src.H * src.W
+    flops = px * (18 * pd.C + 2 * pd.C * pc1.N + (2 * pc1.N * pc2.N if pc2 is not None else 0))
+    plan.add(label, "head", thunk, px * (src.c + dst.c) * ESIZE[pc1.dtype], flops)
+
+
 def op_dwconv(plan, label, pd, src, dst, act=_lib.ACT_NONE, res=None):
     lib = _lib.load()
     assert src.c == pd.C == dst.c and (src.B, src.H, src.W) == (dst.B, dst.H, dst.W)

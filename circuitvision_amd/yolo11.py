@@ -21,7 +21,8 @@ import torch
 
 from . import _lib
 from ._lib import ACT_NONE, ACT_SILU, F16, F32
-from .engine import (ESIZE, Buf, PackedConv, PackedDW, Plan, c3k2_supported, make_attn_desc, op_attention, op_c3k2, op_call, op_conv,
+from .engine import (ESIZE, Buf, PackedConv, PackedDW, Plan, c3k2_supported, dwpw_supported, make_attn_desc, op_attention, op_c3k2, op_call, op_conv,
+                     op_dwpw,
                      op_dwconv, op_sppf_pool)
 
 SCALES = {"n": (0.50, 0.25, 1024), "s": (0.50, 0.50, 1024), "m": (0.50, 1.00, 512),
@@ -235,6 +236,7 @@ class Yolo11Plan:
         best class straight from the decode kernel); the detections are identical."""
         self.keep_scores = keep_scores
         self.fuse_c3k2 = fuse_c3k2 and os.environ.get("CVMI_FUSE_C3K2", "1") != "0"
+        self.fuse_dwpw = fuse_c3k2 and os.environ.get("CVMI_FUSE_DWPW", "1") != "0"
         assert H % 32 == 0 and W % 32 == 0, "network input must be a multiple of stride 32"
         self.wt, self.B, self.H, self.W = weights, B, H, W
         self.dt, self.dev = weights.dtype, weights.device
@@ -394,17 +396,24 @@ class Yolo11Plan:
         self.cv(f"model.23.cv2.{i}.1", t1, t2, 3, kind="head")
         self.cv(f"model.23.cv2.{i}.2", t2, bx, act=ACT_NONE, kind="head")
         self.plan.lane(2 * i + 2)
-        d1 = self.buf(f.H, f.W, f.c).view()
-        op_dwconv(self.plan, f"model.23.cv3.{i}.0.0", wt.packed[f"model.23.cv3.{i}.0.0"], f, d1, act=ACT_SILU)
-        u1 = self.buf(f.H, f.W, c3).view()
-        self.cv(f"model.23.cv3.{i}.0.1", d1, u1, kind="head")
-        d2 = self.buf(f.H, f.W, c3).view()
-        op_dwconv(self.plan, f"model.23.cv3.{i}.1.0", wt.packed[f"model.23.cv3.{i}.1.0"], u1, d2, act=ACT_SILU)
-        u2 = self.buf(f.H, f.W, c3).view()
-        self.cv(f"model.23.cv3.{i}.1.1", d2, u2, kind="head")
         cl = Buf(self.B, f.H, f.W, ncp, self.dt, self.dev, zero=True)
         self.act_bytes += cl.nbytes
-        self.cv(f"model.23.cv3.{i}.2", u2, cl.view(0, nc), act=ACT_NONE, kind="head")
+        u1 = self.buf(f.H, f.W, c3).view()
+        pk = wt.packed
+        if self.fuse_dwpw and dwpw_supported(f.c, c3, 0, self.dt) and dwpw_supported(c3, c3, nc, self.dt):
+            # class branch in two launches: [dw3x3 + 1x1], [dw3x3 + 1x1 + class 1x1]; the intermediates stay in LDS
+            op_dwpw(self.plan, f"model.23.cv3.{i}.0", pk[f"model.23.cv3.{i}.0.0"], pk[f"model.23.cv3.{i}.0.1"], f, u1)
+            op_dwpw(self.plan, f"model.23.cv3.{i}.1-2", pk[f"model.23.cv3.{i}.1.0"], pk[f"model.23.cv3.{i}.1.1"], u1, cl.view(0, nc),
+                    pc2=pk[f"model.23.cv3.{i}.2"])
+        else:
+            d1 = self.buf(f.H, f.W, f.c).view()
+            op_dwconv(self.plan, f"model.23.cv3.{i}.0.0", pk[f"model.23.cv3.{i}.0.0"], f, d1, act=ACT_SILU)
+            self.cv(f"model.23.cv3.{i}.0.1", d1, u1, kind="head")
+            d2 = self.buf(f.H, f.W, c3).view()
+            op_dwconv(self.plan, f"model.23.cv3.{i}.1.0", pk[f"model.23.cv3.{i}.1.0"], u1, d2, act=ACT_SILU)
+            u2 = self.buf(f.H, f.W, c3).view()
+            self.cv(f"model.23.cv3.{i}.1.1", d2, u2, kind="head")
+            self.cv(f"model.23.cv3.{i}.2", u2, cl.view(0, nc), act=ACT_NONE, kind="head")
         self._det_boxes.append(bx)
         self._det_cls.append(cl)
         self.plan.lane(0)

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define CVMI_VERSION 101
+#define CVMI_VERSION 102
 
 typedef void* cvmi_stream_t; /* hipStream_t */
 
@@ -101,6 +101,25 @@ typedef struct {
 } cvmi_c3k2_desc;
 int cvmi_c3k2_supported(int c1, int c, int h, int c2, int fuse_cv1, int dtype);
 int cvmi_c3k2(const cvmi_c3k2_desc* d, cvmi_stream_t stream);
+
+/* ---- fused depthwise 3x3 + pointwise 1x1 (+ chained 1x1): YOLO11 Detect class branch ---------
+ * Replaces, inside YOLO.predict (circuit_analyzer.py:268), the ultralytics Detect.cv3[i] sub-chains
+ *   N2 == 0:  y = SiLU(pw1 * SiLU(dw (*) x))                       [DWConv(C, C, 3), Conv(C, N1, 1)]
+ *   N2 >  0:  y = w2 * SiLU(pw1 * SiLU(dw (*) x)) + b2             [... , Conv2d(N1, N2, 1)] (class logits, no activation)
+ * in one launch each (intermediates stay in LDS).  wd / bd: cvmi_dwconv3x3 layout ([9][C] tap-major, bias [C]);
+ * w1 / b1, w2 / b2: cvmi_conv2d-packed ([Npad >= 128][kpad], zero padded, BN folded).  Only the first N2 (or N1)
+ * channels of a y pixel are written.  cvmi_dwpw_supported() tells which (C, N1, N2) are built (fp16 only). */
+typedef struct {
+  const void* x; void* y;
+  const void* wd; const float* bd;
+  const void* w1; const float* b1;
+  const void* w2; const float* b2;
+  int x_ld, y_ld, kpad1, kpad2;
+  int B, H, W, C, N1, N2;
+  int dtype;
+} cvmi_dwpw_desc;
+int cvmi_dwpw_supported(int C, int N1, int N2, int dtype);
+int cvmi_dwpw(const cvmi_dwpw_desc* d, cvmi_stream_t stream);
 
 /* ---- depthwise 3x3 stride-1 conv + bias + act (YOLO Detect cls branch, C2PSA pe) -------------
  * w: [9][C] (tap-major), bias [C] f32.  Replaces ultralytics DWConv inside YOLO.predict. */

@@ -170,6 +170,46 @@ def test_dwconv3x3(dtype):
     torch.testing.assert_close(from_view(yb.view()), ref, **TOL[dtype])
 
 
+@pytest.mark.parametrize("cfg", [
+    # B, C, H, W, N1, N2
+    (2, 64, 24, 32, 80, 0),        # one 64-channel chunk, whole tiles
+    (3, 128, 20, 20, 80, 0),       # two chunks, ragged tiles (20 = 2.5 x 8 rows, 1.25 x 16 columns)
+    (1, 256, 13, 21, 80, 0),       # four chunks, odd sizes
+    (2, 80, 20, 20, 80, 62),       # chained class conv: ragged channel tail (62 of 64), padding lanes untouched
+    (1, 80, 40, 40, 80, 62),
+    (2, 64, 9, 17, 72, 0),         # N1 < 80
+    (2, 128, 20, 20, 64, 0),       # 64-column pointwise tile (YOLO11-n with nc <= 64: c3 = 64)
+    (2, 64, 40, 40, 64, 62),       # chained class conv on the 64-column tile
+])
+def test_dwpw_fused_detect_class_branch(cfg):
+    """DWConv3x3+SiLU -> Conv1x1+SiLU (-> Conv2d 1x1) in one launch vs the fp32 statement (ultralytics Detect.cv3)."""
+    from circuitvision_amd.engine import dwpw_supported, op_dwpw
+    B, C_, H, W, N1, N2 = cfg
+    assert dwpw_supported(C_, N1, N2, F16)
+    g = torch.Generator().manual_seed(7)
+    x = quant(torch.randn(B, C_, H, W, generator=g), F16)
+    wd = quant(torch.randn(C_, 1, 3, 3, generator=g) / 3, F16)
+    bd = torch.randn(C_, generator=g) * 0.3
+    w1 = quant(torch.randn(N1, C_, 1, 1, generator=g) / C_ ** 0.5, F16)
+    b1 = torch.randn(N1, generator=g) * 0.3
+    ref = F.silu(F.conv2d(F.silu(F.conv2d(x, wd, bd, padding=1, groups=C_)), w1, b1))
+    pc2 = None
+    if N2:
+        w2 = quant(torch.randn(N2, N1, 1, 1, generator=g) / N1 ** 0.5, F16)
+        b2 = torch.randn(N2, generator=g)
+        ref = F.conv2d(ref, w2, b2)
+        pc2 = PackedConv(w2, b2, F16)
+    nout = N2 or N1
+    xb = to_buf(x, F16)
+    yb = Buf(B, H, W, (nout + 7) // 8 * 8 + 8, F16, zero=True)
+    plan = Plan(stream())
+    op_dwpw(plan, "t", PackedDW(wd, bd, F16), PackedConv(w1, b1, F16), xb.view(), yb.view(0, nout), pc2=pc2)
+    run(plan)
+    torch.testing.assert_close(from_view(yb.view(0, nout)), ref, **TOL[F16])
+    assert float(yb.t[..., nout:].abs().max()) == 0.0
+    assert not dwpw_supported(48, 80, 0, F16) and not dwpw_supported(64, 80, 0, F32)
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_sppf_pool(dtype):
     g = torch.Generator().manual_seed(2)
