@@ -37,22 +37,21 @@ __device__ __forceinline__ void mma16(const u32x4& a, const u32x4& b, f32x16& c)
 
 // CC channels per chunk (64 or 80), NCHUNK chunks (C = CC * NCHUNK), N1P / N2P = padded widths of the pointwise / chained conv
 template <int CC, int NCHUNK, int N1P, int N2P>
-__global__ __launch_bounds__(256, 2) void dwpw_kernel(const DwPwArgs p) {
+__global__ __launch_bounds__(256, (NCHUNK > 1 ? 2 : 3)) void dwpw_kernel(const DwPwArgs p) {
   constexpr int NCK = CC / 8;                       // 16-byte channel chunks per pixel
   constexpr int PSTR = CC * 2 + 16;                 // LDS row stride of patch / operand tile / weight rows: odd multiple of 16 bytes
   constexpr int C = CC * NCHUNK;
-  constexpr int PATCH_B = PH * PW * PSTR, W1_B = N1P * PSTR, AS_B = BMT * PSTR;
+  constexpr int PATCH_B = PH * PW * PSTR, AS_B = BMT * PSTR;
   constexpr int HSTR = N1P * 2 + 16, OSTR = (N2P > 0 ? N2P : 8) * 2 + 16;
   constexpr int WD_B = 9 * CC * 2;
-  static_assert(BMT * HSTR <= PATCH_B + W1_B, "the activated pointwise tile overlays patch + weight chunk");
+  static_assert(BMT * HSTR <= (N2P > 0 ? PATCH_B : PATCH_B + AS_B), "the activated pointwise tile overlays the patch (and, unchained, the operand tile)");
   static_assert(N2P == 0 || BMT * OSTR <= AS_B, "the output tile overlays the operand tile");
   static_assert(N1P % 32 == 0 && N2P % 32 == 0 && CC % 16 == 0, "MFMA tiling");
   constexpr int TN1 = N1P / 32, TN2 = N2P / 32;
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const patch = smem;
-  char* const w1s = smem + PATCH_B;
-  char* const As = w1s + W1_B;
+  char* const As = smem + PATCH_B;
   char* const wds = As + AS_B;
   float* const bds = reinterpret_cast<float*>(wds + WD_B);
   float* const b1s = bds + CC;
@@ -68,28 +67,42 @@ __global__ __launch_bounds__(256, 2) void dwpw_kernel(const DwPwArgs p) {
   const int lr = lane & 31, lh = lane >> 5;
 
   // ---- staging (one round trip per chunk) ------------------------------------------------------------------------
-  constexpr int NP = (PH * PW * NCK + 255) / 256, NW = (N1P * NCK + 255) / 256;
-  u32x4 pv[NP], wv1[NW], wdv;
+  // (the pointwise weights are NOT staged: every wave needs all of them exactly once per chunk, so each lane fetches its
+  //  MFMA A fragments straight from L2 with the patch -- 14 KB less LDS: three workgroups per CU instead of two)
+  // patch staging map: a pass covers RPP rows of 16 columns (thread -> row-in-pass, column, channel chunk), a last pass the
+  // two halo columns 16 / 17 of all rows: every pass is "base pointer + pass * row pitch" (the generic "chunk id -> pixel"
+  // map cost ~45 VALU instructions per load in divisions and 64-bit multiplies)
+  constexpr int TPR = 16 * NCK, RPP = 256 / TPR, NMAIN = PH / RPP, NP = NMAIN + 1;
+  static_assert(PH % RPP == 0 && PH * 2 * NCK <= 256, "patch staging map");
+  u32x4 pv[NP], wf1[TN1][CC / 16], wdv;
   bool pok[NP];
   float bdv;
+  const int m_rsel = tid / TPR, m_t = tid - m_rsel * TPR;
+  const int m_pc = m_t / NCK, m_ck = m_t - m_pc * NCK;
+  const bool m_act = m_rsel < RPP;
+  const int t_pr = tid / (2 * NCK), t_rem = tid - t_pr * (2 * NCK);
+  const int t_pc = 16 + t_rem / NCK, t_ck = t_rem % NCK;
+  const bool t_act = tid < PH * 2 * NCK;
+  const size_t row_pitch = (size_t)p.W * p.x_ld * 2;
+  const char* const img = p.x + (size_t)b * p.H * row_pitch;
+  const bool m_xok = m_act && (unsigned)(ox0 - 1 + m_pc) < (unsigned)p.W;
+  const bool t_xok = t_act && (unsigned)(ox0 - 1 + t_pc) < (unsigned)p.W;
+  const char* const m_src = img + (size_t)(m_xok ? ox0 - 1 + m_pc : 0) * p.x_ld * 2 + (m_xok ? m_ck * 16 : 0);
+  const char* const t_src = img + (size_t)(t_xok ? ox0 - 1 + t_pc : 0) * p.x_ld * 2 + (t_xok ? t_ck * 16 : 0);
+  const int m_dst = (m_rsel * PW + m_pc) * PSTR + m_ck * 16, t_dst = (t_pr * PW + t_pc) * PSTR + t_ck * 16;
   auto load_chunk = [&](int c0) {
 #pragma unroll
-    for (int i = 0; i < NP; ++i) {
-      const int id = tid + i * 256;
-      const int pp = id / NCK, ck = id - pp * NCK;
-      const int pr = pp / PW, pc = pp - pr * PW;
-      const int iy = oy0 - 1 + pr, ix = ox0 - 1 + pc;
-      const bool ok = id < PH * PW * NCK && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-      const int iyc = ok ? iy : 0, ixc = ok ? ix : 0;                  // branch-free: clamped address + select at LDS-write time
-      pv[i] = *reinterpret_cast<const u32x4*>(p.x + ((((size_t)b * p.H + iyc) * p.W + ixc) * p.x_ld + c0 + (ok ? ck * 8 : 0)) * 2);
+    for (int i = 0; i < NMAIN; ++i) {
+      const int iy = oy0 - 1 + i * RPP + m_rsel;
+      const bool ok = m_xok && (unsigned)iy < (unsigned)p.H;           // branch-free: clamped address + select at LDS-write time
+      pv[i] = *reinterpret_cast<const u32x4*>(m_src + (size_t)(ok ? iy : 0) * row_pitch + c0 * 2);
       pok[i] = ok;
     }
-#pragma unroll
-    for (int i = 0; i < NW; ++i) {
-      const int id = tid + i * 256;
-      const int n = id / NCK, ck = id - n * NCK;
-      const bool ok = id < N1P * NCK;
-      wv1[i] = *reinterpret_cast<const u32x4*>(p.w1 + ((size_t)(ok ? n : 0) * p.kpad1 + c0 + (ok ? ck * 8 : 0)) * 2);
+    {
+      const int iy = oy0 - 1 + t_pr;
+      const bool ok = t_xok && (unsigned)iy < (unsigned)p.H;
+      pv[NMAIN] = *reinterpret_cast<const u32x4*>(t_src + (size_t)(ok ? iy : 0) * row_pitch + c0 * 2);
+      pok[NMAIN] = ok;
     }
     {
       const int tap = tid / NCK, ck = tid - tap * NCK;
@@ -98,19 +111,19 @@ __global__ __launch_bounds__(256, 2) void dwpw_kernel(const DwPwArgs p) {
     }
     bdv = p.bd[c0 + (tid < CC ? tid : 0)];
   };
+  auto load_wfrag = [&](int c0) {
+#pragma unroll
+    for (int i = 0; i < TN1; ++i)
+#pragma unroll
+      for (int ks = 0; ks < CC / 16; ++ks)
+        wf1[i][ks] = *reinterpret_cast<const u32x4*>(p.w1 + ((size_t)(i * 32 + lr) * p.kpad1 + c0 + ks * 16 + lh * 8) * 2);
+  };
   auto store_chunk = [&]() {
+    if (m_act) {
 #pragma unroll
-    for (int i = 0; i < NP; ++i) {
-      const int id = tid + i * 256;
-      const int pp = id / NCK, ck = id - pp * NCK;
-      if (id < PH * PW * NCK) *reinterpret_cast<u32x4*>(patch + pp * PSTR + ck * 16) = pok[i] ? pv[i] : u32x4{0u, 0u, 0u, 0u};
+      for (int i = 0; i < NMAIN; ++i) *reinterpret_cast<u32x4*>(patch + m_dst + i * (RPP * PW * PSTR)) = pok[i] ? pv[i] : u32x4{0u, 0u, 0u, 0u};
     }
-#pragma unroll
-    for (int i = 0; i < NW; ++i) {
-      const int id = tid + i * 256;
-      const int n = id / NCK, ck = id - n * NCK;
-      if (id < N1P * NCK) *reinterpret_cast<u32x4*>(w1s + n * PSTR + ck * 16) = wv1[i];
-    }
+    if (t_act) *reinterpret_cast<u32x4*>(patch + t_dst) = pok[NMAIN] ? pv[NMAIN] : u32x4{0u, 0u, 0u, 0u};
     if (tid < 9 * NCK) *reinterpret_cast<u32x4*>(wds + tid * 16) = wdv;        // [tap][CC]: chunk tid = tap * NCK + ck
     if (tid < CC) bds[tid] = bdv;
   };
@@ -119,6 +132,7 @@ __global__ __launch_bounds__(256, 2) void dwpw_kernel(const DwPwArgs p) {
   float b2v = 0.f;
   if constexpr (N2P > 0) b2v = p.b2[tid < N2P ? tid : 0];
   load_chunk(0);
+  load_wfrag(0);
 
   f32x16 acc[TN1];
 #pragma unroll
@@ -127,14 +141,14 @@ __global__ __launch_bounds__(256, 2) void dwpw_kernel(const DwPwArgs p) {
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
   for (int cc = 0; cc < NCHUNK; ++cc) {
-    if (cc) __syncthreads();                          // the previous chunk's operand tile and weights are consumed
+    if (cc) __syncthreads();                          // the previous chunk's operand tile is consumed
     store_chunk();
     if (cc == 0) {
       if (tid < N1P) b1s[tid] = b1v;
       if (N2P > 0 && tid < N2P) b2s[tid] = b2v;
     }
     __syncthreads();
-    if (cc + 1 < NCHUNK) load_chunk((cc + 1) * CC);
+    if (cc + 1 < NCHUNK) load_chunk((cc + 1) * CC);     // next patch / taps: in flight during this chunk's arithmetic
     // ---- depthwise 3x3 + bias + SiLU on the VALU: strip of 4 pixels x 8 channels per item -----------------------
     for (int item = tid; item < 32 * NCK; item += 256) {
       const int strip = item / NCK, ck = item - strip * NCK;
@@ -148,19 +162,18 @@ __global__ __launch_bounds__(256, 2) void dwpw_kernel(const DwPwArgs p) {
       }
 #pragma unroll 1
       for (int ky = 0; ky < 3; ++ky) {                  // (not unrolled: 18 hoisted patch reads + the next chunk's staging registers spill)
-        float wt[3][8];
+        f16x8 wt[3];                                    // operands stay fp16: fma(ext(x), ext(w), acc) is one v_fma_mix_f32
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx) unpack16<f16>(*reinterpret_cast<const u32x4*>(wds + ((ky * 3 + kx) * NCK + ck) * 16), wt[kx]);
+        for (int kx = 0; kx < 3; ++kx) wt[kx] = *reinterpret_cast<const f16x8*>(wds + ((ky * 3 + kx) * NCK + ck) * 16);
 #pragma unroll
         for (int cx = 0; cx < 6; ++cx) {
-          float xf[8];
-          unpack16<f16>(*reinterpret_cast<const u32x4*>(patch + ((r + ky) * PW + x0 + cx) * PSTR + ck * 16), xf);
+          const f16x8 xf = *reinterpret_cast<const f16x8*>(patch + ((r + ky) * PW + x0 + cx) * PSTR + ck * 16);
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const int kx = cx - q;                      // same accumulation order as dwconv3x3_strip_kernel
             if (kx >= 0 && kx < 3) {
 #pragma unroll
-              for (int e = 0; e < 8; ++e) a[q][e] = fmaf(xf[e], wt[kx][e], a[q][e]);
+              for (int e = 0; e < 8; ++e) a[q][e] = fmaf((float)xf[e], (float)wt[kx][e], a[q][e]);
             }
           }
         }
@@ -178,11 +191,9 @@ __global__ __launch_bounds__(256, 2) void dwpw_kernel(const DwPwArgs p) {
     for (int ks = 0; ks < CC / 16; ++ks) {
       const u32x4 xf = *reinterpret_cast<const u32x4*>(As + (wv * 32 + lr) * PSTR + ks * 32 + lh * 16);
 #pragma unroll
-      for (int i = 0; i < TN1; ++i) {
-        const u32x4 wf = *reinterpret_cast<const u32x4*>(w1s + (i * 32 + lr) * PSTR + ks * 32 + lh * 16);
-        mma16(wf, xf, acc[i]);
-      }
+      for (int i = 0; i < TN1; ++i) mma16(wf1[i][ks], xf, acc[i]);
     }
+    if (cc + 1 < NCHUNK) load_wfrag((cc + 1) * CC);      // (after the MFMAs, which consume this chunk's fragments; they land during the next depthwise stage)
   }
 
   // chained 1x1: its weight fragments come straight from L2 and are requested before the activation epilogue
@@ -194,7 +205,7 @@ __global__ __launch_bounds__(256, 2) void dwpw_kernel(const DwPwArgs p) {
       for (int ks = 0; ks < N1P / 16; ++ks)
         w2f[i][ks] = *reinterpret_cast<const u32x4*>(p.w2 + ((size_t)(i * 32 + lr) * p.kpad2 + ks * 16 + lh * 8) * 2);
   }
-  __syncthreads();                                    // every wave is done with patch / weight chunk: the activated tile overlays them
+  __syncthreads();                                    // every wave is done with patch / operand tile: the activated tile overlays them
 
   // ---- epilogue 1: bias + SiLU -> fp16 tile Ht [128 pixels][N1P] ---------------------------------------------------
   char* const Ht = smem;
@@ -264,8 +275,8 @@ __global__ __launch_bounds__(256, 2) void dwpw_kernel(const DwPwArgs p) {
 template <int CC, int NCHUNK, int N1P, int N2P>
 int launch_dwpw(DwPwArgs& a, int B, hipStream_t stream) {
   constexpr int PSTR = CC * 2 + 16;
-  constexpr size_t lds = (size_t)PH * PW * PSTR + (size_t)N1P * PSTR + (size_t)BMT * PSTR + 9 * CC * 2 + (CC + N1P + (N2P > 0 ? N2P : 4)) * sizeof(float);
-  static_assert(lds <= 80 * 1024, "two workgroups per CU");
+  constexpr size_t lds = (size_t)PH * PW * PSTR + (size_t)BMT * PSTR + 9 * CC * 2 + (CC + N1P + (N2P > 0 ? N2P : 4)) * sizeof(float);
+  static_assert(lds <= 64 * 1024, "two to three workgroups per CU");
   static bool attr_done = false;
   if (!attr_done && lds > 64 * 1024) {
     CVMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dwpw_kernel<CC, NCHUNK, N1P, N2P>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
