@@ -76,6 +76,8 @@ SIGNATURES = {
     "cvmi_conv2d": (_i, [C.POINTER(ConvDesc), _vp]),
     "cvmi_c3k2_supported": (_i, [_i, _i, _i, _i, _i, _i]),
     "cvmi_c3k2": (_i, [C.POINTER(C3k2Desc), _vp]),
+    "cvmi_stem2_supported": (_i, [_i, _i, _i]),
+    "cvmi_stem2": (_i, [_vp, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "cvmi_dwpw_supported": (_i, [_i, _i, _i, _i]),
     "cvmi_dwpw": (_i, [C.POINTER(DwPwDesc), _vp]),
     "cvmi_dwconv3x3": (_i, [_vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),

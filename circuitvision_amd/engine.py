@@ -274,6 +274,28 @@ def op_c3k2(plan, label, src, dst, pc_cv1, pc_m1, pc_m2, pc_cv2, c, h, fuse_cv1,
     plan.add(label, "conv", thunk, px * (src.c + dst.c) * ESIZE[pc_cv2.dtype], flops)
 
 
+def stem2_supported(c0, c1, dtype):
+    return bool(_lib.load().cvmi_stem2_supported(c0, c1, dtype))
+
+
+def op_stem2(plan, label, pc0, pc1, src, dst):
+    """Fused model.0 + model.1 (one launch).  src: space-to-depth(2) image view (16 channels), dst: model.1 output view."""
+    lib = _lib.load()
+    assert src.c == 16 and pc0.Cin == 16 and pc1.Cin == pc0.N and dst.c == pc1.N
+    assert (dst.H, dst.W) == ((src.H - 1) // 2 + 1, (src.W - 1) // 2 + 1) and dst.B == src.B
+    args = (src.ptr, src.ld, pc0.w.data_ptr(), pc0.bias.data_ptr(), pc0.Kpad, pc1.w.data_ptr(), pc1.bias.data_ptr(), pc1.Kpad,
+            dst.ptr, dst.ld, src.B, src.H, src.W, pc0.N, pc1.N, pc1.dtype)
+    plan.keep.append((pc0, pc1, src, dst))
+    sp0, fn = plan.sptr, lib.cvmi_stem2
+
+    def thunk(sp=None):
+        sp = sp0 if sp is None else sp
+        _lib.check(fn(*args, sp), label)
+
+    px0, px1 = src.B * src.H * src.W, dst.B * dst.H * dst.W
+    plan.add(label, "stem", thunk, (px0 * src.c + px1 * dst.c) * ESIZE[pc1.dtype], 2 * px0 * 27 * pc0.N + 2 * px1 * 9 * pc0.N * pc1.N)
+
+
 def dwpw_supported(C_, n1, n2, dtype):
     return bool(_lib.load().cvmi_dwpw_supported(C_, n1, n2, dtype))
 

@@ -22,7 +22,7 @@ import torch
 from . import _lib
 from ._lib import ACT_NONE, ACT_SILU, F16, F32
 from .engine import (ESIZE, Buf, PackedConv, PackedDW, Plan, c3k2_supported, dwpw_supported, make_attn_desc, op_attention, op_c3k2, op_call, op_conv,
-                     op_dwpw,
+                     op_dwpw, op_stem2, stem2_supported,
                      op_dwconv, op_sppf_pool)
 
 SCALES = {"n": (0.50, 0.25, 1024), "s": (0.50, 0.50, 1024), "m": (0.50, 1.00, 512),
@@ -237,6 +237,7 @@ class Yolo11Plan:
         self.keep_scores = keep_scores
         self.fuse_c3k2 = fuse_c3k2 and os.environ.get("CVMI_FUSE_C3K2", "1") != "0"
         self.fuse_dwpw = fuse_c3k2 and os.environ.get("CVMI_FUSE_DWPW", "1") != "0"
+        self.fuse_stem = fuse_c3k2 and os.environ.get("CVMI_FUSE_STEM", "1") != "0"
         assert H % 32 == 0 and W % 32 == 0, "network input must be a multiple of stride 32"
         self.wt, self.B, self.H, self.W = weights, B, H, W
         self.dt, self.dev = weights.dtype, weights.device
@@ -306,10 +307,13 @@ class Yolo11Plan:
         wt, ch, rep, ca = self.wt, self.wt.ch, self.wt.rep, self.wt.c3k_all
         B, H, W = self.B, self.H, self.W
         self.x_in = Buf(B, H // 2, W // 2, 16, self.dt, self.dev, zero=True)       # space-to-depth(2) image, see Yolo11Weights.stem
-        x = self.buf(H // 2, W // 2, ch(64)).view()
-        op_conv(self.plan, "model.0", wt.packed["model.0"], [(self.x_in.view(), 0)], x, stride=1, pad=1, act=ACT_SILU, out_hw=(H // 2, W // 2), kind="stem")
         y = self.buf(H // 4, W // 4, ch(128)).view()
-        self.cv("model.1", x, y, 3, 2)
+        if self.fuse_stem and stem2_supported(ch(64), ch(128), self.dt):
+            op_stem2(self.plan, "model.0-1", wt.packed["model.0"], wt.packed["model.1"], self.x_in.view(), y)
+        else:
+            x = self.buf(H // 2, W // 2, ch(64)).view()
+            op_conv(self.plan, "model.0", wt.packed["model.0"], [(self.x_in.view(), 0)], x, stride=1, pad=1, act=ACT_SILU, out_hw=(H // 2, W // 2), kind="stem")
+            self.cv("model.1", x, y, 3, 2)
         x = self.c3k2("model.2", [(y, 0)], ch(256), rep(2), ca, 0.25)
         y = self.buf(H // 8, W // 8, ch(256)).view()
         self.cv("model.3", x, y, 3, 2)

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define CVMI_VERSION 102
+#define CVMI_VERSION 103
 
 typedef void* cvmi_stream_t; /* hipStream_t */
 
@@ -101,6 +101,16 @@ typedef struct {
 } cvmi_c3k2_desc;
 int cvmi_c3k2_supported(int c1, int c, int h, int c2, int fuse_cv1, int dtype);
 int cvmi_c3k2(const cvmi_c3k2_desc* d, cvmi_stream_t stream);
+
+/* ---- fused YOLO11 stem: model.0 (Conv 3x3 s2, 3 -> c0) + model.1 (Conv 3x3 s2, c0 -> c1), SiLU each -------
+ * Replaces the first two layers of ultralytics' DetectionModel inside YOLO.predict (circuit_analyzer.py:268) in one
+ * launch: the c0-channel half-resolution map never reaches HBM.  x: the space-to-depth(2) image cvmi_letterbox(s2d=1)
+ * writes, [B, H2, W2, x_ld >= 16] (12 real channels); w0 / b0: model.0 as the equivalent 2x2 / stride-1 conv over the
+ * 16 s2d channels, taps at block offsets (-1, 0), cvmi_conv2d-packed (k = (ty*2 + tx)*16 + c); w1 / b1: model.1,
+ * cvmi_conv2d-packed; y: [B, ceil(H2/2), ceil(W2/2), y_ld >= c1].  fp16, (c0, c1) = (16, 32) (YOLO11-n) is built. */
+int cvmi_stem2_supported(int c0, int c1, int dtype);
+int cvmi_stem2(const void* x, int x_ld, const void* w0, const float* b0, int kpad0, const void* w1, const float* b1, int kpad1,
+               void* y, int y_ld, int B, int H2, int W2, int c0, int c1, int dtype, cvmi_stream_t stream);
 
 /* ---- fused depthwise 3x3 + pointwise 1x1 (+ chained 1x1): YOLO11 Detect class branch ---------
  * Replaces, inside YOLO.predict (circuit_analyzer.py:268), the ultralytics Detect.cv3[i] sub-chains

@@ -170,6 +170,33 @@ def test_dwconv3x3(dtype):
     torch.testing.assert_close(from_view(yb.view()), ref, **TOL[dtype])
 
 
+@pytest.mark.parametrize("hw", [(64, 96), (96, 72), (40, 56)])
+def test_stem2_fused_first_two_layers(hw):
+    """model.0 + model.1 (Conv 3x3 s2 + SiLU twice) in one launch on the space-to-depth image vs the fp32 statement;
+    (96, 72) and (40, 56) give ragged output tiles (model.1 grid 24 x 18 / 10 x 14 against 8 x 16 tiles)."""
+    from circuitvision_amd.engine import op_stem2, stem2_supported
+    from circuitvision_amd.yolo11 import SyntheticParams, Yolo11Weights
+    assert stem2_supported(16, 32, F16) and not stem2_supported(64, 128, F16)
+    H, W = hw
+    B = 2
+    wt = Yolo11Weights("n", 62, SyntheticParams(seed=5, nc=62), F16)
+    g = torch.Generator().manual_seed(9)
+    x = quant(torch.rand(B, 3, H, W, generator=g), F16)
+    w0, b0 = wt._fold("model.0", 3, 16, 3)
+    w1, b1 = wt._fold("model.1", 16, 32, 3)
+    t = quant(F.silu(F.conv2d(x, quant(w0, F16), b0, stride=2, padding=1)), F16)     # the fused kernel keeps model.0's output as fp16 too
+    ref = F.silu(F.conv2d(t, quant(w1, F16), b1, stride=2, padding=1))
+    s2d = x.reshape(B, 3, H // 2, 2, W // 2, 2).permute(0, 2, 4, 3, 5, 1).reshape(B, H // 2, W // 2, 12)
+    xb = Buf(B, H // 2, W // 2, 16, F16, zero=True)
+    xb.t[..., :12] = s2d.to(xb.t.dtype)
+    yb = Buf(B, H // 4, W // 4, 40, F16, zero=True)
+    plan = Plan(stream())
+    op_stem2(plan, "t", wt.packed["model.0"], wt.packed["model.1"], xb.view(), yb.view(0, 32))
+    run(plan)
+    torch.testing.assert_close(from_view(yb.view(0, 32)), ref, **TOL[F16])
+    assert float(yb.t[..., 32:].abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("cfg", [
     # B, C, H, W, N1, N2
     (2, 64, 24, 32, 80, 0),        # one 64-channel chunk, whole tiles

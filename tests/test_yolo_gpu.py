@@ -212,6 +212,7 @@ def test_c3k2_fused_blocks_match_unfused_launch_chain(hw):
         plan = Yolo11Plan(wt, B, H, W, torch.cuda.Stream(), fuse_c3k2=fuse)
         labels = [op[0] for op in plan.plan.ops]
         assert ("model.2" in labels) == fuse and ("model.16.fused" in labels) == fuse and ("model.2.cv2" in labels) != fuse
+        assert ("model.0-1" in labels) == fuse and ("model.1" in labels) != fuse                           # fused stem
         assert ("model.23.cv3.0.1-2" in labels) == fuse and ("model.23.cv3.0.1.0" in labels) != fuse     # Detect class branch: 2 launches vs 5
         plan.set_input_nchw(x)
         torch.cuda.synchronize()
