@@ -150,7 +150,7 @@ class Plan:
 
     def _run_lanes(self):
         """Issue the ops for capture: lane 0 on the plan's stream, other lanes on side streams between fork/join."""
-        active = {}
+        active, lane_fork = {}, {}
         for (label, kind, thunk, _, _), lane in zip(self.ops, self.lanes):
             if lane == -1:                                   # fork point: lanes that START after it wait for it;
                 self._fork_ev = torch.cuda.Event()           # lanes forked earlier keep running until the join
@@ -160,15 +160,16 @@ class Plan:
                     ev = torch.cuda.Event()
                     ev.record(st)
                     self.stream.wait_event(ev)
-                active = {}
+                active, lane_fork = {}, {}
             elif lane == 0:
                 thunk()
             else:
                 if lane not in self._lane_streams:
                     self._lane_streams[lane] = torch.cuda.Stream(device=self.stream.device)
                 st = self._lane_streams[lane]
-                if lane not in active:
-                    st.wait_event(self._fork_ev)
+                if lane_fork.get(lane) is not self._fork_ev:     # first op of this lane after the latest fork point (a lane may be
+                    st.wait_event(self._fork_ev)                 # reused after a later fork: it then also waits for that one)
+                    lane_fork[lane] = self._fork_ev
                     active[lane] = st
                 thunk(st.cuda_stream)
 

@@ -391,15 +391,22 @@ class Yolo11Plan:
         wt = self.wt
         nc, c2, c3 = wt.nc, wt.det_c2, wt.det_c3
         ncp = (nc + 7) // 8 * 8
-        self.plan.fork()
-        self.plan.lane(2 * i + 1)
+        # Side lanes of the captured graph.  Measured (B = 32, ms per step): every branch on its own lane (6 lanes) 1.16, one lane
+        # per level 1.10, ONE side lane for all heads 1.09, no side lane 1.16 -- a replayed HIP graph pays ~1.8 us per node on a
+        # chain but ~3.3 us per node when nodes alternate between lanes (tools/graph_gap.py), so the heads share one lane that
+        # runs beside the rest of the neck.  CVMI_YOLO_LANES: tuning experiments only (0 none, 1 per level, 2 per branch, 3 one).
+        lanes = int(os.environ.get("CVMI_YOLO_LANES", "3"))
+        if lanes:
+            self.plan.fork()
+            self.plan.lane(1 if lanes == 3 else (1 + min(i, 1)) if lanes == 4 else 2 * i + 1)
         t1 = self.buf(f.H, f.W, c2).view()
         t2 = self.buf(f.H, f.W, c2).view()
         bx = self.buf(f.H, f.W, 64).view()
         self.cv(f"model.23.cv2.{i}.0", f, t1, 3, kind="head")
         self.cv(f"model.23.cv2.{i}.1", t1, t2, 3, kind="head")
         self.cv(f"model.23.cv2.{i}.2", t2, bx, act=ACT_NONE, kind="head")
-        self.plan.lane(2 * i + 2)
+        if lanes == 2:
+            self.plan.lane(2 * i + 2)
         cl = Buf(self.B, f.H, f.W, ncp, self.dt, self.dev, zero=True)
         self.act_bytes += cl.nbytes
         u1 = self.buf(f.H, f.W, c3).view()
