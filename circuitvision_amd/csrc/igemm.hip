@@ -33,6 +33,7 @@ struct ConvKArgs {
   int act, scalar_gather;
   int res_mod, act_after_res, shuf_c, res_rep;
   int plain;
+  int rows2;                             // 1x1 / s1 / p0 over two concatenated sources with channel counts that are K-tile multiples
   int nb_n;
   int bias_off;                          // igemm_kernel: LDS byte offset of the parked bias row
   FastDiv div_ctot, div_kw;
@@ -298,12 +299,24 @@ __global__ __launch_bounds__(WM * WN * 64 * KS, (KS > 1 ? 4 : WM * WN == 8 ? 4 :
   }
 
   const char* a_ptr[A_IT];
+  const char* a_ptr1[A_IT];                       // rows2: row pointer into the second source
   const char* b_ptr[B_IT];
+  // rows2: a 1x1 / stride-1 conv over the concat of two sources (either may be 2x nearest-upsampled): every output row reads ONE
+  // row of each source, so the gather collapses to two row pointers per slot -- as cheap as PLAIN (the YOLO neck's concat convs)
+  const bool rows2 = !PLAIN && p.rows2;
 #pragma unroll
   for (int i = 0; i < A_IT; ++i) {
     const int row = (tid + i * NT) / CH;
     const int m = a_ok[i] ? m0 + row : 0;
     a_ptr[i] = p.x0 + ((size_t)m * p.x0_ld + cchunk * VEC) * ES;
+    a_ptr1[i] = a_ptr[i];
+    if (rows2) {
+      const int oy = a_iy0[i], ox = a_ix0[i];       // stride 1, pad 0: the window origin is the output pixel
+      const size_t pix0 = ((size_t)a_b[i] * (p.H >> p.up0) + (oy >> p.up0)) * (size_t)(p.W >> p.up0) + (ox >> p.up0);
+      const size_t pix1 = ((size_t)a_b[i] * (p.H >> p.up1) + (oy >> p.up1)) * (size_t)(p.W >> p.up1) + (ox >> p.up1);
+      a_ptr[i] = p.x0 + (pix0 * p.x0_ld + cchunk * VEC) * ES;
+      a_ptr1[i] = p.x1 + (pix1 * p.x1_ld + cchunk * VEC) * ES - (size_t)p.c0 * ES;      // indexed by the concat channel
+    }
   }
 #pragma unroll
   for (int i = 0; i < B_IT; ++i) {
@@ -322,6 +335,12 @@ __global__ __launch_bounds__(WM * WN * 64 * KS, (KS > 1 ? 4 : WM * WN == 8 ? 4 :
       if constexpr (PLAIN) {
         const bool ok = a_ok[i] && k < p.K;                       // branch-free (see gather_chunk)
         st.a[i] = *reinterpret_cast<const u32x4*>(a_ptr[i] + (ok ? (size_t)kt * BKB : (size_t)0) - (ok ? 0 : cchunk * 16));
+        st.m[i] = ok;
+      } else if (rows2) {
+        const int kc = kt * BK;
+        const bool ok = a_ok[i] && kc < p.K;
+        const char* src = (ok && kc >= p.c0) ? a_ptr1[i] : a_ptr[i];       // masked slots read source 0's row start (a_ptr1 is biased by -c0)
+        st.a[i] = *reinterpret_cast<const u32x4*>(src + (ok ? (size_t)kc * ES : (size_t)0));
         st.m[i] = ok;
       } else if (fastg) {
         // K-tile inside one (tap, source): the tap / channel bookkeeping is wave-uniform scalar state advanced per tile,
@@ -497,8 +516,10 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_glds_kernel(const ConvKA
 
   // per-lane source pointers of this wave's pieces (k advances by one tile per iteration)
   const char* src[PIECES / NW];
+  const char* src1[PIECES / NW];                                // rows2 (1x1 conv over two concatenated sources): row pointer into the second source
   int adj[PIECES / NW];
   const int nk = (p.K + BK - 1) / BK, krem = p.K % BK;
+  const int kt1 = p.rows2 ? p.c0 / BK : nk;                     // first K-tile of the second source
 #pragma unroll
   for (int i = 0; i < PIECES / NW; ++i) {
     const int piece = wv * (PIECES / NW) + i;
@@ -509,18 +530,29 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_glds_kernel(const ConvKA
       int m = m0 + row;
       m = m < p.M ? m : p.M - 1;                                // tail rows: any valid row (never stored)
       src[i] = p.x0 + ((size_t)m * p.x0_ld + slot * VEC) * ES;
+      src1[i] = src[i];
+      if (p.rows2) {                                            // either source may be 2x nearest-upsampled: output pixel -> source pixel
+        const int ohow = p.OH * p.OW;
+        const int b = m / ohow, r = m - b * ohow;
+        const int oy = r / p.OW, ox = r - oy * p.OW;
+        const size_t pix0 = ((size_t)b * (p.H >> p.up0) + (oy >> p.up0)) * (size_t)(p.W >> p.up0) + (ox >> p.up0);
+        const size_t pix1 = ((size_t)b * (p.H >> p.up1) + (oy >> p.up1)) * (size_t)(p.W >> p.up1) + (ox >> p.up1);
+        src[i] = p.x0 + (pix0 * p.x0_ld + slot * VEC) * ES;
+        src1[i] = p.x1 + (pix1 * p.x1_ld + slot * VEC) * ES - (size_t)p.c0 * ES;       // indexed by the concat channel
+      }
       // K not a multiple of the tile depth: the last tile's out-of-row chunks re-read the previous tile's chunk (finite data
       // against the zero-padded weight columns [K, Kpad)), see gemm256_kernel
       if (krem && slot * VEC >= krem) adj[i] = -BKB;
     } else {
       src[i] = p.w + ((size_t)(n0 + row - BM) * p.Kpad + slot * VEC) * ES;
+      src1[i] = src[i];
     }
   }
   auto issue = [&](int stage, int kt) {
 #pragma unroll
     for (int i = 0; i < PIECES / NW; ++i) {
       const int piece = wv * (PIECES / NW) + i;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + (long long)kt * BKB + (kt == nk - 1 ? (long long)adj[i] : 0ll)),
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((kt < kt1 ? src[i] : src1[i]) + (long long)kt * BKB + (kt == nk - 1 ? (long long)adj[i] : 0ll)),
                                        (__attribute__((address_space(3))) void*)(smem + stage * STAGE + piece * 1024), 16, 0, 0);
     }
   };
@@ -1448,8 +1480,8 @@ int launch_typed(ConvKArgs& a, hipStream_t stream) {
   }
   static const int glds_min_tiles = getenv("CVMI_GLDS_MINTILES") ? atoi(getenv("CVMI_GLDS_MINTILES")) : 512;   // tuning experiments only
   // (K not a multiple of the 128-byte tile: only from K = 256 elements up -- at K = 144 the padded third tile costs more than the DMA saves)
-  if (use_glds && a.plain && a.K % (16 / (int)sizeof(T)) == 0 && (a.Kpad * (int)sizeof(T)) % 128 == 0 && a.K * (int)sizeof(T) >= 256 &&
-      ((a.K * (int)sizeof(T)) % 128 == 0 || a.K >= 256) && N >= 96 &&
+  if (use_glds && (a.plain || a.rows2) && a.K % (16 / (int)sizeof(T)) == 0 && (a.Kpad * (int)sizeof(T)) % 128 == 0 && a.K * (int)sizeof(T) >= 256 &&
+      ((a.K * (int)sizeof(T)) % 128 == 0 || a.K >= 256) && N >= (a.rows2 ? 64 : 96) &&
       (long long)cdiv(M, 128) * cdiv(N, 128) >= glds_min_tiles) {                      // large GEMMs only: small grids need the smaller tiles below
     if (use_glds == 2 || N <= 640) return launch_glds<T, TO, 128, 64, 2, 2>(a, stream);      // measured: wins up to N = 576
     return launch_glds<T, TO, 128, 128, 2, 2>(a, stream);
@@ -1526,6 +1558,8 @@ extern "C" int cvmi_conv2d(const cvmi_conv_desc* d, cvmi_stream_t stream_) {
   a.res_mod = d->res_mod; a.act_after_res = d->act_after_res; a.shuf_c = d->shuffle_cout; a.res_rep = d->res_rep;
   a.plain = (d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0 && d->c1 == 0 && d->up0 == 0 && !d->scalar_gather &&
              d->OH == d->H && d->OW == d->W) ? 1 : 0;
+  a.rows2 = (!a.plain && d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0 && !d->scalar_gather && d->OH == d->H && d->OW == d->W &&
+             d->c1 > 0 && d->c0 % 64 == 0 && ctot % 64 == 0 && d->dtype == CVMI_F16) ? 1 : 0;
   CVMI_CHECK(d->res_mod >= 0 && d->shuffle_cout >= 0, "conv2d: negative res_mod / shuffle_cout");
   CVMI_CHECK(d->res_rep <= 1 || (d->shuffle_cout > 0 && d->res && d->B % d->res_rep == 0), "conv2d: res_rep needs shuffle_cout, a residual and B %% res_rep == 0");
   if (d->shuffle_cout > 0) {

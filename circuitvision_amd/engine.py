@@ -34,6 +34,14 @@ class Buf:
     def view(self, c0=0, c=None):
         return View(self, c0, self.C - c0 if c is None else c)
 
+    def images(self, b0, nb):
+        """Images [b0, b0 + nb) of this buffer as a Buf that shares its storage."""
+        assert 0 <= b0 and b0 + nb <= self.B
+        o = Buf.__new__(Buf)
+        o.B, o.H, o.W, o.C, o.dtype = nb, self.H, self.W, self.C, self.dtype
+        o.t = self.t[b0:b0 + nb]
+        return o
+
     @property
     def nbytes(self):
         return self.t.numel() * self.t.element_size()

@@ -123,6 +123,23 @@ def test_conv2d_two_sources_upsample(dtype):
     run(plan)
     torch.testing.assert_close(from_view(yb.view(16, 40)), ref, **TOL[dtype])
     assert float(yb.t[..., :16].abs().max()) == 0.0 and float(yb.t[..., 56:].abs().max()) == 0.0
+    # channel counts that are K-tile multiples take the two-row-pointer gather (the YOLO neck's concat convs); both orders of
+    # (upsampled, plain) sources, ragged M
+    for up_first in (True, False):
+        B, H, W = 3, 18, 22
+        a = quant(torch.randn(B, 128, H // 2, W // 2, generator=g), dtype)
+        b = quant(torch.randn(B, 64, H, W, generator=g), dtype)
+        w = quant(torch.randn(96, 192, 1, 1, generator=g) / 14, dtype)
+        bias = torch.randn(96, generator=g)
+        ua = F.interpolate(a, scale_factor=2, mode="nearest")
+        ref = F.silu(F.conv2d(torch.cat((ua, b) if up_first else (b, ua), 1), w, bias))
+        plan = Plan(stream())
+        ab, bb = to_buf(a, dtype), to_buf(b, dtype)
+        yb = Buf(B, H, W, 96, dtype, zero=True)
+        srcs = [(ab.view(), 1), (bb.view(), 0)] if up_first else [(bb.view(), 0), (ab.view(), 1)]
+        op_conv(plan, "t", PackedConv(w, bias, dtype), srcs, yb.view(), act=ACT_SILU)
+        run(plan)
+        torch.testing.assert_close(from_view(yb.view()), ref, **TOL[dtype])
 
 
 def test_conv2d_f16_in_f32_out():
