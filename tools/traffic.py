@@ -13,7 +13,7 @@ def total(d, counter, pat):
     return s
 
 fetch_dir, write_dir, steps, out = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
-pat = sys.argv[5] if len(sys.argv) > 5 else r"igemm_kernel|gemm_glds|gemm256|conv_tile_kernel|c3k2_kernel|dwconv3x3|sppf_pool|attn_f16|attn64"
+pat = sys.argv[5] if len(sys.argv) > 5 else r"igemm_kernel|gemm_glds|gemm256|conv_tile_kernel|c3k2_kernel|dwpw_kernel|stem2_kernel|dwconv3x3|sppf_pool|attn_f16|attn64"
 fetch = total(fetch_dir, "FETCH_SIZE", pat) * 1024 * 2 / steps
 write = total(write_dir, "WRITE_SIZE", pat) * 1024 / steps
 res = {"hbm_bytes_per_step": int(fetch + write), "fetch_bytes_per_step_corrected_x2": int(fetch), "write_bytes_per_step": int(write),
