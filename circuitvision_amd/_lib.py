@@ -92,6 +92,7 @@ SIGNATURES = {
     "cvmi_nchw_to_nhwc": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "cvmi_nhwc_to_nchw_f32": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _i, _vp]),
     "cvmi_layernorm": (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _i, C.c_longlong, _i, _f, _i, _i, _i, _i, _i, _vp]),
+    "cvmi_layernorm_dual": (_i, [_vp, _i, _vp, _vp, _vp, _i, _vp, _i, C.c_longlong, _i, _f, _vp]),
     "cvmi_maxpool2x2": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "cvmi_space_to_depth4": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "cvmi_cast": (_i, [_vp, _i, _i, _vp, _i, _i, C.c_longlong, _i, _vp]),

@@ -16,7 +16,9 @@ __device__ __forceinline__ float wave_sum(float v) {
 template <typename TI, typename TO, int NCH, int WD>
 __global__ __launch_bounds__(256) void layernorm_kernel(const TI* __restrict__ x, int x_ld, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, TO* __restrict__ y, int y_ld, long long rows, int C,
-                                                       float eps, int act, int G, int pw, int pwp, int phw, int phpwp) {
+                                                       float eps, int act, int G, int pw, int pwp, int phw, int phpwp,
+                                                       f16* __restrict__ y2, int y2_ld) {
+  // y2 (optional): a second, fp16 copy of the output rows (the GEMM-operand copy of an f32 stream -- saves the cast pass)
   // pw > 0: rows are pixels of [*, H, W] images (phw = H*W, pw = W) and are written into a zero-padded
   // [*, Hp, Wp] grid (phpwp = Hp*Wp, pwp = Wp) -- Hiera's pad-to-window-multiple, applied after the norm
   // WD = 16-byte input chunks per slot: 2 for f32 -> f16, so that a slot's 8 outputs leave as ONE 16-byte store
@@ -80,6 +82,12 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const TI* __restrict__ x
         for (int e = 0; e < SV; ++e) pk.v[e] = (TO)act_apply<false>((v[i][e] - mean) * rstd * gm[e] + bt[e], act);
       }
       *reinterpret_cast<Pack*>(yr + c) = pk;
+      if (y2) {
+        struct alignas(2 * SV > 16 ? 16 : 2 * SV) Pack2 { f16 v[SV]; } p2;
+#pragma unroll
+        for (int e = 0; e < SV; ++e) p2.v[e] = (f16)(float)pk.v[e];
+        *reinterpret_cast<Pack2*>(y2 + orow * y2_ld + c) = p2;
+      }
     }
   }
 }
@@ -512,7 +520,7 @@ inline int grid_for(long long total, int block = 256, int cap = 256 * 16) {
 
 template <typename TI, typename TO>
 int launch_ln(const void* x, int x_ld, const float* gamma, const float* beta, void* y, int y_ld, long long rows, int C, float eps, int act,
-              int pw, int pwp, int phw, int phpwp, hipStream_t stream) {
+              int pw, int pwp, int phw, int phpwp, hipStream_t stream, void* y2 = nullptr, int y2_ld = 0) {
   constexpr int VI = Elem<TI>::VEC;
   // f32 -> f16 with C a multiple of 8: slots of 8 channels (two 16-byte loads, one 16-byte store)
   constexpr bool CAN_WIDE = sizeof(TI) == 4 && sizeof(TO) == 2;
@@ -532,7 +540,7 @@ int launch_ln(const void* x, int x_ld, const float* gamma, const float* beta, vo
   CVMI_CHECK(bestG * bestN >= chunks, "layernorm: C=%d too wide", C);
   const int rpw = 64 / bestG;
   const dim3 g((unsigned)((rows + 4 * rpw - 1) / (4 * rpw))), b(256);
-#define CVMI_LN(N, W) hipLaunchKernelGGL((layernorm_kernel<TI, TO, N, W>), g, b, 0, stream, (const TI*)x, x_ld, gamma, beta, (TO*)y, y_ld, rows, C, eps, act, bestG, pw, pwp, phw, phpwp)
+#define CVMI_LN(N, W) hipLaunchKernelGGL((layernorm_kernel<TI, TO, N, W>), g, b, 0, stream, (const TI*)x, x_ld, gamma, beta, (TO*)y, y_ld, rows, C, eps, act, bestG, pw, pwp, phw, phpwp, (f16*)y2, y2_ld)
 #define CVMI_LN_SW(W)                                                                                                    \
   switch (bestN) {                                                                                                       \
     case 1: CVMI_LN(1, W); break;                                                                                        \
@@ -571,6 +579,14 @@ extern "C" int cvmi_layernorm(const void* x, int x_ld, int x_dtype, const float*
   if (x_dtype == CVMI_F32 && y_dtype == CVMI_F16) return launch_ln<float, f16>(x, x_ld, gamma, beta, y, y_ld, rows, C, eps, act, pw, pwp, phw, phpwp, s);
   if (x_dtype == CVMI_F16 && y_dtype == CVMI_F16) return launch_ln<f16, f16>(x, x_ld, gamma, beta, y, y_ld, rows, C, eps, act, pw, pwp, phw, phpwp, s);
   return launch_ln<f16, float>(x, x_ld, gamma, beta, y, y_ld, rows, C, eps, act, pw, pwp, phw, phpwp, s);
+}
+
+extern "C" int cvmi_layernorm_dual(const void* x, int x_ld, const float* gamma, const float* beta, void* y, int y_ld, void* y2, int y2_ld,
+                                   long long rows, int C, float eps, cvmi_stream_t stream_) {
+  CVMI_CHECK(x && gamma && beta && y && y2 && rows > 0 && C > 0, "layernorm_dual: bad arguments");
+  CVMI_CHECK(C % 8 == 0 && x_ld % 4 == 0 && y_ld % 4 == 0 && y2_ld % 8 == 0 && x_ld >= C && y_ld >= C && y2_ld >= C &&
+             (((uintptr_t)x | (uintptr_t)y | (uintptr_t)y2 | (uintptr_t)gamma | (uintptr_t)beta) & 15) == 0, "layernorm_dual: C=%d / ld not 16-byte aligned", C);
+  return launch_ln<float, float>(x, x_ld, gamma, beta, y, y_ld, rows, C, eps, CVMI_ACT_NONE, 0, 0, 0, 0, (hipStream_t)stream_, y2, y2_ld);
 }
 
 extern "C" int cvmi_maxpool2x2(const void* x, int x_ld, void* y, int y_ld, int B, int H, int W, int C, int dtype, cvmi_stream_t stream_) {

@@ -397,11 +397,26 @@ class Rows:
         return self.t.data_ptr() + self.offset * self.t.element_size()
 
 
-def op_layernorm(plan, label, src, gamma, beta, dst, eps=1e-6, act=_lib.ACT_NONE, pad=None):
-    """src / dst: Rows (or View, treated as B*H*W rows).  pad = (H, W, Hp, Wp): dst is the zero-padded grid."""
+def op_layernorm(plan, label, src, gamma, beta, dst, eps=1e-6, act=_lib.ACT_NONE, pad=None, dst2=None):
+    """src / dst: Rows (or View, treated as B*H*W rows).  pad = (H, W, Hp, Wp): dst is the zero-padded grid.
+    dst2 (f32 -> f32 only): an additional fp16 copy of the result."""
     lib = _lib.load()
     src, dst = _as_rows(src), _as_rows(dst)
     assert src.C == dst.C == gamma.numel()
+    if dst2 is not None:
+        dst2 = _as_rows(dst2)
+        assert pad is None and act == _lib.ACT_NONE and src.dtype == dst.dtype == _lib.F32 and dst2.dtype == _lib.F16
+        assert dst2.rows == src.rows and dst2.C == src.C
+        args2 = (src.ptr, src.ld, gamma.data_ptr(), beta.data_ptr(), dst.ptr, dst.ld, dst2.ptr, dst2.ld, src.rows, src.C, float(eps))
+        plan.keep.append((src, dst, dst2, gamma, beta))
+        sp1, fn2 = plan.sptr, lib.cvmi_layernorm_dual
+
+        def thunk2(sp=None):
+            sp = sp1 if sp is None else sp
+            _lib.check(fn2(*args2, sp), label)
+
+        plan.add(label, "layernorm", thunk2, src.rows * src.C * (4 + 4 + 2), 8 * src.rows * src.C)
+        return
     if pad is None:
         assert src.rows == dst.rows
         pad = (0, 0, 0, 0)

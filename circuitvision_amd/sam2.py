@@ -550,9 +550,9 @@ class Sam2Plan:
         self.feat_s0, self.feat_s1, self.keys0 = feat_s0, feat_s1, keys
         q = Buf(NB, 1, T, 256, F32, self.dev, zero=True)
 
-        def ln(label, key, src, dst):
+        def ln(label, key, src, dst, dst2=None):
             gam, bet = wt.ln[key]
-            op_layernorm(self.plan, label, src.view(), gam, bet, dst.view(), 1e-5)
+            op_layernorm(self.plan, label, src.view(), gam, bet, dst.view(), 1e-5, dst2=dst2.view() if dst2 is not None else None)
 
         def attention(label, qb, q_off, kb, k_off, vb, v_off, ob, Nq, Nk, hd):
             es = ESIZE[dt]
@@ -563,6 +563,7 @@ class Sam2Plan:
             op_attention(self.plan, label, desc, (qb, kb, vb, ob), flops=4 * NB * 8 * Nq * Nk * hd)
             self.plan.ops[-1] = (self.plan.ops[-1][0], "decoder") + self.plan.ops[-1][2:]
 
+        dual = dt == F16                         # norm4 writes the fp16 operand copy of the image stream itself (no cast pass)
         qn = bufd(1, T, 256, tag="qn")           # compute-dtype copies of the f32 streams
         kn = bufd(fs, fs, 256, tag="kn")
         G = lambda *a, **k: self.gemm(*a, kind="decoder", **k)
@@ -584,7 +585,8 @@ class Sam2Plan:
             ln(f"{p}.norm1", f"{p}.norm1", q, q)
             # --- tokens attend to the image
             op_cast(self.plan, f"{p}.t2i.castq", q.view(), qn.view())
-            op_cast(self.plan, f"{p}.t2i.castk", keys.view(), kn.view())
+            if l == 0 or not dual:
+                op_cast(self.plan, f"{p}.t2i.castk", keys.view(), kn.view())
             tq = bufd(1, T, 128, tag="t2i_q")
             G(f"{p}.t2i.q", f"{p}.t2i.q", qn.view(), tq.view(), **tpe(f"{p}.t2i.q_pe", 128))
             kv = bufd(fs, fs, 256, tag="t2i_kv")
@@ -608,10 +610,11 @@ class Sam2Plan:
             ao3 = bufd(fs, fs, 128, tag="i2t_ao")
             attention(f"{p}.i2t.attn", iq, 0, ikv, 0, ikv, 128, ao3, P, T, 16)
             G(f"{p}.i2t.out", f"{p}.i2t.out", ao3.view(), keys.view(), res=keys.view())
-            ln(f"{p}.norm4", f"{p}.norm4", keys, keys)
+            ln(f"{p}.norm4", f"{p}.norm4", keys, keys, dst2=kn if dual else None)      # + the fp16 copy the next k / v projection reads
         # --- final token -> image attention
         op_cast(self.plan, "final.castq", q.view(), qn.view())
-        op_cast(self.plan, "final.castk", keys.view(), kn.view())
+        if not dual:
+            op_cast(self.plan, "final.castk", keys.view(), kn.view())
         tq = bufd(1, T, 128, tag="t2i_q")
         G("final.q", "final.q", qn.view(), tq.view(), **tpe("final.q_pe", 128))
         kv = bufd(fs, fs, 256, tag="t2i_kv")

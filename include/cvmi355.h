@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define CVMI_VERSION 103
+#define CVMI_VERSION 104
 
 typedef void* cvmi_stream_t; /* hipStream_t */
 
@@ -211,6 +211,10 @@ int cvmi_nhwc_to_nchw_f32(const void* src, int src_dtype, int src_ld, float* dst
 int cvmi_layernorm(const void* x, int x_ld, int x_dtype, const float* gamma, const float* beta,
                    void* y, int y_ld, int y_dtype, long long rows, int C, float eps, int act,
                    int pad_h, int pad_w, int pad_hp, int pad_wp, cvmi_stream_t stream);
+/* Same over an f32 stream, writing the f32 result to y AND an fp16 copy to y2 (the GEMM-operand copy the next layer
+ * reads: saves a cast pass over the stream; SAM 2 two-way transformer norm4, sam2_infer.py:252). */
+int cvmi_layernorm_dual(const void* x, int x_ld, const float* gamma, const float* beta, void* y, int y_ld, void* y2, int y2_ld,
+                        long long rows, int C, float eps, cvmi_stream_t stream);
 
 /* 2x2 / stride 2 max-pool, NHWC (Hiera shortcut path of the q-pooling blocks: do_pool(proj(x))). */
 int cvmi_maxpool2x2(const void* x, int x_ld, void* y, int y_ld, int B, int H, int W, int C, int dtype,

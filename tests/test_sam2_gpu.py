@@ -37,6 +37,21 @@ def test_layernorm(din, dout, C_, act):
     torch.testing.assert_close(yb.t.float().cpu(), ref, **tol)
 
 
+def test_layernorm_dual_output():
+    """f32 stream -> f32 result + fp16 operand copy in one pass (the decoder's norm4)."""
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(2, 9, 11, 256, generator=g) * 2 - 0.5
+    gam, bet = torch.rand(256, generator=g) + 0.5, torch.randn(256, generator=g)
+    ref = F.layer_norm(x, (256,), gam, bet, 1e-5)
+    xb = Buf(2, 9, 11, 256, F32); xb.t.copy_(x)
+    yb = Buf(2, 9, 11, 256, F16, zero=True)
+    plan = Plan(stream())
+    op_layernorm(plan, "ln", xb.view(), gam.cuda(), bet.cuda(), xb.view(), 1e-5, dst2=yb.view())      # in place on the stream
+    run(plan)
+    torch.testing.assert_close(xb.t.cpu(), ref, rtol=1e-5, atol=1e-5)
+    assert torch.equal(yb.t.cpu(), xb.t.cpu().to(torch.float16))
+
+
 @pytest.mark.parametrize("dtype", [F16, F32])
 def test_maxpool_and_cast(dtype):
     g = torch.Generator().manual_seed(0)

@@ -18,6 +18,7 @@ def main():
     ap.add_argument("--batch", type=int, default=None)
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--top", type=int, default=0)
+    ap.add_argument("--prompts", type=int, default=0)
     a = ap.parse_args()
     stream = torch.cuda.Stream()
     if a.workload.startswith("yolo"):
@@ -29,7 +30,7 @@ def main():
     else:
         from circuitvision_amd.sam2 import HIERA_L, LORA_TARGETS_REFERENCE, Sam2Plan, Sam2Weights, SamSyntheticParams
         wt = Sam2Weights(SamSyntheticParams(0, LORA_TARGETS_REFERENCE), HIERA_L, 1024, _lib.F16)
-        sp = Sam2Plan(wt, a.batch or 16, stream)
+        sp = Sam2Plan(wt, a.batch or 16, stream, prompts=a.prompts)
         sp.x_in.t.normal_(0, 1)
         plan = sp.plan
     torch.cuda.synchronize()
