@@ -24,6 +24,7 @@ struct AttnArgs {
   int B, heads, Nq, Nk, dqk, dv;
   float scale;
   int win, grid_h, grid_w, q_pool;
+  int q_bdiv, kv_bdiv;   // batch sharing (no window): q rows of batch entry b come from entry b / q_bdiv, k / v rows from b / kv_bdiv
   int qtiles;      // ceil(Nq / 32)
   int items;       // B * heads * qtiles
   FastDiv div_win; // window mode: key -> (row, column) inside the window without a hardware division
@@ -88,7 +89,7 @@ __global__ __launch_bounds__(256) void attn_f16_kernel(const AttnArgs p) {
       u32x4 v = {0u, 0u, 0u, 0u};
       if (q_ok && d0 < p.dqk) {
         if (!p.q_pool) {
-          const long long off = tok_off(b, qi, p.q_sb, p.q_st, p.win, p.grid_h, p.grid_w) + (long long)h * p.q_sh + d0;
+          const long long off = tok_off(b / p.q_bdiv, qi, p.q_sb, p.q_st, p.win, p.grid_h, p.grid_w) + (long long)h * p.q_sh + d0;
           v = *reinterpret_cast<const u32x4*>(p.q + off * 2);
         } else {                               // q = 2x2 max-pool of the window's projected q tokens
           const int py = qi / qwin, px = qi - py * qwin;
@@ -144,7 +145,7 @@ __global__ __launch_bounds__(256) void attn_f16_kernel(const AttnArgs p) {
       const long long pix0 = tok_off(lb, 0, 1, 1, p.win, p.grid_h, p.grid_w);      // window origin, in pixels
       korg = pix0 * p.k_st; vorg = pix0 * p.v_st;
     } else {
-      korg = (long long)lb * p.k_sb; vorg = (long long)lb * p.v_sb;
+      korg = (long long)(lb / p.kv_bdiv) * p.k_sb; vorg = (long long)(lb / p.kv_bdiv) * p.v_sb;
     }
     kbase = p.k + (korg + (long long)lhd * p.k_sh) * 2;
     vbase = p.v + (vorg + (long long)lhd * p.v_sh) * 2;
@@ -356,7 +357,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn64_kernel(const 
     const int qc = q_ok ? qi : 0;
     int t = qc;
     if (p.q_pool) { const int py = qc / qwin, px = qc - py * qwin; t = (2 * py) * p.win + 2 * px; }
-    qoff0 = tok_off(b, t, p.q_sb, p.q_st, p.win, p.grid_h, p.grid_w) + (long long)h * p.q_sh;
+    qoff0 = tok_off(b / p.q_bdiv, t, p.q_sb, p.q_st, p.win, p.grid_h, p.grid_w) + (long long)h * p.q_sh;
   }
   u32x4 qf[QS];
 #pragma unroll
@@ -401,7 +402,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn64_kernel(const 
       const long long pix0 = tok_off(b, 0, 1, 1, p.win, p.grid_h, p.grid_w);
       korg = pix0 * p.k_st; vorg = pix0 * p.v_st;
     } else {
-      korg = (long long)b * p.k_sb; vorg = (long long)b * p.v_sb;
+      korg = (long long)(b / p.kv_bdiv) * p.k_sb; vorg = (long long)(b / p.kv_bdiv) * p.v_sb;
     }
     kbase = p.k + (korg + (long long)h * p.k_sh) * 2;
     vbase = p.v + (vorg + (long long)h * p.v_sh) * 2;
@@ -1404,6 +1405,10 @@ extern "C" int cvmi_attention(const cvmi_attn_desc* d, cvmi_stream_t stream_) {
   a.v_sb = d->v_sb; a.v_sh = d->v_sh; a.v_st = d->v_st; a.o_sb = d->o_sb; a.o_sh = d->o_sh; a.o_st = d->o_st;
   a.B = d->B; a.heads = d->heads; a.Nq = d->Nq; a.Nk = d->Nk; a.dqk = d->dqk; a.dv = d->dv; a.scale = d->scale;
   a.win = d->win; a.grid_h = d->grid_h; a.grid_w = d->grid_w; a.q_pool = d->q_pool;
+  a.q_bdiv = d->q_bdiv > 1 ? d->q_bdiv : 1; a.kv_bdiv = d->kv_bdiv > 1 ? d->kv_bdiv : 1;
+  const bool shared = a.q_bdiv > 1 || a.kv_bdiv > 1;
+  CVMI_CHECK(!shared || (d->win == 0 && d->dtype == CVMI_F16 && d->dqk <= 64 && d->dv <= 64 && d->B % a.q_bdiv == 0 && d->B % a.kv_bdiv == 0),
+             "attention: batch sharing (q_bdiv / kv_bdiv) needs fp16, no window, head dims <= 64 and B a multiple of the divisor");
   a.qtiles = (d->Nq + 31) / 32;
   a.div_win.init(d->win > 0 ? (unsigned)d->win : 1u);
   a.items = d->B * d->heads * a.qtiles;

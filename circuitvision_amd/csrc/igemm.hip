@@ -105,6 +105,15 @@ __device__ __forceinline__ u32x4 gather_chunk(const ConvKArgs& p, int k, int b, 
   return v;
 }
 
+// residual row of output row m: plain, a constant broadcast over the batch (res_mod rows, m % res_mod), or one image's rows
+// shared by res_rep consecutive batch entries (res_mod rows per image: entry e reads image e / res_rep)
+__device__ __forceinline__ size_t res_row(const ConvKArgs& p, int m) {
+  if (p.res_mod <= 0) return (size_t)m;
+  const int r = m % p.res_mod;
+  if (p.res_rep <= 1) return (size_t)r;
+  return (size_t)(m / p.res_mod / p.res_rep) * (size_t)p.res_mod + (size_t)r;
+}
+
 // ---- shared epilogue: bias + act in registers -> LDS tile [BM][BN] (TO) -> coalesced 16-byte stores (+ residual,
 //      batch-broadcast residual, activation-after-residual, ConvTranspose scatter) -----------------------------------
 template <typename T, typename TO, int BM, int BN, int WM, int WN, int KS = 1>
@@ -136,7 +145,7 @@ __device__ __forceinline__ void gemm_epilogue(const ConvKArgs& p, f32x16 (&acc)[
       const int row = idx / NCH_, ch = idx - row * NCH_;
       int m = m0 + row;
       m = m < p.M ? m : p.M - 1;
-      const size_t rpix = p.res_mod > 0 ? (size_t)(m % p.res_mod) : (size_t)m;
+      const size_t rpix = res_row(p, m);
       rv[it] = *reinterpret_cast<const u32x4*>(p.res + (rpix * p.res_ld + n0 + ch * OVEC) * OES);
     }
   }
@@ -195,7 +204,7 @@ __device__ __forceinline__ void gemm_epilogue(const ConvKArgs& p, f32x16 (&acc)[
     const int m = m0 + row, n = n0 + ch * OVEC;
     if (m >= p.M || n >= p.N) continue;
     u32x4 cv = *reinterpret_cast<const u32x4*>(Ct + row * CROWB + ch * 16);
-    size_t ypix = (size_t)m, rpix = p.res_mod > 0 ? (size_t)(m % p.res_mod) : (size_t)m;
+    size_t ypix = (size_t)m, rpix = res_row(p, m);
     int nn = n;
     if (p.shuf_c > 0) {                            // ConvTranspose 2x2/s2: scatter to the 2x grid
       const int q = n / p.shuf_c;
@@ -1459,7 +1468,7 @@ int launch_typed(ConvKArgs& a, hipStream_t stream) {
     // (N = 576 -> 75 % of 3 column tiles: ties / loses against the 128-row kernels below)
     static const int g256_mink = getenv("CVMI_G256_MINK") ? atoi(getenv("CVMI_G256_MINK")) : 128;     // tuning experiments only
     static const int g256_minn = getenv("CVMI_G256_MINN") ? atoi(getenv("CVMI_G256_MINN")) : 384;
-    if (use_g256 && a.plain && a.K % 8 == 0 && a.K >= g256_mink && a.Kpad % 64 == 0 && N % 8 == 0 && N >= g256_minn && a.shuf_c == 0) {
+    if (use_g256 && a.plain && a.K % 8 == 0 && a.K >= g256_mink && a.Kpad % 64 == 0 && N % 8 == 0 && N >= g256_minn && a.shuf_c == 0 && a.res_rep <= 1) {
       const long long tiles = (long long)cdiv(M, 256) * cdiv(N, 256);
       const double col_eff = (double)N / (cdiv(N, 256) * 256), wave_eff = (double)tiles / (double)(cdiv(tiles, 256) * 256);
       if (tiles >= 256 && ((col_eff >= 0.8 && wave_eff >= 0.8) || use_g256 >= 3)) {
@@ -1561,7 +1570,8 @@ extern "C" int cvmi_conv2d(const cvmi_conv_desc* d, cvmi_stream_t stream_) {
   a.rows2 = (!a.plain && d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0 && !d->scalar_gather && d->OH == d->H && d->OW == d->W &&
              d->c1 > 0 && d->c0 % 64 == 0 && ctot % 64 == 0 && d->dtype == CVMI_F16) ? 1 : 0;
   CVMI_CHECK(d->res_mod >= 0 && d->shuffle_cout >= 0, "conv2d: negative res_mod / shuffle_cout");
-  CVMI_CHECK(d->res_rep <= 1 || (d->shuffle_cout > 0 && d->res && d->B % d->res_rep == 0), "conv2d: res_rep needs shuffle_cout, a residual and B %% res_rep == 0");
+  CVMI_CHECK(d->res_rep <= 1 || (d->res && d->B % d->res_rep == 0 && (d->shuffle_cout > 0 || d->res_mod == d->OH * d->OW)),
+             "conv2d: res_rep needs a residual, B %% res_rep == 0 and either shuffle_cout or res_mod == OH * OW");
   if (d->shuffle_cout > 0) {
     CVMI_CHECK(d->N == 4 * d->shuffle_cout && d->shuffle_cout % ovec == 0 && d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0 &&
                d->res_mod == 0, "conv2d: shuffle_cout needs a 1x1 conv with N == 4*shuffle_cout (multiple of %d)", ovec);

@@ -231,7 +231,8 @@ def op_conv(plan, label, pc, srcs, dst, stride=1, pad=None, act=_lib.ACT_NONE, r
     else:
         assert (dst.B, dst.H, dst.W) == (v0.B, OH, OW) and dst.c == pc.N, (label, (dst.B, dst.H, dst.W, dst.c), (v0.B, OH, OW, pc.N))
     if res_rep > 1:
-        assert shuffle_cout and res is not None and res.B * res_rep == v0.B, (label, "res_rep needs a per-image residual")
+        assert res is not None and res.B * res_rep == v0.B, (label, "res_rep needs a per-image residual")
+        assert shuffle_cout or res_mod == dst.H * dst.W, (label, "res_rep: ConvTranspose scatter or res_mod = rows per image")
     out_f32 = 1 if (dst.dtype == F32 and pc.dtype == F16) else 0
     d = ConvDesc(
         x0=v0.ptr, x1=(v1.ptr if v1 is not None else None), w=pc.w.data_ptr(), bias=pc.bias.data_ptr(),

@@ -20,6 +20,7 @@ mode GEMM / attention operands are fp16.  F32 mode runs everything on exact-f32 
 """
 import hashlib
 import math
+import os
 import threading
 
 import numpy as np
@@ -531,8 +532,14 @@ class Sam2Plan:
             emb = self.buf(fs, fs, 256, F32)
             self.gemm("embed", "embed_box", [(s2.view(), 0), (s3.view(), 1)], emb.view(), kind="neck")
             keys = bufd(fs, fs, 256, F32)
-            op_call(self.plan, "repeat_embed", "decoder", lib.cvmi_repeat_images, (emb.t.data_ptr(), keys.t.data_ptr(), P * 256 * 4, B, NP),
-                    keep=(emb, keys), bytes_=(B + NB) * P * 256 * 4)
+            # Until layer 0's image -> token attention writes into it, the image stream of every prompt of an image IS that image's
+            # embedding: in fp16 mode layer 0 reads the B shared copies (k / v and q projections on B images instead of B * P,
+            # attention kernels index the shared batch entry, the first residual add broadcasts) and the repeat pass disappears.
+            # f32 parity mode keeps the literal repeat_image formulation (upstream MaskDecoder.predict_masks) as the cross-check.
+            self.share_l0 = dt == F16 and os.environ.get("CVMI_SAM_SHARE_L0", "1") != "0"
+            if not self.share_l0:
+                op_call(self.plan, "repeat_embed", "decoder", lib.cvmi_repeat_images, (emb.t.data_ptr(), keys.t.data_ptr(), P * 256 * 4, B, NP),
+                        keep=(emb, keys), bytes_=(B + NB) * P * 256 * 4)
             T = 6 + self.K
             self.coords = torch.zeros(NB, self.K, 2, dtype=torch.float32, device=self.dev)
             self.labels = torch.full((NB, self.K), -1, dtype=torch.int32, device=self.dev)
@@ -554,12 +561,12 @@ class Sam2Plan:
             gam, bet = wt.ln[key]
             op_layernorm(self.plan, label, src.view(), gam, bet, dst.view(), 1e-5, dst2=dst2.view() if dst2 is not None else None)
 
-        def attention(label, qb, q_off, kb, k_off, vb, v_off, ob, Nq, Nk, hd):
+        def attention(label, qb, q_off, kb, k_off, vb, v_off, ob, Nq, Nk, hd, q_bdiv=0, kv_bdiv=0):
             es = ESIZE[dt]
             desc = make_attn_desc(q=qb.t.data_ptr() + q_off * es, k=kb.t.data_ptr() + k_off * es, v=vb.t.data_ptr() + v_off * es, o=ob.t.data_ptr(),
                                   q_sb=Nq * qb.C, q_sh=hd, q_st=qb.C, k_sb=Nk * kb.C, k_sh=hd, k_st=kb.C, v_sb=Nk * vb.C, v_sh=hd, v_st=vb.C,
                                   o_sb=Nq * ob.C, o_sh=hd, o_st=ob.C, B=NB, heads=8, Nq=Nq, Nk=Nk, dqk=hd, dv=hd, scale=hd ** -0.5, dtype=dt,
-                                  win=0, grid_h=0, grid_w=0, q_pool=0)
+                                  win=0, grid_h=0, grid_w=0, q_pool=0, q_bdiv=q_bdiv, kv_bdiv=kv_bdiv)
             op_attention(self.plan, label, desc, (qb, kb, vb, ob), flops=4 * NB * 8 * Nq * Nk * hd)
             self.plan.ops[-1] = (self.plan.ops[-1][0], "decoder") + self.plan.ops[-1][2:]
 
@@ -585,14 +592,20 @@ class Sam2Plan:
             ln(f"{p}.norm1", f"{p}.norm1", q, q)
             # --- tokens attend to the image
             op_cast(self.plan, f"{p}.t2i.castq", q.view(), qn.view())
-            if l == 0 or not dual:
-                op_cast(self.plan, f"{p}.t2i.castk", keys.view(), kn.view())
+            share = l == 0 and NP and getattr(self, "share_l0", False)      # layer 0 of the box path: image-side tensors per IMAGE
+            if share:
+                kn_l = self.buf(fs, fs, 256, tag="kn_shared")
+                op_cast(self.plan, f"{p}.t2i.castk", emb.view(), kn_l.view())
+            else:
+                kn_l = kn
+                if l == 0 or not dual:
+                    op_cast(self.plan, f"{p}.t2i.castk", keys.view(), kn.view())
             tq = bufd(1, T, 128, tag="t2i_q")
             G(f"{p}.t2i.q", f"{p}.t2i.q", qn.view(), tq.view(), **tpe(f"{p}.t2i.q_pe", 128))
-            kv = bufd(fs, fs, 256, tag="t2i_kv")
-            G(f"{p}.t2i.kv", f"{p}.t2i.kv", kn.view(), kv.view(), res=_ConstView(wt.const[f"{p}.t2i.kv_pe"], 256), res_mod=P)
+            kv = self.buf(fs, fs, 256, tag="t2i_kv_shared") if share else bufd(fs, fs, 256, tag="t2i_kv")
+            G(f"{p}.t2i.kv", f"{p}.t2i.kv", kn_l.view(), kv.view(), res=_ConstView(wt.const[f"{p}.t2i.kv_pe"], 256), res_mod=P)
             ao2 = bufd(1, T, 128, tag="t2i_ao")
-            attention(f"{p}.t2i.attn", tq, 0, kv, 0, kv, 128, ao2, T, P, 16)
+            attention(f"{p}.t2i.attn", tq, 0, kv, 0, kv, 128, ao2, T, P, 16, kv_bdiv=NP if share else 0)
             G(f"{p}.t2i.out", f"{p}.t2i.out", ao2.view(), q.view(), res=q.view())
             ln(f"{p}.norm2", f"{p}.norm2", q, q)
             # --- MLP on the tokens
@@ -603,13 +616,16 @@ class Sam2Plan:
             ln(f"{p}.norm3", f"{p}.norm3", q, q)
             # --- image attends to the tokens
             op_cast(self.plan, f"{p}.i2t.castq", q.view(), qn.view())
-            iq = bufd(fs, fs, 128, tag="i2t_q")
-            G(f"{p}.i2t.q", f"{p}.i2t.q", kn.view(), iq.view(), res=_ConstView(wt.const[f"{p}.i2t.q_pe"], 128), res_mod=P)
+            iq = self.buf(fs, fs, 128, tag="i2t_q_shared") if share else bufd(fs, fs, 128, tag="i2t_q")
+            G(f"{p}.i2t.q", f"{p}.i2t.q", kn_l.view(), iq.view(), res=_ConstView(wt.const[f"{p}.i2t.q_pe"], 128), res_mod=P)
             ikv = bufd(1, T, 256, tag="i2t_kv")
             G(f"{p}.i2t.kv", f"{p}.i2t.kv", qn.view(), ikv.view(), **tpe(f"{p}.i2t.kv_pe", 256))
             ao3 = bufd(fs, fs, 128, tag="i2t_ao")
-            attention(f"{p}.i2t.attn", iq, 0, ikv, 0, ikv, 128, ao3, P, T, 16)
-            G(f"{p}.i2t.out", f"{p}.i2t.out", ao3.view(), keys.view(), res=keys.view())
+            attention(f"{p}.i2t.attn", iq, 0, ikv, 0, ikv, 128, ao3, P, T, 16, q_bdiv=NP if share else 0)
+            if share:      # first write of the per-prompt image stream: keys[b] = emb[b / P] + out-projection
+                G(f"{p}.i2t.out", f"{p}.i2t.out", ao3.view(), keys.view(), res=emb.view(), res_mod=P, res_rep=NP)
+            else:
+                G(f"{p}.i2t.out", f"{p}.i2t.out", ao3.view(), keys.view(), res=keys.view())
             ln(f"{p}.norm4", f"{p}.norm4", keys, keys, dst2=kn if dual else None)      # + the fp16 copy the next k / v projection reads
         # --- final token -> image attention
         op_cast(self.plan, "final.castq", q.view(), qn.view())

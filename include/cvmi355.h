@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define CVMI_VERSION 104
+#define CVMI_VERSION 105
 
 typedef void* cvmi_stream_t; /* hipStream_t */
 
@@ -81,8 +81,8 @@ typedef struct cvmi_conv_desc {
   int shuffle_cout;                 /* > 0: ConvTranspose2d(k=2,s=2) as GEMM: N = 4*shuffle_cout, column
                                        n = (dy*2+dx)*shuffle_cout + co is stored at output pixel
                                        (2*oy+dy, 2*ox+dx), channel co of a [B,2*OH,2*OW,*] tensor (y, res) */
-  int res_rep;                      /* > 1 (with shuffle_cout): the residual has B / res_rep images, image b reads
-                                       residual image b / res_rep (high-res features shared by the prompts of an image) */
+  int res_rep;                      /* > 1 (with shuffle_cout, or with res_mod == OH * OW): the residual has B / res_rep images, image b
+                                       reads residual image b / res_rep (tensors shared by the prompts of an image) */
 } cvmi_conv_desc;
 int cvmi_conv2d(const cvmi_conv_desc* d, cvmi_stream_t stream);
 
@@ -156,6 +156,9 @@ typedef struct cvmi_attn_desc {
   int dtype;
   int win, grid_h, grid_w;   /* window mode (0 = off): window side, image grid size in pixels */
   int q_pool;                /* 1: q window is max-pooled 2x2 (Nq = (win/2)^2) */
+  int q_bdiv, kv_bdiv;       /* > 1 (fp16, no window, head dims <= 64): q rows of batch entry b are read from entry b / q_bdiv,
+                                k / v rows from entry b / kv_bdiv -- the prompts of one image sharing its image-side tensors
+                                (SAM 2 MaskDecoder with repeat_image, first two-way layer); 0 / 1 = off */
 } cvmi_attn_desc;
 int cvmi_attention(const cvmi_attn_desc* d, cvmi_stream_t stream);
 

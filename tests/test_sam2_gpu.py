@@ -433,6 +433,22 @@ def test_sam2_box_prompts_mini_match_oracle(dtype):
     assert float((lo[:, 0] - lo[:, 1]).abs().max()) > 1e-3            # the prompts do change the masks
 
 
+def test_sam2_box_decoder_layer0_sharing_equals_repeat_image(monkeypatch):
+    """fp16 box path: layer 0 on the B shared image embeddings (attention batch divisors, broadcast residual) vs the literal
+    repeat_image formulation (B * P copies) on the same weights: same masks up to the summation order of different GEMM tiles."""
+    B, P, R = 2, 5, 256
+    outs = []
+    for share in ("1", "0"):
+        monkeypatch.setenv("CVMI_SAM_SHARE_L0", share)
+        sp, _ = _run_boxes(MINI, mini_targets(), lambda p: mini_oracle(p, R), R, F16, B, P)
+        labels = [op[0] for op in sp.plan.ops]
+        assert ("repeat_embed" in labels) == (share == "0")
+        outs.append((sp.low_res.clone().cpu(), sp.iou.clone().cpu(), sp.keys_out.t.clone().cpu()))
+    torch.testing.assert_close(outs[0][2], outs[1][2], rtol=2e-3, atol=2e-3)          # image stream after the two-way transformer
+    torch.testing.assert_close(outs[0][0], outs[1][0], rtol=5e-3, atol=5e-3)
+    torch.testing.assert_close(outs[0][1], outs[1][1], rtol=5e-3, atol=5e-3)
+
+
 def test_infer_masks_boxes_boundary_and_graph_replay():
     """`infer_masks(images, boxes)` through the model object: graph replay with new boxes, boxes=None == forward."""
     from circuitvision_amd.sam2 import Sam2Weights, SamSyntheticParams
