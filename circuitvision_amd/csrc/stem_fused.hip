@@ -22,15 +22,22 @@ constexpr int TH = 8, TW = 16;
 constexpr int SH = 2 * TH + 1, SW = 2 * TW + 1;   // model.0 halo tile (17 x 33)
 constexpr int PH = SH + 1, PW = SW + 1;           // s2d patch (18 x 34)
 constexpr int NS = SH * SW;                       // 561 stem pixels
-constexpr int PXB = 32;                           // 16 fp16 channels per pixel, unpadded
+// LDS layouts (no padding bytes; both conflict-free for the 16-byte MFMA operand reads):
+//   patch  [chunk 0..1][pixel]                      a lane group reads one 8-channel chunk of consecutive pixels -> consecutive slots
+//   T      [chunk 0..1][column parity][row][17]     model.1 walks T with stride 2 in x: even and odd columns live in separate planes,
+//                                                   so its 16 consecutive output columns read 16 consecutive slots
+constexpr int PPLANE = PH * PW * 16;              // bytes of one patch chunk plane (612 pixels)
+constexpr int TROW = (SW / 2 + 1) * 16;           // 17 slots per (parity, row)
+constexpr int TPLANE = SH * TROW;                 // one (chunk, parity) plane
+__device__ __forceinline__ int t_off(int ck, int sy, int sx) { return ((ck * 2 + (sx & 1)) * SH + sy) * TROW + (sx >> 1) * 16; }
 
 __device__ __forceinline__ void mma16(const u32x4& a, const u32x4& b, f32x16& c) {
   c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
 
 __global__ __launch_bounds__(256, 4) void stem2_kernel(const StemArgs p) {
-  constexpr int PATCH_B = PH * PW * PXB;            // 19584
-  constexpr int T_B = (NS + 31) / 32 * 32 * PXB;    // 18432 (576 pixel slots)
+  constexpr int PATCH_B = 2 * PPLANE;               // 19584
+  constexpr int T_B = 4 * TPLANE;                   // 18496
   constexpr int OSTR = 32 * 2 + 16;                 // output tile row stride
   static_assert(TH * TW * OSTR <= PATCH_B, "the output tile overlays the patch");
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -77,7 +84,8 @@ __global__ __launch_bounds__(256, 4) void stem2_kernel(const StemArgs p) {
   const float bias_v = tid < 32 ? p.b0[tid] : (tid < 64 ? p.b1[tid - 32] : 0.f);
   if (p_rsel < RPP) {
 #pragma unroll
-    for (int i = 0; i < NP; ++i) *reinterpret_cast<u32x4*>(patch + ((i * RPP + p_rsel) * RC + p_t) * 16) = pok[i] ? pv[i] : u32x4{0u, 0u, 0u, 0u};
+    for (int i = 0; i < NP; ++i)
+      *reinterpret_cast<u32x4*>(patch + (p_t & 1) * PPLANE + ((i * RPP + p_rsel) * PW + (p_t >> 1)) * 16) = pok[i] ? pv[i] : u32x4{0u, 0u, 0u, 0u};
   }
   if (tid < 64) b0s[tid] = bias_v;                   // b0s[0..32) = model.0 bias (16 real), b1s = b0s + 32
   __syncthreads();
@@ -90,25 +98,24 @@ __global__ __launch_bounds__(256, 4) void stem2_kernel(const StemArgs p) {
   for (int mt = wv; mt < (NS + 31) / 32; mt += 4, sy += 3, sx += 128 - 3 * SW) {
     if (sx >= SW) { sx -= SW; ++sy; }
     const int m = mt * 32 + lr;
-    if (m >= NS) { sy = SH - 1; sx = SW - 1; }          // slots past the tile: any valid pixel (their output is zeroed, never read)
+    if (m >= NS) { sy = SH - 1; sx = SW - 1; }          // lanes past the tile: any valid pixel for the reads; they do not write
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      const u32x4 xf = *reinterpret_cast<const u32x4*>(patch + ((sy + (t >> 1)) * PW + sx + (t & 1)) * PXB + lh * 16);
+      const u32x4 xf = *reinterpret_cast<const u32x4*>(patch + lh * PPLANE + ((sy + (t >> 1)) * PW + sx + (t & 1)) * 16);
       mma16(w0f[t], xf, acc);
     }
     const bool in_img = m < NS && (unsigned)(Y0 + sy) < (unsigned)p.H2 && (unsigned)(X0 + sx) < (unsigned)p.W2;
 #pragma unroll
     for (int q = 0; q < 2; ++q) {                     // registers 4q..4q+3 = channels 8q + 4 lh + (0..3)
-      const int nl = 8 * q + 4 * lh;
       const f32x4 bv = b0v[q];
       float v[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] = in_img ? act_apply<true>(acc[4 * q + e] + bv[e], CVMI_ACT_SILU) : 0.f;   // outside: model.1's zero padding
       const f16x4 hv = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
-      *reinterpret_cast<f16x4*>(T + m * PXB + nl * 2) = hv;
+      if (m < NS) *reinterpret_cast<f16x4*>(T + t_off(q, sy, sx) + lh * 8) = hv;      // chunk q = channels 8q..8q+7, this lane's half at 4 lh
     }
   }
   __syncthreads();
@@ -122,7 +129,7 @@ __global__ __launch_bounds__(256, 4) void stem2_kernel(const StemArgs p) {
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
-      const u32x4 xf = *reinterpret_cast<const u32x4*>(T + ((2 * r + t / 3) * SW + 2 * c + t % 3) * PXB + lh * 16);
+      const u32x4 xf = *reinterpret_cast<const u32x4*>(T + t_off(lh, 2 * r + t / 3, 2 * c + t % 3));
       mma16(w1f[t], xf, acc);
     }
     char* const Ot = patch;                           // the patch is dead since the barrier above
@@ -165,7 +172,7 @@ extern "C" int cvmi_stem2(const void* x, int x_ld, const void* w0, const float* 
   a.tiles_x = cdiv(a.OW, TW); a.tiles_y = cdiv(a.OH, TH);
   const long long blocks = (long long)B * a.tiles_y * a.tiles_x;
   CVMI_CHECK(blocks > 0 && blocks < (1ll << 31), "stem2: bad grid");
-  constexpr size_t lds = (size_t)PH * PW * PXB + (size_t)(NS + 31) / 32 * 32 * PXB + 64 * sizeof(float);
+  constexpr size_t lds = (size_t)2 * PPLANE + (size_t)4 * TPLANE + 64 * sizeof(float);
   hipLaunchKernelGGL(stem2_kernel, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream_, a);
   CVMI_LAUNCH_CHECK();
   return 0;
