@@ -398,7 +398,7 @@ class Yolo11Plan:
         lanes = int(os.environ.get("CVMI_YOLO_LANES", "3"))
         if lanes:
             self.plan.fork()
-            self.plan.lane(1 if lanes == 3 else (1 + min(i, 1)) if lanes == 4 else 2 * i + 1)
+            self.plan.lane(1 if lanes in (3, 5) else (1 + min(i, 1)) if lanes == 4 else 2 * i + 1)
         t1 = self.buf(f.H, f.W, c2).view()
         t2 = self.buf(f.H, f.W, c2).view()
         bx = self.buf(f.H, f.W, 64).view()
@@ -407,6 +407,8 @@ class Yolo11Plan:
         self.cv(f"model.23.cv2.{i}.2", t2, bx, act=ACT_NONE, kind="head")
         if lanes == 2:
             self.plan.lane(2 * i + 2)
+        elif lanes == 5 and i == 2:
+            self.plan.lane(2)                # the last level is the serial tail of the step: its two branches side by side
         cl = Buf(self.B, f.H, f.W, ncp, self.dt, self.dev, zero=True)
         self.act_bytes += cl.nbytes
         u1 = self.buf(f.H, f.W, c3).view()
