@@ -70,13 +70,13 @@ class SAM2Model:
     def to(self, *_a, **_k):
         return self
 
-    def plan(self, B, prompts=0, high_res=True):
+    def plan(self, B, prompts=0, high_res=True, points=3):
         if self.weights is None:
             raise RuntimeError("SAM2 weights not loaded (call load_state_dict first)")
-        key = (B, prompts, high_res)
+        key = (B, prompts, high_res, points if prompts else 0)
         if key not in self._plans:
             with torch.cuda.device(self.dev):
-                self._plans[key] = Sam2Plan(self.weights, B, self.stream, self.dynamic, prompts=prompts, high_res=high_res)
+                self._plans[key] = Sam2Plan(self.weights, B, self.stream, self.dynamic, prompts=prompts, points=points, high_res=high_res)
         return self._plans[key]
 
     def _stage_images(self, p, images):
@@ -114,27 +114,51 @@ class SAM2Model:
 
     forward = __call__
 
-    def infer_masks(self, images, boxes=None, return_high_res=True):
+    def infer_masks(self, images, boxes=None, return_high_res=True, points=None, point_labels=None):
         """Batched segmentation entry point (north_star).  images [B,3,R,R].
-        boxes=None: exactly `SAM2ImageWrapper.forward` (learned prompts) -> (high_res [B,1,R,R], low_res [B,1,R/4,R/4], iou [B,1]).
-        boxes [B,P,4] (xyxy in the R x R input pixel space, e.g. detector boxes scaled by R / original size): upstream
-        SAM2ImagePredictor box prompting on the same weights, one mask per box (multimask_output=False with the stability
-        fallback) -> (high_res logits [B,P,R,R] or None, low_res logits [B,P,R/4,R/4] (unclamped), iou [B,P])."""
-        if boxes is None:
+        No prompt: exactly `SAM2ImageWrapper.forward` (learned prompts) -> (high_res [B,1,R,R], low_res [B,1,R/4,R/4], iou [B,1]).
+        boxes [B,P,4] (xyxy in the R x R input pixel space, e.g. detector boxes scaled by R / original size) and / or
+        points [B,P,K,2] (x, y) with point_labels [B,P,K] (1 foreground click, 0 background click, -1 "not a point" padding token,
+        upstream's filler for ragged click lists -- still a token the decoder sees): upstream
+        SAM2ImagePredictor prompting on the same weights -- a box enters as two corner points labelled 2 / 3, clicks follow it,
+        one padding point closes the list -- one mask per prompt (multimask_output=False with the stability fallback) ->
+        (high_res logits [B,P,R,R] or None, low_res logits [B,P,R/4,R/4] (unclamped), iou [B,P])."""
+        if boxes is None and points is None:
             return self(images)
         self._check_images(images)
-        bx = torch.as_tensor(boxes, dtype=torch.float32)
         B = images.shape[0]
-        if bx.dim() != 3 or bx.shape[0] != B or bx.shape[2] != 4 or bx.shape[1] == 0:
-            raise ValueError(f"boxes must be [B={B}, P>0, 4] xyxy, got {tuple(bx.shape)}")
-        P = bx.shape[1]
+        bx = pts = None
+        if boxes is not None:
+            bx = torch.as_tensor(boxes, dtype=torch.float32)
+            if bx.dim() != 3 or bx.shape[0] != B or bx.shape[2] != 4 or bx.shape[1] == 0:
+                raise ValueError(f"boxes must be [B={B}, P>0, 4] xyxy, got {tuple(bx.shape)}")
+        if points is not None:
+            pts = torch.as_tensor(points, dtype=torch.float32)
+            if point_labels is None:
+                raise ValueError("points need point_labels")
+            lab = torch.as_tensor(point_labels).to(torch.int32)
+            if pts.dim() != 4 or pts.shape[0] != B or pts.shape[3] != 2 or pts.shape[1] == 0 or pts.shape[2] == 0 or tuple(lab.shape) != tuple(pts.shape[:3]):
+                raise ValueError(f"points must be [B={B}, P>0, K>0, 2] with point_labels [B, P, K], got {tuple(pts.shape)} / {tuple(lab.shape)}")
+            if bx is not None and bx.shape[1] != pts.shape[1]:
+                raise ValueError("boxes and points disagree on the number of prompts per image")
+            if int(lab.min()) < -1 or int(lab.max()) > 1:
+                raise ValueError("point_labels must be -1 (padding token), 0 (background) or 1 (foreground)")
+        P = (bx if bx is not None else pts).shape[1]
+        nb, nk = (2 if bx is not None else 0), (pts.shape[2] if pts is not None else 0)
+        K = nb + nk + 1                                            # + the closing padding point
         R, f0 = self.image_size, self.image_size // 4
         with self._lock, torch.cuda.device(self.dev):
-            p = self.plan(B, prompts=P, high_res=return_high_res)
-            corners = bx.reshape(B * P, 2, 2)
-            p.coords[:, :2].copy_(corners, non_blocking=False)
-            p.coords[:, 2].zero_()
-            p.labels.copy_(torch.tensor([2, 3, -1], dtype=torch.int32).expand(B * P, 3))
+            p = self.plan(B, prompts=P, high_res=return_high_res, points=K)
+            coords = torch.zeros(B * P, K, 2, dtype=torch.float32)
+            labels = torch.full((B * P, K), -1, dtype=torch.int32)
+            if bx is not None:
+                coords[:, :2] = bx.reshape(B * P, 2, 2)
+                labels[:, 0], labels[:, 1] = 2, 3
+            if pts is not None:
+                coords[:, nb:nb + nk] = pts.reshape(B * P, nk, 2)
+                labels[:, nb:nb + nk] = lab.reshape(B * P, nk)
+            p.coords.copy_(coords, non_blocking=False)
+            p.labels.copy_(labels, non_blocking=False)
             keep = self._stage_images(p, images)
             p.plan.run()
             self.stream.synchronize()

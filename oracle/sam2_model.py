@@ -507,6 +507,32 @@ def predict_boxes(wrapper, images, boxes, multimask_output=False):
     return torch.stack(his), torch.stack(lows), torch.stack(ious)
 
 
+def predict_prompts(wrapper, images, boxes=None, points=None, labels=None, multimask_output=False):
+    """predict_boxes generalised to the predictor's full sparse prompt (SAM2ImagePredictor._predict): per prompt the box
+    corners (labels 2 / 3) first, then the clicks (points [B,P,K,2], labels [B,P,K] in {1, 0, -1}), then one padding point."""
+    m = wrapper.sam2_model
+    embed, high_res = wrapper.encode(images)
+    embed = embed + m.no_mem_embed.view(1, -1, 1, 1)
+    fs = embed.shape[-1]
+    pe = dense_pe(m.sam_prompt_encoder.pe_layer.positional_encoding_gaussian_matrix, fs, fs)
+    dense = m.sam_prompt_encoder.dense_no_mask(fs)
+    his, lows, ious = [], [], []
+    for b in range(images.shape[0]):
+        cs, ls = [], []
+        if boxes is not None:
+            cs.append(boxes[b].float().reshape(-1, 2, 2))
+            ls.append(torch.tensor([[2, 3]], dtype=torch.long).expand(boxes.shape[1], 2))
+        if points is not None:
+            cs.append(points[b].float())
+            ls.append(labels[b].long())
+        sparse = m.sam_prompt_encoder.embed_points(torch.cat(cs, 1), torch.cat(ls, 1), pad=True)
+        low, iou, _ = m.sam_mask_decoder(embed[b:b + 1], pe, sparse, dense, [h[b:b + 1] for h in high_res],
+                                         multimask_output=multimask_output, repeat_image=True)
+        his.append(F.interpolate(low, size=(m.image_size, m.image_size), mode="bilinear", align_corners=False)[:, 0])
+        lows.append(low[:, 0]); ious.append(iou[:, 0])
+    return torch.stack(his), torch.stack(lows), torch.stack(ious)
+
+
 def postprocess_masks(masks, orig_hw):
     """src/sam2_infer.py:88-128 with max_hole_area = max_sprinkle_area = 0 (circuit_analyzer.py:245-250)."""
     return F.interpolate(masks.float(), orig_hw, mode="bilinear", align_corners=False)

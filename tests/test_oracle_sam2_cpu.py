@@ -314,3 +314,15 @@ def test_predict_boxes_shapes_and_independence_tiny_trunk():
     assert hi.shape == (2, 3, 256, 256) and lo.shape == (2, 3, 64, 64) and iou.shape == (2, 3)
     torch.testing.assert_close(lo[1, 1], lo1[0, 0], rtol=1e-4, atol=1e-5)
     torch.testing.assert_close(iou[1, 1], iou1[0, 0], rtol=1e-4, atol=1e-5)
+    # predict_prompts: boxes alone == predict_boxes; clicks change the masks; a -1 slot is one more "not a point" TOKEN (upstream
+    # pads ragged click lists with it), so it is not a no-op either
+    pts = torch.tensor([[[[40., 50.]], [[120., 130.]], [[200., 30.]]], [[[45., 55.]], [[140., 25.]], [[100., 225.]]]])
+    lab = torch.ones(2, 3, 1, dtype=torch.long)
+    with torch.no_grad():
+        hi2, lo2, iou2 = osam.predict_prompts(w, x, boxes=boxes)
+        _, lo3, _ = osam.predict_prompts(w, x, boxes=boxes, points=pts, labels=lab)
+        _, lo4, _ = osam.predict_prompts(w, x, boxes=boxes, points=torch.cat((pts, pts * 0), 2), labels=torch.cat((lab, -lab), 2))
+        _, lo5, _ = osam.predict_prompts(w, x, points=pts, labels=lab)
+    assert torch.equal(lo2, lo) and torch.equal(iou2, iou) and torch.equal(hi2, hi)
+    assert float((lo3 - lo).abs().max()) > 1e-4 and lo5.shape == lo.shape
+    assert float((lo4 - lo3).abs().max()) > 1e-4 and torch.isfinite(lo4).all()

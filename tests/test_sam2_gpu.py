@@ -433,6 +433,41 @@ def test_sam2_box_prompts_mini_match_oracle(dtype):
     assert float((lo[:, 0] - lo[:, 1]).abs().max()) > 1e-3            # the prompts do change the masks
 
 
+def test_infer_masks_click_prompts_match_oracle():
+    """`infer_masks(images, points=..., point_labels=...)` and boxes + clicks through the model object vs the oracle's predictor
+    semantics (corners, clicks, padding point); a -1 slot is one more "not a point" token on both sides."""
+    from circuitvision_amd.sam2 import SamSyntheticParams
+    from circuitvision_amd.sam2_infer import SAM2Model
+    R, B, P = 256, 2, 3
+    model = SAM2Model(MINI, R, dtype="f32", use_refinement=True)
+    p = SamSyntheticParams(seed=9, lora_targets=mini_targets(), std=0.05)
+    model.load_params(p)
+    oracle = mini_oracle(p, R)
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(B, 3, R, R, generator=g)
+    pts = torch.rand(B, P, 2, 2, generator=g) * (R - 1)
+    lab = torch.tensor([1, 0]).expand(B, P, 2).clone()
+    boxes = _boxes(B, P, R, seed=4)
+    for bx in (None, boxes):
+        hi, lo, iou = model.infer_masks(x, boxes=bx, points=pts, point_labels=lab)
+        with torch.no_grad():
+            rhi, rlo, riou = osam.predict_prompts(oracle, x, boxes=bx, points=pts, labels=lab)
+        torch.testing.assert_close(lo.cpu(), rlo, rtol=1e-3, atol=1e-3)
+        torch.testing.assert_close(hi.cpu(), rhi, rtol=1e-3, atol=1e-3)
+        torch.testing.assert_close(iou.cpu(), riou, rtol=1e-3, atol=1e-3)
+    # a padded click list: the extra slot is labelled -1 ("not a point" token, like the closing padding point)
+    pts3 = torch.cat((pts, torch.zeros(B, P, 1, 2)), 2)
+    lab3 = torch.cat((lab, -torch.ones(B, P, 1, dtype=lab.dtype)), 2)
+    with torch.no_grad():
+        _, rlo3, _ = osam.predict_prompts(oracle, x, points=pts3, labels=lab3)
+    _, lo3, _ = model.infer_masks(x, points=pts3, point_labels=lab3, return_high_res=False)
+    torch.testing.assert_close(lo3.cpu(), rlo3, rtol=1e-3, atol=1e-3)
+    with pytest.raises(ValueError):
+        model.infer_masks(x, points=pts)
+    with pytest.raises(ValueError):
+        model.infer_masks(x, points=pts, point_labels=lab + 2)
+
+
 def test_sam2_box_decoder_layer0_sharing_equals_repeat_image(monkeypatch):
     """fp16 box path: layer 0 on the B shared image embeddings (attention batch divisors, broadcast residual) vs the literal
     repeat_image formulation (B * P copies) on the same weights: same masks up to the summation order of different GEMM tiles."""
