@@ -16,6 +16,7 @@ Prints ONE JSON line (rank 0).  Extra objects:
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -223,6 +224,18 @@ def main():
     stream.synchronize()
 
     plan = yp.plan
+    # Seeded random weights never clear conf = 0.25, which would leave NMS without work.  All class logits of an anchor shift
+    # together when the three class-conv biases do, so one shift (from one un-timed pass) puts the ~CAND highest-scoring anchors per
+    # image above the threshold: the candidate volume of a busy schematic, sorted and suppressed inside the timed region.
+    # (The synthetic head's logits are nearly constant -- 18 distinct fp16 values -- so ties make it 325 candidates and 54 kept
+    # detections per image at CAND = 256.)
+    CAND = int(os.environ.get("CVMI_BENCH_CAND", "256"))          # (the environment knob is for NMS scaling experiments only)
+    plan.run_eager()
+    stream.synchronize()
+    lg = torch.cat([c.t[..., :nc].float().amax(-1).reshape(a.batch, -1) for c in yp.cls_bufs], 1).flatten()   # best class logit per anchor
+    kth = float(lg.kthvalue(lg.numel() - CAND * a.batch + 1).values)
+    for i in range(3):
+        wt.packed[f"model.23.cv3.{i}.2"].bias[:nc] += (math.log(0.25 / 0.75) - kth + 1e-3)
     plan.capture()
     for _ in range(a.warmup):
         plan.run()

@@ -4,15 +4,19 @@
 //   1. per anchor: best class score (first maximum), candidate iff score > conf_thres;
 //      key = (score bits << 32) | ~anchor  -> unique, so the order is deterministic
 //   2. bitonic sort of the keys in LDS, descending  (= score desc, anchor index asc on ties)
-//   3. boxes -> xyxy (xy -/+ wh/2), offset by cls * max_wh, area; staged in the workspace
+//   3. boxes -> xyxy (xy -/+ wh/2), offset by cls * max_wh, area; staged in LDS behind the sorted keys when they fit
+//      (up to ~4 k candidates; the workspace otherwise) -- the greedy pass re-reads them once per kept box
 //   4. greedy pass: next unsuppressed candidate is kept, every later candidate with
 //      inter / (area_i + area_j - inter) > iou_thres is marked in an LDS bitmask; stops at max_det.
+//      The pass only records the kept sorted positions; the detections are written afterwards, one thread each
+//      (a kept box costs one LDS round + one barrier, not a chain of dependent global loads).
 #include "common.hpp"
 
 namespace {
 
 constexpr int NMS_THREADS = 1024;
 constexpr int NMS_MAX_A = 16384;
+constexpr int NMS_MAX_DET = 4096;                  // LDS list of kept positions
 
 struct Cand { float x1, y1, x2, y2, area; };   // offset boxes (class * max_wh added)
 
@@ -63,13 +67,18 @@ __global__ __launch_bounds__(NMS_THREADS) void yolo_nms_kernel(const float* __re
   }
   __syncthreads();
   const int n = s_count;
+  // From here on every step is a short data-parallel pass followed by a barrier.  With up to 2048 candidates the passes fit four
+  // waves (one per SIMD): the other twelve retire now, and a barrier among four waves is several times cheaper than among sixteen
+  // (36 sort passes + one barrier per kept box at 256 candidates: 52 -> 20 us per image).
+  const int nthr = n <= 2048 ? 256 : NMS_THREADS;
+  if (tid >= nthr) return;
 
   // 2. bitonic sort, descending, over the smallest power of two >= n
   int Ps = 1;
   while (Ps < n) Ps <<= 1;
   for (int k = 2; k <= Ps; k <<= 1) {
     for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int t = tid; t < Ps / 2; t += NMS_THREADS) {
+      for (int t = tid; t < Ps / 2; t += nthr) {
         const int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1));
         const int hi = lo | j;
         const bool desc = (lo & k) == 0;
@@ -80,22 +89,29 @@ __global__ __launch_bounds__(NMS_THREADS) void yolo_nms_kernel(const float* __re
     }
   }
 
-  // 3. candidate geometry in sorted order
-  for (int i = tid; i < n; i += NMS_THREADS) {
+  // 3. candidate geometry in sorted order: in LDS behind the Ps sorted keys when it fits, in the workspace otherwise
+  const bool geo_lds = (size_t)Ps * 8 + (size_t)n * sizeof(Cand) <= (size_t)P * 8;
+  // boxes as 16-byte vectors + a separate area array (one ds_read_b128 + one ds_read_b32 per candidate instead of five scalar reads)
+  f32x4* const box_l = reinterpret_cast<f32x4*>(keys + (Ps > 2 ? Ps : 2));
+  float* const area_l = reinterpret_cast<float*>(box_l + n);
+  f32x4* const box_g = reinterpret_cast<f32x4*>(cand);
+  float* const area_g = reinterpret_cast<float*>(box_g + A);
+  for (int i = tid; i < n; i += nthr) {
     const int a = (int)(0xFFFFFFFFu - (unsigned)(keys[i] & 0xFFFFFFFFull));
     const float cx = pb[a], cy = pb[(size_t)A + a], w = pb[(size_t)2 * A + a], h = pb[(size_t)3 * A + a];
     const float hw = w / 2.f, hh = h / 2.f;
     const float off = (float)cls_ws[a] * max_wh;
-    Cand c;
-    c.x1 = (cx - hw) + off; c.y1 = (cy - hh) + off; c.x2 = (cx + hw) + off; c.y2 = (cy + hh) + off;
-    c.area = (c.x2 - c.x1) * (c.y2 - c.y1);
-    cand[i] = c;
+    f32x4 c;
+    c[0] = (cx - hw) + off; c[1] = (cy - hh) + off; c[2] = (cx + hw) + off; c[3] = (cy + hh) + off;
+    const float area = (c[2] - c[0]) * (c[3] - c[1]);
+    if (geo_lds) { box_l[i] = c; area_l[i] = area; } else { box_g[i] = c; area_g[i] = area; }
   }
-  for (int i = tid; i < (P >> 6); i += NMS_THREADS) supp[i] = 0ull;
+  for (int i = tid; i < (P >> 6); i += nthr) supp[i] = 0ull;
   __threadfence_block();
   __syncthreads();
 
-  // 4. greedy suppression
+  // 4. greedy suppression (kept sorted positions -> LDS list); a kept box costs one LDS round and one barrier
+  int* const kept_pos = reinterpret_cast<int*>(&s_count + 4);                        // [max_det], behind the counter
   int kept = 0;
   int i = 0;
   while (kept < max_det) {
@@ -111,30 +127,37 @@ __global__ __launch_bounds__(NMS_THREADS) void yolo_nms_kernel(const float* __re
     }
     if (found < 0 || found >= n) break;
     i = found;
-    const Cand ci = cand[i];
-    if (tid == 0) {
-      const int a = (int)(0xFFFFFFFFu - (unsigned)(keys[i] & 0xFFFFFFFFull));
-      const float cx = pb[a], cy = pb[(size_t)A + a], w = pb[(size_t)2 * A + a], h = pb[(size_t)3 * A + a];
-      const float hw = w / 2.f, hh = h / 2.f;
-      float* o = out_det + ((size_t)b * max_det + kept) * 6;
-      o[0] = cx - hw; o[1] = cy - hh; o[2] = cx + hw; o[3] = cy + hh;
-      o[4] = __uint_as_float((unsigned)(keys[i] >> 32));
-      o[5] = (float)cls_ws[a];
-      out_idx[(size_t)b * max_det + kept] = a;
-    }
+    const f32x4 ci = geo_lds ? box_l[i] : box_g[i];
+    const float ai = geo_lds ? area_l[i] : area_g[i];
+    if (tid == 0) kept_pos[kept] = i;
     ++kept;
-    for (int j = i + 1 + tid; j < n; j += NMS_THREADS) {
+    for (int j = i + 1 + tid; j < n; j += nthr) {
       if ((supp[j >> 6] >> (j & 63)) & 1ull) continue;
-      const Cand cj = cand[j];
-      const float xx1 = fmaxf(ci.x1, cj.x1), yy1 = fmaxf(ci.y1, cj.y1);
-      const float xx2 = fminf(ci.x2, cj.x2), yy2 = fminf(ci.y2, cj.y2);
+      const f32x4 cj = geo_lds ? box_l[j] : box_g[j];
+      const float xx1 = fmaxf(ci[0], cj[0]), yy1 = fmaxf(ci[1], cj[1]);
+      const float xx2 = fminf(ci[2], cj[2]), yy2 = fminf(ci[3], cj[3]);
       const float w = fmaxf(0.f, xx2 - xx1), h = fmaxf(0.f, yy2 - yy1);
       const float inter = w * h;
-      const float ovr = inter / (ci.area + cj.area - inter);
-      if (ovr > iou_thres) atomicOr(&supp[j >> 6], 1ull << (j & 63));
+      if (inter > 0.f || iou_thres < 0.f) {            // (disjoint boxes -- other classes, mostly -- have ovr = 0: never above a threshold >= 0)
+        const float aj = geo_lds ? area_l[j] : area_g[j];
+        const float ovr = inter / (ai + aj - inter);
+        if (ovr > iou_thres) atomicOr(&supp[j >> 6], 1ull << (j & 63));
+      }
     }
     ++i;
     __syncthreads();
+  }
+  // 5. detections of the kept candidates, one thread each
+  for (int k = tid; k < kept; k += nthr) {
+    const unsigned long long key = keys[kept_pos[k]];
+    const int a = (int)(0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull));
+    const float cx = pb[a], cy = pb[(size_t)A + a], w = pb[(size_t)2 * A + a], h = pb[(size_t)3 * A + a];
+    const float hw = w / 2.f, hh = h / 2.f;
+    float* o = out_det + ((size_t)b * max_det + k) * 6;
+    o[0] = cx - hw; o[1] = cy - hh; o[2] = cx + hw; o[3] = cy + hh;
+    o[4] = __uint_as_float((unsigned)(key >> 32));
+    o[5] = (float)cls_ws[a];
+    out_idx[(size_t)b * max_det + k] = a;
   }
   if (tid == 0) out_count[b] = kept;
 }
@@ -150,11 +173,11 @@ static int nms_launch(const float* pred, const float* best_score, const int* bes
                       int max_det, float max_wh, float* out_det, int* out_idx, int* out_count, void* workspace, hipStream_t stream) {
   int P = 1024;
   while (P < A) P <<= 1;
-  const size_t lds = (size_t)P * 8 + (size_t)(P / 64) * 8 + 16;
+  const size_t lds = (size_t)P * 8 + (size_t)(P / 64) * 8 + 16 + (size_t)max_det * sizeof(int);
   static bool attr_done = false;
   if (!attr_done) {
     CVMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&yolo_nms_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 NMS_MAX_A * 8 + (NMS_MAX_A / 64) * 8 + 16));
+                                 NMS_MAX_A * 8 + (NMS_MAX_A / 64) * 8 + 16 + NMS_MAX_DET * (int)sizeof(int)));
     attr_done = true;
   }
   hipLaunchKernelGGL(yolo_nms_kernel, dim3(B), dim3(NMS_THREADS), lds, stream, pred, best_score, best_cls, nc, A, conf_thres, iou_thres, max_det,
@@ -166,7 +189,7 @@ static int nms_launch(const float* pred, const float* best_score, const int* bes
 extern "C" int cvmi_yolo_nms(const float* pred, int B, int nc, int A, float conf_thres, float iou_thres, int max_det, float max_wh,
                              float* out_det, int* out_idx, int* out_count, void* workspace, cvmi_stream_t stream_) {
   CVMI_CHECK(pred && out_det && out_idx && out_count && workspace, "yolo_nms: null pointer");
-  CVMI_CHECK(B > 0 && nc > 0 && A > 0 && max_det > 0, "yolo_nms: bad shape");
+  CVMI_CHECK(B > 0 && nc > 0 && A > 0 && max_det > 0 && max_det <= NMS_MAX_DET, "yolo_nms: bad shape");
   CVMI_CHECK(A <= NMS_MAX_A, "yolo_nms: A=%d exceeds %d anchors", A, NMS_MAX_A);
   CVMI_CHECK(conf_thres >= 0.f, "yolo_nms: conf_thres must be >= 0 (keys rely on non-negative scores)");
   hipStream_t stream = (hipStream_t)stream_;
@@ -185,7 +208,7 @@ extern "C" int cvmi_yolo_nms_best(const float* pred, const float* best_score, co
                                   float iou_thres, int max_det, float max_wh, float* out_det, int* out_idx, int* out_count, void* workspace,
                                   cvmi_stream_t stream_) {
   CVMI_CHECK(pred && best_score && best_cls && out_det && out_idx && out_count && workspace, "yolo_nms_best: null pointer");
-  CVMI_CHECK(B > 0 && nc > 0 && A > 0 && max_det > 0, "yolo_nms_best: bad shape");
+  CVMI_CHECK(B > 0 && nc > 0 && A > 0 && max_det > 0 && max_det <= NMS_MAX_DET, "yolo_nms_best: bad shape");
   CVMI_CHECK(A <= NMS_MAX_A, "yolo_nms_best: A=%d exceeds %d anchors", A, NMS_MAX_A);
   CVMI_CHECK(conf_thres >= 0.f, "yolo_nms_best: conf_thres must be >= 0");
   return nms_launch(pred, best_score, best_cls, B, nc, A, conf_thres, iou_thres, max_det, max_wh, out_det, out_idx, out_count, workspace,
