@@ -277,7 +277,13 @@ template <typename T, int KS, int S, int CC>
 int launch_tile_n(TileArgs& a, int B, hipStream_t stream) {
   // (16 x 16 tiles were measured: no gain over 8 x 16 on any YOLO11-n layer, so only the smaller tile is built)
   if (a.N <= 32) return launch_tile<T, KS, S, CC, 32, 4, 1, 8>(a, B, stream);
-  if (a.N <= 64) return launch_tile<T, KS, S, CC, 64, 2, 2, 8>(a, B, stream);
+  if (a.N <= 64) {
+    // small maps (the 20 x 20 level at batch 32: 192 tiles of 8 x 16 for 256 CUs): 4 x 16 tiles double the workgroups and
+    // halve each one's dependent chain (stage, barrier, 9 taps of MFMAs, store)
+    static const int th4 = getenv("CVMI_TILE_TH4") ? atoi(getenv("CVMI_TILE_TH4")) : 1;       // tuning experiments only
+    if (th4 && sizeof(T) == 2 && (long long)B * cdiv(a.OH, 8) * a.tiles_x <= 256) return launch_tile<T, KS, S, CC, 64, 2, 2, 4>(a, B, stream);
+    return launch_tile<T, KS, S, CC, 64, 2, 2, 8>(a, B, stream);
+  }
   return launch_tile<T, KS, S, CC, 128, 2, 2, 8>(a, B, stream);
 }
 
