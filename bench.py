@@ -1,23 +1,37 @@
 #!/usr/bin/env python3
-"""bench.py -- throughput of the detector hot path on N MI355X (one process per GPU).
+"""bench.py -- throughput of CircuitVision's dense-vision hot path on N MI355X (one process per GPU).
 
-Workload (BASELINE.json configs[1]): YOLO11-n, 640x640, batch 32 per GPU, fp16 storage / fp32
-accumulate, synthetic letterboxed circuit images already resident in HBM (NHWC fp16), seeded random
-weights (nc = 62).  A "step" = network forward + Detect decode + NMS for one batch, replayed as one
-captured HIP graph.  N > 1: every rank runs its own batch shard (weak scaling), weights are
-broadcast once from rank 0 over RCCL; there is no per-step collective.
+Default workload `circuit` = the metric BASELINE.json names, "circuit images/sec (YOLOv11 640^2 + SAM2.1-L 1024^2)":
+a STEP pushes one batch of 32 circuit images per GPU through BOTH stages --
+    YOLO11-n, 640x640, batch 32, fp16: forward + Detect decode + NMS           (BASELINE configs[1])
+    SAM 2.1 Hiera-L, 1024x1024, 2 x batch 16, fp16 operands / f32 streams:
+        image encoder + learned-prompt mask decoder + upsample / refinement     (BASELINE configs[2])
+-- as three captured HIP graphs replayed back to back on one stream; inputs (letterboxed / normalised synthetic circuit
+drawings) are resident in HBM before the timed region, weights are seeded random (nc = 62, LoRA merged).
+`value` = images through both stages per second, whole job.  N > 1: every rank runs its own 32 images (weak scaling), the
+weights are broadcast once from rank 0 over RCCL, there is no per-step collective.
+
+Other workloads: yolo11n / yolo11l / sam2l / sam2l_box (one stage alone), pipeline (BASELINE configs[3]: YOLO11-l + SAM 2.1-L
+over 64 images TOTAL, sharded over the ranks -- strong scaling).
+
+`--gpus N` without a torchrun environment launches the N ranks itself (fresh child processes, before anything touches the
+GPU); under torchrun WORLD_SIZE must equal --gpus.
 
 Prints ONE JSON line (rank 0).  Extra objects:
-  roofline     conv stack (all network launches of one step) against the HBM roof; `achieved` =
-               SURVEY.md 8(d) algorithmic bytes (81.8 MB fp16 activations / image + 5.2 MB weights
-               per batch) / the summed duration of those launches, measured with event pairs on the
-               engine's stream in un-captured passes.
-  cpu_baseline the CPU fp32 oracle (oracle/yolo11.py + oracle/nms.py) on a bounded sample.
+  roofline      the dominant kernel family of the workload (default: the Hiera linear-layer GEMMs, MFMA-bound);
+  rooflines     every family the north_star sets a target on: YOLO11-n conv stack vs the HBM roof (SURVEY.md 8(d) algorithmic
+                bytes: 81.8 MB fp16 activations / image + 5.2 MB weights / batch), Hiera GEMMs, global and windowed attention vs
+                the dense fp16 MFMA peak.  `achieved` = algorithmic bytes (flops) / the summed duration of those launches,
+                measured here with HIP event pairs on the engine's stream in un-captured passes.
+  cpu_baseline  the CPU fp32 oracle (oracle/) timed on this host: physical cores, CPU model and the sample are stated.
+  stages        per-stage ms / images/s / launch breakdown.
 """
 import argparse
 import json
 import math
 import os
+import statistics
+import subprocess
 import sys
 import time
 
@@ -25,71 +39,137 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
+METRIC = "circuit images/sec (YOLOv11 640² + SAM2.1-L 1024²) at 1/2/4/8 MI355X"
 ALGO_ACT_MB_PER_IMAGE = 81.8     # 40.9 M fp16 activation elements moved / image
 ALGO_WEIGHT_MB = 5.2             # 2.59 M params fp16, once per batch
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
+SAM_FLOP_PER_IMAGE = 1.83e12     # trunk linear 1606 G + attention 203 G + conv/neck/decoder/refine
+MFMA_PEAK_TFLOPS = 2500.0        # dense fp16/bf16 (MI355X_MICROARCH.md)
+YOLO_STACK_KINDS = ("stem", "conv", "head", "dwconv", "pool", "attention")
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--workload", default="yolo11n", choices=["yolo11n", "yolo11l", "sam2l", "sam2l_box"],
-                    help="yolo11n = BASELINE configs[1] (default, the bench line); sam2l = configs[2]; "
-                         "sam2l_box = one GPU's share of configs[4] (16 images x 32 box prompts)")
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--workload", default="circuit", choices=["circuit", "yolo11n", "yolo11l", "sam2l", "sam2l_box", "pipeline"],
+                    help="circuit = YOLO11-n B=32 + SAM2.1-L 2 x B=16 per step (default: the BASELINE metric); yolo11n = configs[1]; "
+                         "sam2l = configs[2]; sam2l_box = one GPU's share of configs[4]; pipeline = configs[3] (64 images total, strong scaling)")
     ap.add_argument("--prompts", type=int, default=32, help="box prompts per image (sam2l_box)")
-    ap.add_argument("--batch", type=int, default=None, help="images per GPU per step (default 32 YOLO / 16 SAM)")
-    ap.add_argument("--scale", default=None)
+    ap.add_argument("--batch", type=int, default=None, help="images per GPU per stage launch (default 32 YOLO / 16 SAM)")
+    ap.add_argument("--total-images", type=int, default=64, help="pipeline workload: images in the whole job")
     ap.add_argument("--dtype", default="f16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile-pass", action="store_true")
-    return ap.parse_args()
+    a = ap.parse_args()
+    sam_heavy = a.workload in ("circuit", "sam2l", "sam2l_box", "pipeline")
+    if a.steps is None:
+        a.steps = 5 if sam_heavy else 50
+    if a.warmup is None:
+        a.warmup = 2 if sam_heavy else 10
+    return a
 
 
-def cpu_baseline(scale, nc, state_dict, seconds=12.0):
-    """Oracle timed on the host cores on a bounded sample: batches of 4 synthetic 640x640 images,
-    forward + NMS, until ~`seconds` of CPU work."""
+def self_launch(a):
+    """`python bench.py --gpus N` outside torchrun: start the N ranks as a child torchrun (nothing in THIS process has touched the
+    GPU yet, and it never will) and exit with the child's code."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+# ---- host description / CPU legs ---------------------------------------------------------------------------------------
+def host_cpu():
+    """(physical cores, model name) from /proc/cpuinfo."""
+    cores, model, phys, core = set(), "unknown", None, None
+    try:
+        for line in open("/proc/cpuinfo"):
+            k, _, v = line.partition(":")
+            k, v = k.strip(), v.strip()
+            if k == "model name":
+                model = v
+            elif k == "physical id":
+                phys = v
+            elif k == "core id":
+                core = v
+            elif not k and phys is not None:
+                cores.add((phys, core)); phys = core = None
+        if phys is not None:
+            cores.add((phys, core))
+    except OSError:
+        pass
+    n = len(cores) or (os.cpu_count() or 1)
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))          # an affinity mask may expose fewer than the package has
+    except AttributeError:
+        pass
+    try:                                                  # ... and so may a cgroup CPU quota ("<quota> <period>" or "max <period>")
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(float(q) / float(p) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return max(1, n), model
+
+
+def yolo_cpu_baseline(scale, nc, state_dict, x, budget_s=40.0):
+    """the CPU fp32 restatement on B = 32 synthetic 640x640 images, forward + NMS, 2 warm-up iterations,
+    median of up to 20 timed iterations (bounded by `budget_s` of CPU time so that the default run stays within minutes)."""
     import torch
     from oracle import nms as onms
     from oracle.yolo11 import YOLO11
+    cores, model = host_cpu()
+    torch.set_num_threads(cores)
     m = YOLO11(scale, nc).eval()
     m.load_state_dict(state_dict, strict=True)
-    x = torch.rand(4, 3, 640, 640, generator=torch.Generator().manual_seed(0))
+    ts = []
     with torch.no_grad():
-        onms.yolo_nms(m(x[:1]))                       # warm-up
-        n, t0 = 0, time.perf_counter()
-        while time.perf_counter() - t0 < seconds:
+        t_all = time.perf_counter()
+        for i in range(22):
+            t0 = time.perf_counter()
             onms.yolo_nms(m(x))
-            n += x.shape[0]
-        dt = time.perf_counter() - t0
-    return {"value": round(n / dt, 3), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{n} synthetic 640x640 images (batches of 4), YOLO11-{scale} fp32 oracle forward + NMS, {dt:.1f} s"}
+            dt = time.perf_counter() - t0
+            if i >= 2:
+                ts.append(dt)
+            if time.perf_counter() - t_all > budget_s and len(ts) >= 3:
+                break
+    med = statistics.median(ts)
+    return {"value": round(x.shape[0] / med, 3), "unit": "images/s", "cores": cores, "cpu_model": model, "kind": "port",
+            "sample": f"YOLO11-{scale} fp32 oracle forward + NMS on the batch of {x.shape[0]} synthetic 640x640 images the GPU ran: 2 warm-up + "
+                      f"{len(ts)} timed iterations (median {med:.3f} s, min {min(ts):.3f}, max {max(ts):.3f})"}
 
 
-SAM_FLOP_PER_IMAGE = 1.83e12     # SURVEY.md 8(d) config 3: trunk linear 1606 G + attention 203 G + conv/neck/decoder/refine
-MFMA_PEAK_TFLOPS = 2500.0        # dense fp16/bf16 (MI355X_MICROARCH.md)
-
-
-def sam_cpu_baseline(state_dict, seconds=20.0, boxes=None):
+def sam_cpu_baseline(state_dict, x, boxes=None, timed=3):
+    """BASELINE.md section 3 asks for B = 16 x >= 5 iterations; at ~10-20 s per image on the host that is > 20 minutes, so the sample is
+    bounded: batch 1, 1 warm-up + `timed` iterations, median."""
     import torch
     from oracle import sam2_model as osam
+    cores, model = host_cpu()
+    torch.set_num_threads(cores)
     w = osam.SAM2ImageWrapper(osam.SAM2Core(osam.HIERA_L, lora=True)).eval()
     w.load_state_dict({("sam2_model." + k if not (k.startswith("dense_") or k.startswith("sparse_") or k.startswith("refinement_")) else k): v
                        for k, v in state_dict.items()}, strict=True)
-    x = torch.randn(1, 3, 1024, 1024, generator=torch.Generator().manual_seed(0))
+    ts = []
     with torch.no_grad():
-        n, t0 = 0, time.perf_counter()
-        while n < 1 or time.perf_counter() - t0 < seconds:
+        for i in range(1 + timed):
+            t0 = time.perf_counter()
             if boxes is None:
-                w(x)
+                w(x[:1])
             else:
-                osam.predict_boxes(w, x, boxes[:1])
-            n += 1
-        dt = time.perf_counter() - t0
-    what = "wrapper forward" if boxes is None else f"encoder + {boxes.shape[1]} box prompts"
-    return {"value": round(n / dt, 4), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{n} synthetic 1024x1024 images (batch 1), SAM2.1 Hiera-L fp32 oracle {what}, {dt:.1f} s"}
+                osam.predict_boxes(w, x[:1], boxes[:1])
+            if i >= 1:
+                ts.append(time.perf_counter() - t0)
+    med = statistics.median(ts)
+    what = "wrapper forward (encoder + learned-prompt decoder + refinement)" if boxes is None else f"encoder + {boxes.shape[1]} box prompts"
+    return {"value": round(1.0 / med, 4), "unit": "images/s", "cores": cores, "cpu_model": model, "kind": "port",
+            "sample": f"SAM2.1 Hiera-L fp32 oracle {what}, batch 1 of the synthetic 1024x1024 images the GPU ran: 1 warm-up + {len(ts)} timed "
+                      f"iterations (median {med:.2f} s); bounded sample -- BASELINE.md's B=16 x 5 would take > 20 min on this host"}
 
 
 def synthetic_boxes(B, P, R=1024, seed=0):
@@ -101,151 +181,234 @@ def synthetic_boxes(B, P, R=1024, seed=0):
     return torch.cat((xy, xy + side), -1)
 
 
-def run_sam(a):
-    """BASELINE configs[2]: SAM 2.1 Hiera-L, 1024x1024, batch 16 per GPU, learned-prompt wrapper forward."""
-    import torch
-    import torch.distributed as dist
-    rank = int(os.environ.get("RANK", "0")); local_rank = int(os.environ.get("LOCAL_RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
-    torch.cuda.set_device(local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    from circuitvision_amd import _lib
-    from circuitvision_amd.distributed import broadcast_packed
-    from circuitvision_amd.sam2 import HIERA_L, LORA_TARGETS_REFERENCE, Sam2Plan, Sam2Weights, SamSyntheticParams
-    from synth import circuit_image
-    B = a.batch or 16
-    dtype = {"f16": _lib.F16, "f32": _lib.F32}[a.dtype]
-    params = SamSyntheticParams(seed=0, lora_targets=LORA_TARGETS_REFERENCE)
-    wt = Sam2Weights(params, HIERA_L, 1024, dtype, device=f"cuda:{local_rank}")
-    if world > 1:
-        broadcast_packed(wt.pc, src=0)
-    stream = torch.cuda.Stream()
-    NPR = a.prompts if a.workload == "sam2l_box" else 0
-    sp = Sam2Plan(wt, B, stream, prompts=NPR)
-    boxes = None
-    if NPR:
-        boxes = synthetic_boxes(B, NPR, seed=rank)
-        sp.coords[:, :2].copy_(boxes.reshape(B * NPR, 2, 2))
-        sp.labels.copy_(torch.tensor([2, 3, -1], dtype=torch.int32).expand(B * NPR, 3))
-    lib = _lib.load()
-    for b in range(B):
-        img = torch.from_numpy(circuit_image(768, 1024, seed=20250704 + rank * B + b)).cuda()
-        _lib.check(lib.cvmi_sam2_transform(img.data_ptr(), 768, 1024, sp.x_in.t[b].data_ptr(), 1024, dtype, stream.cuda_stream), "transform")
-    stream.synchronize()
-    plan = sp.plan
-    plan.capture()
-    for _ in range(a.warmup):
-        plan.run()
-    stream.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        plan.run()
-    stream.synchronize(); torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX); dt = float(t.item()); dist.barrier()
-    roofline = breakdown = cpu = None
-    if rank == 0 and not a.no_profile_pass:
+# ---- stages ------------------------------------------------------------------------------------------------------------------
+class YoloStage:
+    """YOLO11 forward + decode + NMS on B resident images (one captured graph)."""
+
+    def __init__(self, a, scale, B, rank, local_rank, world, stream, seed0):
+        import torch
+        from circuitvision_amd import _lib
+        from circuitvision_amd.distributed import broadcast_packed
+        from circuitvision_amd.yolo11 import SyntheticParams, Yolo11Plan, Yolo11Weights
+        from synth import circuit_image
+        self.scale, self.B, self.nc = scale, B, 62
+        self.dtype = {"f16": _lib.F16, "f32": _lib.F32}[a.dtype]
+        self.params = SyntheticParams(seed=0, nc=self.nc)
+        self.wt = Yolo11Weights(scale, self.nc, self.params, self.dtype, device=f"cuda:{local_rank}")
+        if world > 1:
+            broadcast_packed(self.wt.packed, src=0)            # one-time RCCL broadcast of the packed weights
+        self.yp = Yolo11Plan(self.wt, B, 640, 640, stream, keep_scores=False)
+        lib = _lib.load()
+        self.seeds = [seed0 + b for b in range(B)]
+        for b, s in enumerate(self.seeds):                      # synthetic circuit images of this rank's shard, letterboxed on the GPU
+            img = torch.from_numpy(circuit_image(640, 640, seed=s)).cuda()
+            _lib.check(lib.cvmi_letterbox(img.data_ptr(), 640, 640, self.yp.x_in.t[b].data_ptr(), 640, 640, 640, 640, 0, 0, self.dtype, 1,
+                                          stream.cuda_stream), "letterbox")
+        stream.synchronize()
+        self.plan = self.yp.plan
+        # Seeded random weights never clear conf = 0.25, which would leave NMS without work.  All class logits of an anchor shift
+        # together when the three class-conv biases do, so one shift (from one un-timed pass) puts the ~CAND highest-scoring anchors
+        # per image above the threshold: the candidate volume of a busy schematic, sorted and suppressed inside the timed region.
+        CAND = int(os.environ.get("CVMI_BENCH_CAND", "256"))      # (the environment knob is for NMS scaling experiments only)
+        self.plan.run_eager()
+        stream.synchronize()
+        nc = self.nc
+        lg = torch.cat([c.t[..., :nc].float().amax(-1).reshape(B, -1) for c in self.yp.cls_bufs], 1).flatten()
+        kth = float(lg.kthvalue(lg.numel() - CAND * B + 1).values)
+        for i in range(3):
+            self.wt.packed[f"model.23.cv3.{i}.2"].bias[:nc] += (math.log(0.25 / 0.75) - kth + 1e-3)
+            self.params.sd[f"model.23.cv3.{i}.2.bias"] += (math.log(0.25 / 0.75) - kth + 1e-3)       # the CPU leg runs the same head
+        self.plan.capture()
+
+    def run(self):
+        self.plan.run()
+
+    def profile(self, reps=5):
         acc = {}
-        plan.timed_eager()
-        reps = 2
+        self.plan.timed_eager()
         for _ in range(reps):
-            for label, kind, ms, b, f in plan.timed_eager():
-                k = acc.setdefault(kind, [0.0, 0, 0, 0]); k[0] += ms / reps; k[1] += 1; k[2] += b / reps; k[3] += f / reps
-        gemm_ms = acc["gemm"][0]; gemm_fl = acc["gemm"][3]
+            for label, kind, ms, b, f in self.plan.timed_eager():
+                k = acc.setdefault(kind, [0.0, 0, 0, 0])
+                k[0] += ms / reps; k[1] += 1; k[2] += b / reps; k[3] += f / reps
+        stack_ms = sum(acc[k][0] for k in YOLO_STACK_KINDS if k in acc)
+        n_launch = sum(acc[k][1] for k in YOLO_STACK_KINDS if k in acc) // reps
+        breakdown = {k: {"ms": round(v[0], 4), "launches": v[1] // reps, "plan_bytes": int(v[2]), "gflop": round(v[3] / 1e9, 3)} for k, v in acc.items()}
+        if self.scale in ("n", "s"):
+            is_cfg1 = self.scale == "n" and self.B == 32
+            algo = (self.B * ALGO_ACT_MB_PER_IMAGE + ALGO_WEIGHT_MB) * 1e6 if is_cfg1 else \
+                float(sum(acc[k][2] for k in YOLO_STACK_KINDS if k in acc)) + self.wt.param_bytes
+            ach = algo / (stack_ms * 1e-3) / 1e9
+            traffic, src = None, None
+            tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
+            if is_cfg1 and os.path.exists(tpath):                 # PMC pass of this exact workload (tools/traffic.py), not read in this run
+                try:
+                    t = json.load(open(tpath))
+                    traffic, src = t.get("hbm_bytes_per_step"), f"profiles/traffic_latest.json ({t.get('collected', 'round 1, before the r02 kernels')}; " \
+                        "rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes; a committed measurement, NOT read in this run)"
+                except Exception:
+                    pass
+            roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+                    "traffic": traffic, "traffic_source": src,
+                    "kernel": f"YOLO11-{self.scale} conv stack: AGGREGATE of its {n_launch} network launches per step (stem2 / c3k2 / conv_tile / igemm / dwpw / "
+                              "dwconv / pool / attention), durations summed from per-launch event pairs; in the captured graph the Detect "
+                              "lane overlaps the neck, so the step is shorter than this sum",
+                    "kernel_ms_per_step": round(stack_ms, 4), "algorithmic_bytes_per_step": int(algo)}
+        else:
+            fl = float(sum(acc[k][3] for k in YOLO_STACK_KINDS if k in acc))
+            ach = fl / (stack_ms * 1e-3) / 1e12
+            roof = {"bound": "mfma", "achieved": round(ach, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4),
+                    "traffic": None, "kernel": f"YOLO11-{self.scale} conv stack: aggregate of {n_launch} launches per step", "kernel_ms_per_step": round(stack_ms, 4),
+                    "algorithmic_flops_per_step": int(fl)}
+        return roof, breakdown
+
+    def cpu_input(self):
+        import numpy as np
+        import torch
+        from synth import circuit_image
+        imgs = np.stack([circuit_image(640, 640, seed=s) for s in self.seeds])
+        return torch.from_numpy(imgs[..., ::-1].copy()).permute(0, 3, 1, 2).float().div(255)
+
+
+class SamStage:
+    """SAM 2.1 Hiera-L on B resident images: learned-prompt wrapper forward (prompts = 0) or P box prompts per image."""
+
+    _weights = {}
+
+    def __init__(self, a, B, rank, local_rank, world, stream, seed0, prompts=0):
+        import torch
+        from circuitvision_amd import _lib
+        from circuitvision_amd.distributed import broadcast_weights
+        from circuitvision_amd.sam2 import HIERA_L, LORA_TARGETS_REFERENCE, Sam2Plan, Sam2Weights, SamSyntheticParams
+        from synth import circuit_image
+        self.B, self.P = B, prompts
+        self.dtype = {"f16": _lib.F16, "f32": _lib.F32}[a.dtype]
+        key = (a.dtype, local_rank)
+        if key not in SamStage._weights:                         # two SAM stages of one step share the weights
+            params = SamSyntheticParams(seed=0, lora_targets=LORA_TARGETS_REFERENCE)
+            wt = Sam2Weights(params, HIERA_L, 1024, self.dtype, device=f"cuda:{local_rank}")
+            if world > 1:
+                broadcast_weights(wt, src=0)
+            SamStage._weights[key] = (params, wt)
+        self.params, self.wt = SamStage._weights[key]
+        self.sp = Sam2Plan(self.wt, B, stream, prompts=prompts)
+        self.boxes = None
+        if prompts:
+            self.boxes = synthetic_boxes(B, prompts, seed=rank)
+            self.sp.coords[:, :2].copy_(self.boxes.reshape(B * prompts, 2, 2))
+            self.sp.labels.copy_(torch.tensor([2, 3, -1], dtype=torch.int32).expand(B * prompts, 3))
+        lib = _lib.load()
+        self.seeds = [seed0 + b for b in range(B)]
+        for b, s in enumerate(self.seeds):
+            img = torch.from_numpy(circuit_image(768, 1024, seed=s)).cuda()
+            _lib.check(lib.cvmi_sam2_transform(img.data_ptr(), 768, 1024, self.sp.x_in.t[b].data_ptr(), 1024, self.dtype, stream.cuda_stream), "transform")
+        stream.synchronize()
+        self.plan = self.sp.plan
+        self.plan.capture()
+
+    def run(self):
+        self.plan.run()
+
+    def profile(self, reps=2):
+        acc = {}
+        self.plan.timed_eager()
+        for _ in range(reps):
+            for label, kind, ms, b, f in self.plan.timed_eager():
+                k = acc.setdefault(kind, [0.0, 0, 0, 0])
+                k[0] += ms / reps; k[1] += 1; k[2] += b / reps; k[3] += f / reps
         total_ms = sum(v[0] for v in acc.values())
-        ach = gemm_fl / (gemm_ms * 1e-3) / 1e12
-        roofline = {"bound": "mfma", "achieved": round(ach, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4),
-                    "traffic": None, "kernel": "igemm_kernel (Hiera linear layers) per step", "kernel_ms_per_step": round(gemm_ms, 3),
-                    "algorithmic_flops_per_step": int(gemm_fl), "whole_step_tflops": round(B * SAM_FLOP_PER_IMAGE / (total_ms * 1e-3) / 1e12, 1)}
+        roofs = {}
+        for name, kind, what in (("sam2l_linear_gemm", "gemm", "Hiera linear layers (qkv / proj / fc1 / fc2 / dim-proj GEMMs: gemm256* / igemm / gemm_glds kernels)"),
+                                 ("sam2l_attention_global", "attn_global", "Hiera global attention, 3 blocks x 4096 x 4096 keys per head (attn_dma72_kernel)"),
+                                 ("sam2l_attention_window", "attn_window", "Hiera windowed attention (attn_res256 / attn_res64 / attn_win16 kernels)")):
+            if kind not in acc:
+                continue
+            ms, n, _, fl = acc[kind]
+            ach = fl / (ms * 1e-3) / 1e12
+            roofs[name] = {"bound": "mfma", "achieved": round(ach, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4),
+                           "traffic": None, "kernel": f"{what}: aggregate of {n // reps} launches per B={self.B} pass",
+                           "kernel_ms_per_step": round(ms, 3), "algorithmic_flops_per_step": int(fl)}
+        roofs["sam2l_linear_gemm"]["whole_pass_tflops"] = round(self.B * SAM_FLOP_PER_IMAGE / (total_ms * 1e-3) / 1e12, 1)
         breakdown = {k: {"ms": round(v[0], 3), "launches": v[1] // reps, "gflop": round(v[3] / 1e9, 1),
                          "tflops": round(v[3] / max(v[0], 1e-9) / 1e9, 1)} for k, v in acc.items()}
-    if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        cpu = sam_cpu_baseline(params.state_dict(), boxes=boxes)
-    if rank == 0:
-        print(json.dumps({
-            "metric": "circuit images/sec (YOLOv11 640² + SAM2.1-L 1024²) at 1/2/4/8 MI355X", "value": round(world * B * a.steps / dt, 3),
-            "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
-            "config": {"workload": (f"SAM2.1 Hiera-L 1024x1024 batch={B}/GPU learned-prompt wrapper forward (BASELINE configs[2])" if not NPR else
-                                    f"SAM2.1 Hiera-L 1024x1024 batch={B}/GPU, {NPR} box prompts per image, fp16 (one GPU's share of BASELINE configs[4])"),
-                       "images_per_step": world * B, "masks_per_step": world * B * max(NPR, 1), "weights": "seeded random, LoRA merged"},
-            "roofline": roofline, "cpu_baseline": cpu, "breakdown": breakdown}), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
+        return roofs, breakdown
+
+    def cpu_input(self):
+        import torch
+        from oracle import sam2_model as osam
+        from synth import circuit_image
+        return torch.stack([osam.sam2_transform(circuit_image(768, 1024, seed=s), 1024) for s in self.seeds[:1]])
 
 
+# ---- main ---------------------------------------------------------------------------------------------------------------------
 def main():
     a = parse()
-    if a.workload in ("sam2l", "sam2l_box"):
-        if a.steps == 50 and a.warmup == 10:
-            a.steps, a.warmup = 5, 2
-        return run_sam(a)
-    a.scale = a.scale or ("l" if a.workload == "yolo11l" else "n")
-    a.batch = a.batch or 32
-    import torch
-    import torch.distributed as dist
-
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and a.gpus > 1:
+        self_launch(a)
+    world = int(env_world or "1")
+    if world != a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}; launch with torchrun --nproc-per-node {a.gpus} or drop the torchrun environment")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != a.gpus and world > 1:
-        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+
+    import torch
+    import torch.distributed as dist
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-
-    from circuitvision_amd import _lib
-    from circuitvision_amd.distributed import broadcast_packed
-    from circuitvision_amd.yolo11 import SyntheticParams, Yolo11Plan, Yolo11Weights
-    from synth import circuit_image
-
-    nc = 62
-    dtype = {"f16": _lib.F16, "f32": _lib.F32}[a.dtype]
-    params = SyntheticParams(seed=0, nc=nc)
-    wt = Yolo11Weights(a.scale, nc, params, dtype, device=f"cuda:{local_rank}")
-    if world > 1:
-        broadcast_packed(wt.packed, src=0)            # one-time RCCL broadcast of the packed weights
     stream = torch.cuda.Stream()
-    yp = Yolo11Plan(wt, a.batch, 640, 640, stream, keep_scores=False)
+    w = a.workload
+    scaling = "weak"
+    if w == "circuit":
+        by, bs = a.batch or 32, 16
+        nsam = by // bs
+        if by % bs:
+            raise SystemExit("--batch must be a multiple of 16 for the circuit workload")
+        seed0 = 20250704 + rank * by
+        stages = [("yolo11n", YoloStage(a, "n", by, rank, local_rank, world, stream, seed0))]
+        stages += [(f"sam2l[{j}]", SamStage(a, bs, rank, local_rank, world, stream, seed0 + j * bs)) for j in range(nsam)]
+        images_per_step = by
+        name = (f"YOLO11-n 640x640 batch={by} fp16 forward+decode+NMS (BASELINE configs[1]) + SAM2.1 Hiera-L 1024x1024 {nsam} x batch={bs} fp16 "
+                "learned-prompt wrapper forward (configs[2]) on the same images, per GPU and step")
+    elif w in ("yolo11n", "yolo11l"):
+        B = a.batch or 32
+        stages = [(w, YoloStage(a, w[-1], B, rank, local_rank, world, stream, 20250704 + rank * B))]
+        images_per_step = B
+        name = f"YOLO11-{w[-1]} 640x640 batch={B}/GPU fp16 forward+decode+NMS" + (" (BASELINE configs[1])" if w == "yolo11n" else "")
+    elif w in ("sam2l", "sam2l_box"):
+        B = a.batch or 16
+        P = a.prompts if w == "sam2l_box" else 0
+        stages = [(w, SamStage(a, B, rank, local_rank, world, stream, 20250704 + rank * B, prompts=P))]
+        images_per_step = B
+        name = (f"SAM2.1 Hiera-L 1024x1024 batch={B}/GPU learned-prompt wrapper forward (BASELINE configs[2])" if not P else
+                f"SAM2.1 Hiera-L 1024x1024 batch={B}/GPU, {P} box prompts per image, fp16 (one GPU's share of BASELINE configs[4])")
+    else:                                                        # pipeline: configs[3], strong scaling over a fixed total
+        from circuitvision_amd.distributed import shard_range
+        lo, hi = shard_range(a.total_images, rank, world)
+        n = hi - lo
+        if a.total_images % world or n % 2:
+            raise SystemExit("--total-images must split evenly (and into an even share) over the ranks")
+        bs = min(16, n)
+        seed0 = 20250704 + lo
+        stages = [("yolo11l", YoloStage(a, "l", n, rank, local_rank, world, stream, seed0))]
+        stages += [(f"sam2l[{j}]", SamStage(a, bs, rank, local_rank, world, stream, seed0 + j * bs)) for j in range(n // bs)]
+        images_per_step = n
+        scaling = "strong"
+        name = (f"full pipeline YOLO11-l 640x640 + SAM2.1 Hiera-L 1024x1024, {a.total_images} circuit images per step sharded over {world} GPU(s) "
+                f"({n} per GPU: detector batch {n}, segmenter {n // bs} x batch {bs}), fp16 (BASELINE configs[3])")
 
-    # synthetic circuit images of this rank's shard, letterboxed on the GPU into the plan's input
-    lib = _lib.load()
-    for b in range(a.batch):
-        img = torch.from_numpy(circuit_image(640, 640, seed=20250704 + rank * a.batch + b)).cuda()
-        _lib.check(lib.cvmi_letterbox(img.data_ptr(), 640, 640, yp.x_in.t[b].data_ptr(), 640, 640, 640, 640, 0, 0, dtype, 1,
-                                      stream.cuda_stream), "letterbox")
-    stream.synchronize()
-
-    plan = yp.plan
-    # Seeded random weights never clear conf = 0.25, which would leave NMS without work.  All class logits of an anchor shift
-    # together when the three class-conv biases do, so one shift (from one un-timed pass) puts the ~CAND highest-scoring anchors per
-    # image above the threshold: the candidate volume of a busy schematic, sorted and suppressed inside the timed region.
-    # (The synthetic head's logits are nearly constant -- 18 distinct fp16 values -- so ties make it 325 candidates and 54 kept
-    # detections per image at CAND = 256.)
-    CAND = int(os.environ.get("CVMI_BENCH_CAND", "256"))          # (the environment knob is for NMS scaling experiments only)
-    plan.run_eager()
-    stream.synchronize()
-    lg = torch.cat([c.t[..., :nc].float().amax(-1).reshape(a.batch, -1) for c in yp.cls_bufs], 1).flatten()   # best class logit per anchor
-    kth = float(lg.kthvalue(lg.numel() - CAND * a.batch + 1).values)
-    for i in range(3):
-        wt.packed[f"model.23.cv3.{i}.2"].bias[:nc] += (math.log(0.25 / 0.75) - kth + 1e-3)
-    plan.capture()
     for _ in range(a.warmup):
-        plan.run()
+        for _, st in stages:
+            st.run()
     stream.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        plan.run()
+        for _, st in stages:
+            st.run()
     stream.synchronize()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
@@ -255,68 +418,62 @@ def main():
         dt = float(t.item())
         dist.barrier()
     ms_per_step = dt / a.steps * 1e3
-    value = world * a.batch * a.steps / dt
+    value = world * images_per_step * a.steps / dt
 
-    # ---- per-launch timing pass (un-captured, event pairs on the engine stream) ------------------
-    roofline, breakdown = None, None
-    if rank == 0 and not a.no_profile_pass:
-        acc = {}
-        reps = 5
-        plan.timed_eager()
-        for _ in range(reps):
-            for label, kind, ms, b, f in plan.timed_eager():
-                k = acc.setdefault(kind, [0.0, 0, 0, 0])
-                k[0] += ms / reps; k[1] += 1; k[2] += b / reps; k[3] += f / reps
-        stack_kinds = ("stem", "conv", "head", "dwconv", "pool", "attention")
-        stack_ms = sum(acc[k][0] for k in stack_kinds if k in acc)
-        is_cfg1 = a.scale == "n" and a.dtype == "f16"
-        if a.scale in ("n", "s"):
-            # HBM-bound scales: SURVEY.md 8(d) algorithmic bytes (config 2) or, for other variants, the plan's own
-            # layer-granular minimum (inputs + outputs of every fused launch) + weights
-            algo_bytes = (a.batch * ALGO_ACT_MB_PER_IMAGE + ALGO_WEIGHT_MB) * 1e6 if is_cfg1 \
-                else float(sum(acc[k][2] for k in stack_kinds if k in acc)) + wt.param_bytes
-            achieved = algo_bytes / (stack_ms * 1e-3) / 1e9
-            traffic = None
-            tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
-            if is_cfg1 and a.batch == 32 and os.path.exists(tpath):      # PMC pass of this exact workload (tools/traffic.py)
-                try:
-                    traffic = json.load(open(tpath)).get("hbm_bytes_per_step")
-                except Exception:
-                    traffic = None
-            roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                        "kernel": "conv stack (igemm / conv_tile / dwconv / pool / attention launches) per step",
-                        "kernel_ms_per_step": round(stack_ms, 4), "algorithmic_bytes_per_step": int(algo_bytes),
-                        # the captured graph runs the Detect chains beside the neck, so the step is shorter than the sum of
-                        # its launches: the same bytes over the measured step time (decode + NMS included)
-                        "achieved_over_graph_step": round(algo_bytes / (ms_per_step * 1e-3) / 1e9, 1),
-                        "frac_over_graph_step": round(algo_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
-        else:
-            # m / l / x are MFMA-bound (87 GFLOP / image for l)
-            fl = float(sum(acc[k][3] for k in stack_kinds if k in acc))
-            achieved = fl / (stack_ms * 1e-3) / 1e12
-            roofline = {"bound": "mfma", "achieved": round(achieved, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": None,
-                        "kernel": "conv stack (igemm / conv_tile launches) per step", "kernel_ms_per_step": round(stack_ms, 4),
-                        "algorithmic_flops_per_step": int(fl)}
-        breakdown = {k: {"ms": round(v[0], 4), "launches": v[1] // reps if v[1] >= reps else v[1],
-                         "plan_bytes": int(v[2]), "gflop": round(v[3] / 1e9, 3)} for k, v in acc.items()}
-
-    cpu = None
-    if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        cpu = cpu_baseline(a.scale, nc, params.state_dict())
+    # ---- per-stage timing (graph replays alone) + per-launch timing pass (un-captured, event pairs on the engine stream)
+    stage_info, rooflines, cpu_parts = {}, {}, {}
+    if rank == 0:
+        for sname, st in stages:
+            if sname.endswith("]") and not sname.endswith("[0]"):
+                continue                                           # identical second SAM stage
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            reps = 3 if isinstance(st, SamStage) else 20
+            st.run(); stream.synchronize()
+            e0.record(stream)
+            for _ in range(reps):
+                st.run()
+            e1.record(stream); stream.synchronize()
+            ms = e0.elapsed_time(e1) / reps
+            key = sname.replace("[0]", "")
+            info = {"batch": st.B, "ms_per_launch": round(ms, 4), "images_per_s": round(st.B / ms * 1e3, 2)}
+            if not a.no_profile_pass:
+                if isinstance(st, YoloStage):
+                    roof, info["breakdown"] = st.profile()
+                    rooflines[f"yolo11{st.scale}_conv_stack"] = roof
+                    info["mean_detections_per_image"] = round(sum(st.yp.det_count.cpu().tolist()) / st.B, 1)
+                else:
+                    roofs, info["breakdown"] = st.profile()
+                    rooflines.update(roofs)
+            stage_info[key] = info
+        if world == 1 and not a.no_cpu_baseline:
+            for sname, st in stages:
+                if sname.endswith("]") and not sname.endswith("[0]"):
+                    continue
+                key = sname.replace("[0]", "")
+                if isinstance(st, YoloStage):
+                    cpu_parts[key] = yolo_cpu_baseline(st.scale, st.nc, st.params.state_dict(), st.cpu_input())
+                else:
+                    cpu_parts[key] = sam_cpu_baseline(st.params.state_dict(), st.cpu_input(), boxes=st.boxes)
 
     if rank == 0:
-        counts = yp.det_count.cpu().tolist()
+        # the dominant kernel family by time: Hiera linear GEMMs wherever SAM runs, else the detector's conv stack
+        top = rooflines.get("sam2l_linear_gemm") or next(iter(rooflines.values()), None)
+        cpu = None
+        if cpu_parts:
+            if len(cpu_parts) == 1:
+                cpu = next(iter(cpu_parts.values()))
+            else:                                                 # one image through both stages on the CPU: times add
+                v = 1.0 / sum(1.0 / p["value"] for p in cpu_parts.values())
+                first = next(iter(cpu_parts.values()))
+                cpu = {"value": round(v, 4), "unit": "images/s", "cores": first["cores"], "cpu_model": first["cpu_model"], "kind": "port",
+                       "sample": "one image through both stages = 1 / (1 / detector rate + 1 / segmenter rate); per-stage samples in `parts`",
+                       "parts": cpu_parts}
         line = {
-            "metric": "circuit images/sec (YOLOv11 640² + SAM2.1-L 1024²) at 1/2/4/8 MI355X",
-            "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f16" if dtype == _lib.F16 else "f32", "data": "synthetic",
-            "config": {"workload": f"YOLO11-{a.scale} 640x640 batch={a.batch}/GPU fp16 forward+decode+NMS (BASELINE configs[1])",
-                       "images_per_step": world * a.batch, "nc": nc, "weights": "seeded random",
-                       "mean_detections_per_image": round(sum(counts) / len(counts), 1)},
-            "roofline": roofline, "cpu_baseline": cpu, "breakdown": breakdown,
+            "metric": METRIC, "value": round(value, 3), "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
+            "dtype": a.dtype, "data": "synthetic",
+            "config": {"workload": name, "images_per_step": world * images_per_step, "nc": 62, "weights": "seeded random (SAM: LoRA merged)"},
+            "roofline": top, "cpu_baseline": cpu, "rooflines": rooflines, "stages": stage_info,
         }
         print(json.dumps(line), flush=True)
     if world > 1:

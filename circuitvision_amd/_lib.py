@@ -103,6 +103,7 @@ SIGNATURES = {
     "cvmi_select_mask": (_i, [_vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp, _i, _i, _vp]),
     "cvmi_bilinear_f32": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _vp, _f, _vp]),
     "cvmi_mask_extent": (_i, [_vp, _i, _i, _i, _vp, _vp]),
+    "cvmi_mask_postprocess": (_i, [_vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp]),
     "cvmi_upsample_refine": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _vp, C.POINTER(_i), _i, _i, _vp]),
     "cvmi_sam2_transform": (_i, [_vp, _i, _i, _vp, _i, _i, _vp]),
 }

@@ -4,7 +4,8 @@
     ({'model': DetectionModel(...), ...}).  ultralytics is not a dependency here, so the pickle is read with a
     restricted unpickler that maps every `ultralytics.*` (and any other unknown) class to an inert stub and lets only
     torch tensor-rebuild helpers and plain containers through; tensors, `names` and the scale are then harvested by
-    walking the stubs' `_modules / _parameters / _buffers` dictionaries.  No code from the checkpoint is executed.
+    walking the stubs' `_modules / _parameters / _buffers` dictionaries.  Only the exact (module, name) pairs of
+    `_SAFE_NAMES` resolve to real objects; every other global the pickle names becomes an inert stub class.
   * SAM 2 base checkpoint {'model': state_dict} (sam2_infer.py:333 build_sam2) and the fine-tuned PEFT-keyed
     state_dict (circuit_analyzer.py:227-233): plain `torch.load(weights_only=True)`; see sam2.SamStateDictParams.
 """
@@ -15,13 +16,23 @@ import zipfile
 
 import torch
 
-_SAFE_PREFIXES = ("torch._utils", "torch.storage", "torch._tensor", "torch.serialization", "collections", "builtins", "numpy")
-_SAFE_NAMES = {
-    ("torch", "FloatStorage"), ("torch", "HalfStorage"), ("torch", "BFloat16Storage"), ("torch", "LongStorage"), ("torch", "IntStorage"),
-    ("torch", "DoubleStorage"), ("torch", "BoolStorage"), ("torch", "ByteStorage"), ("torch", "Size"), ("torch", "device"), ("torch", "dtype"),
-    ("torch.nn.parameter", "Parameter"), ("torch", "Tensor"), ("torch", "float32"), ("torch", "float16"),
-}
-_BLOCKED_BUILTINS = {"eval", "exec", "compile", "open", "__import__", "getattr", "setattr", "delattr", "input", "globals", "locals", "vars"}
+# Exact (module, name) allow-list: everything a tensor-bearing checkpoint needs to be rebuilt and nothing that can run code.
+# No module prefix is trusted as a whole -- `numpy.testing._private.utils.runstring` (exec) and
+# `torch.storage._load_from_bytes` (an unrestricted nested torch.load) both live under innocent-looking trees.
+_STORAGES = ("FloatStorage", "HalfStorage", "BFloat16Storage", "DoubleStorage", "LongStorage", "IntStorage", "ShortStorage",
+             "CharStorage", "ByteStorage", "BoolStorage", "UntypedStorage")
+_DTYPES = ("float32", "float16", "bfloat16", "float64", "int64", "int32", "int16", "int8", "uint8", "bool")
+_SAFE_NAMES = (
+    {("torch", n) for n in _STORAGES + _DTYPES + ("Size", "device", "dtype", "Tensor")}
+    | {("torch.storage", "UntypedStorage"), ("torch.storage", "TypedStorage")}
+    | {("torch._utils", n) for n in ("_rebuild_tensor", "_rebuild_tensor_v2", "_rebuild_parameter", "_rebuild_parameter_with_state")}
+    | {("torch.nn.parameter", "Parameter"), ("torch._tensor", "_rebuild_from_type_v2")}
+    | {("collections", "OrderedDict"), ("collections", "defaultdict")}
+    | {("builtins", n) for n in ("set", "frozenset", "dict", "list", "tuple", "slice", "complex", "int", "float", "bool", "str",
+                                 "bytes", "bytearray", "range", "object")}
+    | {(m, n) for m in ("numpy.core.multiarray", "numpy._core.multiarray") for n in ("scalar", "_reconstruct")}
+    | {("numpy", "dtype"), ("numpy", "ndarray")}
+)
 
 
 class _Stub:
@@ -46,14 +57,10 @@ def _stub_class(module, name):
 
 class RestrictedUnpickler(pickle.Unpickler):
     def find_class(self, module, name):
-        if (module, name) in _SAFE_NAMES or any(module == p or module.startswith(p + ".") for p in _SAFE_PREFIXES):
-            if module == "builtins" and name in _BLOCKED_BUILTINS:
-                raise pickle.UnpicklingError(f"blocked builtin {name}")
+        if (module, name) in _SAFE_NAMES:
             mod = __import__(module, fromlist=[name])
             return getattr(mod, name)
-        if module == "torch.nn.parameter" and name == "Parameter":
-            return torch.nn.Parameter
-        return _stub_class(module, name)           # ultralytics.*, torch.nn.modules.*, pathlib, ...: never executed
+        return _stub_class(module, name)           # ultralytics.*, torch.nn.modules.*, pathlib, os, numpy.testing, ...: inert
 
 
 class _RestrictedPickle:
@@ -77,7 +84,7 @@ def _walk(mod, prefix, out):
 
 
 def load_ultralytics_pt(path):
-    """-> {'state_dict': {ultralytics key: tensor}, 'names': {int: str}, 'scale': 'n'|'s'|'m'|'l'|'x'}"""
+    """-> {'state_dict': {ultralytics key: tensor}, 'names': {int: str}, 'scale': 'n'|'s'|'m'|'l'|'x', 'imgsz': int | None}"""
     ck = torch.load(path, map_location="cpu", weights_only=False, pickle_module=_RestrictedPickle)
     if isinstance(ck, dict) and "state_dict" in ck and "scale" in ck:           # already converted
         return ck
@@ -99,7 +106,16 @@ def load_ultralytics_pt(path):
     scale = yaml_.get("scale") if isinstance(yaml_, dict) else None
     if scale not in ("n", "s", "m", "l", "x"):
         scale = infer_scale(sd)
-    return {"state_dict": sd, "names": names, "scale": scale}
+    # ultralytics' Model._load keeps train_args['imgsz'] as the predict-time default (overrides survive _reset_ckpt_args)
+    targs = ck.get("train_args") if isinstance(ck, dict) else None
+    if not isinstance(targs, dict):
+        targs = getattr(model, "args", None)
+        targs = targs if isinstance(targs, dict) else getattr(targs, "__dict__", {})
+    imgsz = targs.get("imgsz") if isinstance(targs, dict) else None
+    if isinstance(imgsz, (list, tuple)):
+        imgsz = max(imgsz)
+    imgsz = int(imgsz) if isinstance(imgsz, (int, float)) and imgsz > 0 else None
+    return {"state_dict": sd, "names": names, "scale": scale, "imgsz": imgsz}
 
 
 def infer_scale(sd):

@@ -11,11 +11,13 @@
 //      The pass only records the kept sorted positions; the detections are written afterwards, one thread each
 //      (a kept box costs one LDS round + one barrier, not a chain of dependent global loads).
 #include "common.hpp"
+#include <mutex>
 
 namespace {
 
 constexpr int NMS_THREADS = 1024;
-constexpr int NMS_MAX_A = 16384;
+constexpr int NMS_LDS_A = 16384;                   // sort keys live in LDS up to this many anchors (imgsz <= 864 square) ...
+constexpr int NMS_MAX_A = 65536;                   // ... and in the workspace above it (checkpoints trained at imgsz 960 / 1024 / 1280)
 constexpr int NMS_MAX_DET = 4096;                  // LDS list of kept positions
 
 struct Cand { float x1, y1, x2, y2, area; };   // offset boxes (class * max_wh added)
@@ -38,16 +40,29 @@ __global__ __launch_bounds__(256) void best_class_kernel(const float* __restrict
   }
 }
 
+// GK: the P sort keys (and the candidate geometry) live in the workspace instead of LDS.  One workgroup still owns the image, so
+// every pass is ordered by __syncthreads() alone (a workgroup's global accesses go through its own CU's L1).
+// Invariant on the early `return` below: the waves with tid >= nthr leave BEFORE any later barrier; on gfx950 an s_barrier
+// counts only the waves of the workgroup that are still alive, so the remaining waves synchronise among themselves.
+template <bool GK>
 __global__ __launch_bounds__(NMS_THREADS) void yolo_nms_kernel(const float* __restrict__ pred, const float* __restrict__ best_score,
                                                               const int* __restrict__ best_cls, int nc, int A, float conf_thres,
                                                               float iou_thres, int max_det, float max_wh, float* __restrict__ out_det,
                                                               int* __restrict__ out_idx, int* __restrict__ out_count,
                                                               char* __restrict__ workspace, int P) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem);           // [P]
-  unsigned long long* supp = keys + P;                                               // [P/64] bitmask
-  int& s_count = *reinterpret_cast<int*>(supp + (P >> 6));                           // all LDS dynamic (16-B aligned base)
   const int b = blockIdx.x, tid = threadIdx.x;
+  const int nb = gridDim.x;
+  unsigned long long* keys;                                                          // [P]
+  unsigned long long* supp;                                                          // [P/64] bitmask, always LDS
+  if constexpr (GK) {
+    keys = reinterpret_cast<unsigned long long*>(workspace + (size_t)nb * (size_t)A * (sizeof(Cand) + sizeof(float) + sizeof(int)) + 256) + (size_t)b * P;
+    supp = reinterpret_cast<unsigned long long*>(smem);
+  } else {
+    keys = reinterpret_cast<unsigned long long*>(smem);
+    supp = keys + P;
+  }
+  int& s_count = *reinterpret_cast<int*>(supp + (P >> 6));                           // all LDS dynamic (16-B aligned base)
   const float* pb = pred + (size_t)b * (4 + nc) * A;
   const int* cls_ws = best_cls + (size_t)b * A;
   const float* sc_ws = best_score + (size_t)b * A;
@@ -90,7 +105,7 @@ __global__ __launch_bounds__(NMS_THREADS) void yolo_nms_kernel(const float* __re
   }
 
   // 3. candidate geometry in sorted order: in LDS behind the Ps sorted keys when it fits, in the workspace otherwise
-  const bool geo_lds = (size_t)Ps * 8 + (size_t)n * sizeof(Cand) <= (size_t)P * 8;
+  const bool geo_lds = !GK && (size_t)Ps * 8 + (size_t)n * sizeof(Cand) <= (size_t)P * 8;
   // boxes as 16-byte vectors + a separate area array (one ds_read_b128 + one ds_read_b32 per candidate instead of five scalar reads)
   f32x4* const box_l = reinterpret_cast<f32x4*>(keys + (Ps > 2 ? Ps : 2));
   float* const area_l = reinterpret_cast<float*>(box_l + n);
@@ -166,22 +181,31 @@ __global__ __launch_bounds__(NMS_THREADS) void yolo_nms_kernel(const float* __re
 
 extern "C" size_t cvmi_yolo_nms_workspace(int B, int A) {
   if (B <= 0 || A <= 0) return 0;
-  return (size_t)B * (size_t)A * (sizeof(Cand) + sizeof(float) + sizeof(int)) + 256;
+  size_t P = 1024;
+  while (P < (size_t)A) P <<= 1;
+  return (size_t)B * (size_t)A * (sizeof(Cand) + sizeof(float) + sizeof(int)) + 256 + (A > NMS_LDS_A ? (size_t)B * P * 8 : 0);
 }
 
 static int nms_launch(const float* pred, const float* best_score, const int* best_cls, int B, int nc, int A, float conf_thres, float iou_thres,
                       int max_det, float max_wh, float* out_det, int* out_idx, int* out_count, void* workspace, hipStream_t stream) {
   int P = 1024;
   while (P < A) P <<= 1;
-  const size_t lds = (size_t)P * 8 + (size_t)(P / 64) * 8 + 16 + (size_t)max_det * sizeof(int);
-  static bool attr_done = false;
-  if (!attr_done) {
-    CVMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&yolo_nms_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 NMS_MAX_A * 8 + (NMS_MAX_A / 64) * 8 + 16 + NMS_MAX_DET * (int)sizeof(int)));
-    attr_done = true;
-  }
-  hipLaunchKernelGGL(yolo_nms_kernel, dim3(B), dim3(NMS_THREADS), lds, stream, pred, best_score, best_cls, nc, A, conf_thres, iou_thres, max_det,
-                     max_wh, out_det, out_idx, out_count, (char*)workspace, P);
+  const bool gk = A > NMS_LDS_A;
+  const size_t lds = (gk ? 0 : (size_t)P * 8) + (size_t)(P / 64) * 8 + 16 + (size_t)max_det * sizeof(int);
+  // once per process; std::call_once so that concurrent first calls from two host threads both see the attribute set
+  static std::once_flag attr_once;
+  static hipError_t attr_err = hipSuccess;
+  std::call_once(attr_once, [] {
+    attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&yolo_nms_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   NMS_LDS_A * 8 + (NMS_LDS_A / 64) * 8 + 16 + NMS_MAX_DET * (int)sizeof(int));
+  });
+  CVMI_HIP(attr_err);
+  if (gk)
+    hipLaunchKernelGGL(yolo_nms_kernel<true>, dim3(B), dim3(NMS_THREADS), lds, stream, pred, best_score, best_cls, nc, A, conf_thres, iou_thres,
+                       max_det, max_wh, out_det, out_idx, out_count, (char*)workspace, P);
+  else
+    hipLaunchKernelGGL(yolo_nms_kernel<false>, dim3(B), dim3(NMS_THREADS), lds, stream, pred, best_score, best_cls, nc, A, conf_thres, iou_thres,
+                       max_det, max_wh, out_det, out_idx, out_count, (char*)workspace, P);
   CVMI_LAUNCH_CHECK();
   return 0;
 }

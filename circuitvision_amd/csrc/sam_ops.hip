@@ -291,19 +291,36 @@ __device__ __forceinline__ float bil_sample(const float* __restrict__ pl, int w,
   return hy * (hx * pl[(size_t)y0 * w + x0] + lx * pl[(size_t)y0 * w + x1]) + ly * (hx * pl[(size_t)y1 * w + x0] + lx * pl[(size_t)y1 * w + x1]);
 }
 
+// y (f32 map), mask (u8 {0,255} of v > thresh) and ext (per-plane extent of the mask, pre-initialised to {W, H, -1, -1}) are each
+// optional: the reference's post-processing (circuit_analyzer.py:354-370) only needs the u8 mask and its bounding rectangle, so the
+// f32 [N,H,W] map need not be written at all.
 __global__ __launch_bounds__(256) void bilinear_kernel(const float* __restrict__ x, int h, int w, float* __restrict__ y, int H, int W,
-                                                      uint8_t* __restrict__ mask, float thresh, float sy, float sx) {
+                                                      uint8_t* __restrict__ mask, float thresh, float sy, float sx, int* __restrict__ ext) {
   const int n = blockIdx.y;
   const float* pl = x + (size_t)n * h * w;
   const int total = H * W;
+  int ex0 = W, ey0 = H, ex1 = -1, ey1 = -1;
   for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
     const int oy = idx / W, ox = idx - oy * W;
     int y0, y1, x0, x1; float ly, lx;
     bil_axis(oy, sy, h, y0, y1, ly);
     bil_axis(ox, sx, w, x0, x1, lx);
     const float v = bil_sample(pl, w, y0, y1, ly, x0, x1, lx);
-    y[(size_t)n * total + idx] = v;
-    if (mask) mask[(size_t)n * total + idx] = v > thresh ? 255 : 0;
+    if (y) y[(size_t)n * total + idx] = v;
+    const bool on = v > thresh;
+    if (mask) mask[(size_t)n * total + idx] = on ? 255 : 0;
+    if (on) { ex0 = min(ex0, ox); ex1 = max(ex1, ox); ey0 = min(ey0, oy); ey1 = max(ey1, oy); }
+  }
+  if (ext) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      ex0 = min(ex0, __shfl_xor(ex0, off)); ey0 = min(ey0, __shfl_xor(ey0, off));
+      ex1 = max(ex1, __shfl_xor(ex1, off)); ey1 = max(ey1, __shfl_xor(ey1, off));
+    }
+    if ((threadIdx.x & 63) == 0 && ex1 >= 0) {
+      atomicMin(ext + n * 4 + 0, ex0); atomicMin(ext + n * 4 + 1, ey0);
+      atomicMax(ext + n * 4 + 2, ex1); atomicMax(ext + n * 4 + 3, ey1);
+    }
   }
 }
 
@@ -664,9 +681,20 @@ extern "C" int cvmi_select_mask(const float* masks, const int* areas, const floa
 }
 
 extern "C" int cvmi_bilinear_f32(const float* x, int N, int h, int w, float* y, int H, int W, uint8_t* mask_u8, float thresh, cvmi_stream_t stream_) {
-  CVMI_CHECK(x && y && N > 0 && h > 0 && w > 0 && H > 0 && W > 0, "bilinear: bad arguments");
+  CVMI_CHECK(x && (y || mask_u8) && N > 0 && N <= 65535 && h > 0 && w > 0 && H > 0 && W > 0, "bilinear: bad arguments");
   hipLaunchKernelGGL(bilinear_kernel, dim3(grid_for((long long)H * W, 256, 1024), N), dim3(256), 0, (hipStream_t)stream_, x, h, w, y, H, W, mask_u8,
-                     thresh, (float)h / (float)H, (float)w / (float)W);
+                     thresh, (float)h / (float)H, (float)w / (float)W, (int*)nullptr);
+  CVMI_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int cvmi_mask_postprocess(const float* x, int N, int h, int w, int H, int W, float thresh, uint8_t* mask_u8, int* extent,
+                                     cvmi_stream_t stream_) {
+  CVMI_CHECK(x && mask_u8 && extent && N > 0 && N <= 65535 && h > 0 && w > 0 && H > 0 && W > 0, "mask_postprocess: bad arguments");
+  hipStream_t s = (hipStream_t)stream_;
+  hipLaunchKernelGGL(mask_extent_init_kernel, dim3((N + 63) / 64), dim3(64), 0, s, extent, N, H, W);
+  hipLaunchKernelGGL(bilinear_kernel, dim3(grid_for((long long)H * W, 256, 1024), N), dim3(256), 0, s, x, h, w, (float*)nullptr, H, W, mask_u8, thresh,
+                     (float)h / (float)H, (float)w / (float)W, extent);
   CVMI_LAUNCH_CHECK();
   return 0;
 }

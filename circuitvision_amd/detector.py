@@ -70,13 +70,16 @@ class YOLO:
     """`YOLO(path)`; path is an ultralytics `.pt` (read without ultralytics, see checkpoints.py), a converted
     {'state_dict', 'names', 'scale'} file, or 'synthetic:<scale>:<nc>[:seed]' for seeded random weights."""
 
-    def __init__(self, path, dtype="f16", device="cuda", imgsz=640, keep_scores=False):
-        """keep_scores=True also materialises ultralytics' full [B, 4+nc, A] prediction tensor (tests / debugging)."""
+    MAX_ANCHORS = 65536          # cvmi_yolo_nms: one workgroup per image, keys in LDS (<= 16384 anchors) or in its workspace
+
+    def __init__(self, path, dtype="f16", device="cuda", imgsz=None, keep_scores=False):
+        """keep_scores=True also materialises ultralytics' full [B, 4+nc, A] prediction tensor (tests / debugging).
+        imgsz=None: the checkpoint's train_args['imgsz'] (what ultralytics' predict() inherits), else 640."""
         require_gpu()
         self.keep_scores = keep_scores
         self.dtype = {"f16": F16, "fp16": F16, "f32": F32, "fp32": F32}[dtype] if isinstance(dtype, str) else dtype
         self.device = device
-        self.imgsz = imgsz
+        ck_imgsz = None
         spec = parse_spec(path)
         if spec is not None:
             scale, nc, seed = spec
@@ -88,6 +91,8 @@ class YOLO:
             scale, names = ck["scale"], {int(k): v for k, v in ck["names"].items()}
             nc = len(names)
             params = StateDictParams(ck["state_dict"])
+            ck_imgsz = ck.get("imgsz")
+        self.imgsz = self._check_imgsz(imgsz if imgsz is not None else (ck_imgsz or 640))
         self.params = params
         self.weights = Yolo11Weights(scale, nc, params, self.dtype, device)
         self.model = SimpleNamespace(names=names, nc=nc, scale=scale, stride=32)
@@ -95,6 +100,16 @@ class YOLO:
         self.stream = torch.cuda.Stream(device=device)
         self._plans = {}
         self._lock = threading.Lock()      # one analyzer is shared by all Streamlit sessions (app.py:134)
+
+    @classmethod
+    def _check_imgsz(cls, imgsz):
+        imgsz = int(max(imgsz)) if isinstance(imgsz, (list, tuple)) else int(imgsz)
+        if imgsz < 32:
+            raise ValueError(f"imgsz={imgsz}: must be >= 32")
+        imgsz = -(-imgsz // 32) * 32                       # ultralytics check_imgsz: round up to a stride multiple
+        if imgsz * imgsz * 21 // 1024 > cls.MAX_ANCHORS:   # anchors of a square input: (1/64 + 1/256 + 1/1024) per pixel
+            raise ValueError(f"imgsz={imgsz} gives more than {cls.MAX_ANCHORS} anchors, beyond what cvmi_yolo_nms handles")
+        return imgsz
 
     # ---- plans ---------------------------------------------------------------------------------
     def plan(self, B, H, W, conf=0.25, iou=0.7, max_det=300):
@@ -105,8 +120,9 @@ class YOLO:
         return self._plans[key]
 
     # ---- reference entry point -----------------------------------------------------------------
-    def predict(self, image, verbose=True, conf=0.25, iou=0.7, max_det=300, **_):
+    def predict(self, image, verbose=True, conf=0.25, iou=0.7, max_det=300, imgsz=None, **_):
         """image: uint8 HxWx3 numpy array (or a list of same-shaped ones).  Returns [Results]."""
+        imgsz = self.imgsz if imgsz is None else self._check_imgsz(imgsz)
         images = image if isinstance(image, (list, tuple)) else [image]
         for im in images:
             if not (isinstance(im, np.ndarray) and im.ndim == 3 and im.shape[2] == 3 and im.dtype == np.uint8):
@@ -114,7 +130,7 @@ class YOLO:
         h0, w0 = images[0].shape[:2]
         if any(im.shape[:2] != (h0, w0) for im in images):
             raise ValueError("a batch must share one image size")
-        nw, nh, top, bottom, left, right = letterbox_geometry(h0, w0, self.imgsz)
+        nw, nh, top, bottom, left, right = letterbox_geometry(h0, w0, imgsz)
         H, W = nh + top + bottom, nw + left + right
         lib = _lib.load()
         with self._lock, torch.cuda.device(self.device):

@@ -30,9 +30,12 @@ def packed_tensors(packed):
 def broadcast_packed(packed, src=0, bucket_bytes=64 << 20):
     """Broadcast every packed weight tensor from `src`.  Tensors are coalesced into flat buckets per
     dtype (a 1->7 xGMI fan-out is per-link bound, so few large messages beat hundreds of small ones)."""
+    return _broadcast_tensors(packed_tensors(packed), src, bucket_bytes)
+
+
+def _broadcast_tensors(tensors, src, bucket_bytes):
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return 0
-    tensors = packed_tensors(packed)
     sent = 0
     by_dtype = {}
     for t in tensors:
@@ -55,13 +58,50 @@ def broadcast_packed(packed, src=0, bucket_bytes=64 << 20):
     return sent
 
 
+def weight_tensors(weights):
+    """Every device tensor of a prepared model (Yolo11Weights / Sam2Weights): packed convs, LayerNorm affine pairs, folded
+    constants, refinement parameters -- what a rank needs to run without reading the checkpoint itself."""
+    out = []
+    for name in ("packed", "pc"):
+        d = getattr(weights, name, None)
+        if d:
+            out += packed_tensors(d)
+    for key in sorted(getattr(weights, "ln", {}) or {}):
+        out += list(weights.ln[key])
+    for key in sorted(getattr(weights, "const", {}) or {}):
+        out.append(weights.const[key])
+    rp = getattr(weights, "refine_params", None)
+    if rp is not None:
+        out.append(rp)
+    return out
+
+
+def broadcast_weights(weights, src=0, bucket_bytes=64 << 20):
+    """One-time broadcast of a whole prepared model from `src` (RCCL over xGMI; gloo in the CPU tests)."""
+    return _broadcast_tensors(weight_tensors(weights), src, bucket_bytes)
+
+
+def gather_rows(t, dst=0):
+    """Gather tensors whose FIRST dimension differs between ranks (uneven shards: shard_range hands out sizes that differ by
+    one when total % world != 0) on `dst`: sizes are exchanged first, every rank pads to the largest shard, `dst` trims.
+    Returns the list of per-rank tensors on `dst`, None elsewhere."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return [t]
+    world, rank = dist.get_world_size(), dist.get_rank()
+    n = torch.tensor([t.shape[0]], dtype=torch.int64, device=t.device)
+    sizes = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(sizes, n)
+    sizes = [int(x.item()) for x in sizes]
+    m = max(sizes)
+    pad = t if t.shape[0] == m else torch.cat((t, t.new_zeros((m - t.shape[0],) + tuple(t.shape[1:]))), 0)
+    pad = pad.contiguous()
+    bufs = [torch.empty_like(pad) for _ in range(world)] if rank == dst else None
+    dist.gather(pad, bufs, dst=dst)
+    return [b[:k] for b, k in zip(bufs, sizes)] if rank == dst else None
+
+
 def gather_detections(det, count, dst=0):
-    """Gather per-rank [B, max_det, 6] detections and [B] counts on `dst` (None elsewhere)."""
+    """Gather per-rank [B_r, max_det, 6] detections and [B_r] counts on `dst` (None elsewhere); B_r may differ between ranks."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return [det], [count]
-    world = dist.get_world_size()
-    dets = [torch.empty_like(det) for _ in range(world)] if dist.get_rank() == dst else None
-    cnts = [torch.empty_like(count) for _ in range(world)] if dist.get_rank() == dst else None
-    dist.gather(det, dets, dst=dst)
-    dist.gather(count, cnts, dst=dst)
-    return dets, cnts
+    return gather_rows(det, dst), gather_rows(count, dst)

@@ -1,0 +1,130 @@
+"""Batched detector -> segmenter pipeline over a shard of circuit images (BASELINE configs[3]).
+
+What it restates, batched and on the device, is the chain the reference runs per uploaded image:
+
+    run_initial_detection              /root/reference/src/analysis_pipeline.py:97-115
+        CircuitAnalyzer.bboxes         src/circuit_analyzer.py:267-287   (YOLO.predict -> dicts, python round(), persistent uid)
+        non_max_suppression_by_confidence(iou 0.6)                       src/utils.py:346-361
+    run_segmentation_and_cropping      src/analysis_pipeline.py:168-225
+        crop_image_and_adjust_bboxes   src/circuit_analyzer.py:937-1284  (host heuristics on <= 300 boxes; stays the caller's:
+                                                                          pass it as `crop_fn`, default = no crop)
+        CircuitAnalyzer.segment_with_sam2                                src/circuit_analyzer.py:321-386
+
+`prompts="learned"` is the reference's own segmentation (one mask per image from the wrapper's learned prompts);
+`prompts="boxes"` feeds the detector's boxes to `infer_masks(images, boxes)` (upstream box prompting, BASELINE configs[4]):
+one mask per detected component.
+
+Images are independent through both models, so a batch shards contiguously over ranks with no collective on the data path
+(`shard_range`); every rank returns the results of its own images, `gather_results` collects them on one rank when a single
+caller needs them.  Results do not depend on how the batch is split (tests: sharded == unsharded, bit for bit).
+"""
+import numpy as np
+import torch
+
+from .detector import non_max_suppression_by_confidence
+from .distributed import gather_rows, shard_range
+
+
+def results_to_bboxes(r):
+    """circuit_analyzer.py:267-287 on one `Results`: lists via .cpu().numpy().tolist(), python round() (half-to-even), uid string."""
+    ids = r.boxes.cls.cpu().numpy().tolist()
+    names = [r.names[int(i)] for i in ids]
+    conf = r.boxes.conf.cpu().numpy().tolist()
+    out = []
+    for i, (xmin, ymin, xmax, ymax) in enumerate(r.boxes.xyxy.cpu().numpy().tolist()):
+        out.append({"class": names[i], "_yolo_class_id_temp": int(ids[i]), "confidence": conf[i],
+                    "xmin": round(xmin), "ymin": round(ymin), "xmax": round(xmax), "ymax": round(ymax),
+                    "persistent_uid": f"{names[i]}_{round(xmin)}_{round(ymin)}_{round(xmax)}_{round(ymax)}"})
+    return out
+
+
+class CircuitPipeline:
+    """detector: `circuitvision_amd.detector.YOLO`-like (`predict(list of uint8 HxWx3) -> [Results]`);
+    segmenter: `SAM2Model`-like (`infer_masks(x, boxes=None)`, `.image_size`); transforms: `SAM2Transforms`-like."""
+
+    def __init__(self, detector, segmenter, transforms, stage2_iou=0.6, max_prompts=32, crop_fn=None, swap_channels=True):
+        """swap_channels: segment_with_sam2 applies cv2.COLOR_BGR2RGB to whatever it is given (circuit_analyzer.py:343), and the
+        pipeline hands it RGB (analysis_pipeline.py:199-203) -- i.e. the reference's segmenter sees the channels reversed."""
+        self.det, self.seg, self.tr = detector, segmenter, transforms
+        self.stage2_iou, self.max_prompts, self.crop_fn, self.swap = stage2_iou, max_prompts, crop_fn, swap_channels
+
+    # ---- stage A: analysis_pipeline.py:97-115
+    def detect(self, images):
+        """-> per image: the bboxes that survive the second-stage NMS (list of dicts, original pixel coordinates)."""
+        out = [None] * len(images)
+        groups = {}
+        for i, im in enumerate(images):
+            groups.setdefault(im.shape[:2], []).append(i)
+        for idxs in groups.values():                                   # one detector batch per image size
+            res = self.det.predict([images[i] for i in idxs], verbose=False)
+            for i, r in zip(idxs, res):
+                out[i] = non_max_suppression_by_confidence(results_to_bboxes(r), iou_threshold=self.stage2_iou)
+        return out
+
+    # ---- stage B: analysis_pipeline.py:168-225
+    def segment(self, images, bboxes, prompts="learned"):
+        R = self.seg.image_size
+        crops, boxes_adj = [], []
+        for im, bb in zip(images, bboxes):
+            if self.crop_fn is not None:
+                im, bb, _ = self.crop_fn(im, [dict(b) for b in bb])
+            crops.append(im)
+            boxes_adj.append(bb)
+        seg_in = [np.ascontiguousarray(im[..., ::-1]) if self.swap else im for im in crops]
+        x = self.tr.forward_batch(seg_in)
+        out = []
+        if prompts == "learned":
+            hi, lo, iou = self.seg.infer_masks(x)
+            for b, im in enumerate(crops):
+                u8, ext = self.tr.postprocess_to_mask(hi[b:b + 1], im.shape[:2])
+                out.append({"image": im, "bboxes": boxes_adj[b], "mask": u8[0, 0], "extent": ext[0], "iou": iou[b]})
+            return out
+        if prompts != "boxes":
+            raise ValueError("prompts must be 'learned' or 'boxes'")
+        P = self.max_prompts
+        bx = torch.zeros(len(crops), P, 4)
+        counts = []
+        for b, (im, bb) in enumerate(zip(crops, boxes_adj)):
+            bb = bb[:P]                                                  # already sorted by confidence (stage-2 NMS order)
+            counts.append(len(bb))
+            if bb:
+                t = torch.tensor([[d["xmin"], d["ymin"], d["xmax"], d["ymax"]] for d in bb], dtype=torch.float32)
+                t = self.tr.transform_boxes(t, normalize=True, orig_hw=im.shape[:2]).reshape(-1, 4)
+                bx[b, :len(bb)] = t
+                bx[b, len(bb):] = t[0]                                   # unused prompt slots repeat the first box (results dropped)
+            else:
+                bx[b] = torch.tensor([0.0, 0.0, R, R])
+        _, lo, iou = self.seg.infer_masks(x, bx, return_high_res=False)
+        for b, im in enumerate(crops):
+            k = counts[b]
+            if k:
+                u8, ext = self.tr.postprocess_to_mask(lo[b, :k].unsqueeze(0), im.shape[:2])
+                masks, ext = u8[0], ext
+            else:
+                masks, ext = torch.zeros(0, *im.shape[:2], dtype=torch.uint8, device=lo.device), []
+            out.append({"image": im, "bboxes": boxes_adj[b][:P], "masks": masks, "extents": ext, "iou": iou[b, :k]})
+        return out
+
+    def run_batch(self, images, prompts="learned", rank=0, world=1):
+        """The share [lo, hi) of `images` that belongs to `rank`: detection, stage-2 NMS, (crop), segmentation.
+        Returns [(global image index, result dict)]."""
+        lo, hi = shard_range(len(images), rank, world)
+        mine = list(images[lo:hi])
+        if not mine:
+            return []
+        bboxes = self.detect(mine)
+        res = self.segment(mine, bboxes, prompts)
+        return [(lo + i, r) for i, r in enumerate(res)]
+
+
+def gather_results(results, key="mask", dst=0):
+    """Collect one same-shaped tensor per image (e.g. the u8 mask of equally sized images) from every rank on `dst`:
+    returns {global index: tensor} there, None elsewhere.  Shards may be uneven."""
+    if not results:
+        raise ValueError("gather_results needs at least one local result per rank (pad the batch or skip the gather)")
+    idx = torch.tensor([i for i, _ in results], dtype=torch.int64, device=results[0][1][key].device)
+    vals = torch.stack([r[key] for _, r in results])
+    gi, gv = gather_rows(idx, dst), gather_rows(vals, dst)
+    if gi is None:
+        return None
+    return {int(i): v for ids, vs in zip(gi, gv) for i, v in zip(ids.tolist(), vs)}

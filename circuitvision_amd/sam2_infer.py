@@ -44,7 +44,7 @@ class SAM2Model:
         self.lora = (lora_rank, lora_alpha)
         self.dynamic = dynamic_multimask_via_stability
         self.sam2_model = SimpleNamespace(image_size=image_size)          # circuit_analyzer.py:237-240 reads .sam2_model.image_size
-        self.weights, self.params = None, None
+        self.weights, self.params, self._pending = None, None, None
         self.stream = torch.cuda.Stream(device=dev)
         self._plans = {}
         self._lock = threading.Lock()                                       # one analyzer is shared across sessions (app.py:134)
@@ -52,7 +52,7 @@ class SAM2Model:
 
     # -- nn.Module-like surface the reference touches
     def load_params(self, params):
-        self.params = params
+        self.params, self._pending = params, None
         with torch.cuda.device(self.dev):
             self.weights = Sam2Weights(params, self.hiera, self.image_size, self.dtype, self.dev, **self.cfg)
         self._plans.clear()
@@ -71,6 +71,8 @@ class SAM2Model:
         return self
 
     def plan(self, B, prompts=0, high_res=True, points=3):
+        if self.weights is None and self._pending is not None:
+            self.load_params(self._pending)           # base checkpoint only (no fine-tuned state dict followed): pack it now
         if self.weights is None:
             raise RuntimeError("SAM2 weights not loaded (call load_state_dict first)")
         key = (B, prompts, high_res, points if prompts else 0)
@@ -187,7 +189,9 @@ def get_modified_sam2(model_cfg_path, checkpoint_path, device="cuda", use_high_r
         targets = lora_target_modules if (use_peft and lora_target_modules is not None) else ()
         model.load_params(SamSyntheticParams(seed=seed, lora_targets=targets, r=lora_rank, alpha=lora_alpha))
     elif isinstance(checkpoint_path, str) and os.path.exists(checkpoint_path):
-        model.load_params(SamBaseCheckpointParams(torch.load(checkpoint_path, map_location="cpu", weights_only=True)))
+        # The reference always loads the fine-tuned state dict next (circuit_analyzer.py:227-233), which replaces every tensor:
+        # packing the base weights is deferred until a forward pass actually needs them.
+        model._pending = SamBaseCheckpointParams(torch.load(checkpoint_path, map_location="cpu", weights_only=True))
     return model
 
 
@@ -218,7 +222,22 @@ class SAM2Transforms:
         return out.permute(2, 0, 1)
 
     def forward_batch(self, img_list):
-        return torch.stack([self(img) for img in img_list], dim=0)
+        """sam2_infer.py:53-56.  -> f32 [B,3,R,R] (channels-last memory); one device synchronisation for the whole batch."""
+        require_gpu()
+        lib = _lib.load()
+        R = self.resolution
+        out = torch.empty(len(img_list), R, R, 3, dtype=torch.float32, device="cuda")
+        srcs = []
+        for img in img_list:
+            img = np.ascontiguousarray(np.asarray(img))
+            if img.ndim != 3 or img.shape[2] != 3 or img.dtype != np.uint8:
+                raise TypeError("SAM2Transforms expects RGB uint8 images (PIL or HxWx3 arrays)")
+            srcs.append(torch.from_numpy(img).cuda())
+        torch.cuda.current_stream().synchronize()
+        for b, src in enumerate(srcs):
+            _lib.check(lib.cvmi_sam2_transform(src.data_ptr(), src.shape[0], src.shape[1], out[b].data_ptr(), R, F32, None), "sam2_transform")
+        torch.cuda.synchronize()
+        return out.permute(0, 3, 1, 2)
 
     def mask_extent(self, mask_u8):
         """Bounding boxes of binary masks [N,H,W] / [B,C,H,W] (u8 on the device): list of (x0, y0, x1, y1) or None per
@@ -233,6 +252,23 @@ class SAM2Transforms:
         _lib.check(lib.cvmi_mask_extent(m.data_ptr(), N, H, W, ext.data_ptr(), None), "mask_extent")
         torch.cuda.synchronize()
         return [None if x1 < 0 else (x0, y0, x1 + 1, y1 + 1) for x0, y0, x1, y1 in ext.cpu().tolist()]
+
+    # sam2_infer.py:58-86 -- what a caller needs to feed detector boxes (original pixels) to `infer_masks`
+    def transform_coords(self, coords, normalize=False, orig_hw=None):
+        """[..., 2] (x, y).  normalize=True: absolute pixels of an orig_hw = (h, w) image -> [0, 1] first; then x resolution."""
+        coords = torch.as_tensor(coords, dtype=torch.float32)
+        if normalize:
+            assert orig_hw is not None
+            h, w = orig_hw
+            coords = coords.clone()
+            coords[..., 0] = coords[..., 0] / w
+            coords[..., 1] = coords[..., 1] / h
+        return coords * self.resolution
+
+    def transform_boxes(self, boxes, normalize=False, orig_hw=None):
+        """[N, 4] xyxy -> [N, 2, 2] corner points in the resolution x resolution input space (as the reference returns them;
+        `.reshape(-1, 4)` gives the xyxy rows `infer_masks(images, boxes)` takes)."""
+        return self.transform_coords(torch.as_tensor(boxes, dtype=torch.float32).reshape(-1, 2, 2), normalize, orig_hw)
 
     def postprocess_masks(self, masks, orig_hw, return_u8=False):
         require_gpu()
@@ -249,3 +285,22 @@ class SAM2Transforms:
                                          float(self.mask_threshold), None), "bilinear")
         torch.cuda.synchronize()
         return (out, u8) if return_u8 else out
+
+    def postprocess_to_mask(self, masks, orig_hw):
+        """circuit_analyzer.py:354-370 in one pass on the device: bilinear resize to orig_hw -> `> mask_threshold` -> u8 {0, 255}
+        -> bounding rectangle.  The f32 [B,C,H,W] map is never written; only the u8 masks and four ints per mask exist afterwards.
+        Returns (mask_u8 [B,C,H,W] on the device, [(x0, y0, x1, y1) | None] per mask, the reference's `sam_extent_bbox`)."""
+        require_gpu()
+        lib = _lib.load()
+        m = masks.float().contiguous()
+        if not m.is_cuda:
+            m = m.cuda()
+        B, C, h, w = m.shape
+        H, W = int(orig_hw[0]), int(orig_hw[1])
+        u8 = torch.empty(B, C, H, W, dtype=torch.uint8, device=m.device)
+        ext = torch.empty(B * C, 4, dtype=torch.int32, device=m.device)
+        torch.cuda.current_stream().synchronize()
+        _lib.check(lib.cvmi_mask_postprocess(m.data_ptr(), B * C, h, w, H, W, float(self.mask_threshold), u8.data_ptr(), ext.data_ptr(), None),
+                   "mask_postprocess")
+        torch.cuda.synchronize()
+        return u8, [None if x1 < 0 else (x0, y0, x1 + 1, y1 + 1) for x0, y0, x1, y1 in ext.cpu().tolist()]

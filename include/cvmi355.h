@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define CVMI_VERSION 105
+#define CVMI_VERSION 106
 
 typedef void* cvmi_stream_t; /* hipStream_t */
 
@@ -262,7 +262,14 @@ int cvmi_select_mask(const float* masks, const int* areas, const float* iou, int
 /* F.interpolate(bilinear, align_corners=False) of f32 planes [N,h,w] -> [N,H,W] (sam2_infer.py:263-268,
  * postprocess_masks :127).  mask_u8 (optional): also writes (value > thresh) ? 255 : 0. */
 int cvmi_bilinear_f32(const float* x, int N, int h, int w, float* y, int H, int W, uint8_t* mask_u8,
-                      float thresh, cvmi_stream_t stream);
+                      float thresh, cvmi_stream_t stream);   /* y may be NULL when mask_u8 is given */
+
+/* The reference's whole mask post-processing in one pass (circuit_analyzer.py:354-370): postprocess_masks' bilinear resize
+ * (sam2_infer.py:127) -> `> thresh` -> u8 {0, 255} (:356-357) -> bounding rectangle of the non-zero pixels (:364-370,
+ * cv2.findContours + boundingRect), WITHOUT materialising the f32 [N,H,W] map: only the u8 mask and four ints per plane
+ * are written.  extent[n] = {min x, min y, max x, max y} or {W, H, -1, -1} for an empty mask. */
+int cvmi_mask_postprocess(const float* x, int N, int h, int w, int H, int W, float thresh, uint8_t* mask_u8,
+                          int* extent, cvmi_stream_t stream);
 
 /* Extent of N binary u8 planes [N,H,W]: extent[n] = {min x, min y, max x, max y} over the non-zero pixels, or
  * {W, H, -1, -1} for an empty plane.  Replaces cv2.findContours(RETR_EXTERNAL) + cv2.boundingRect on the SAM 2 mask

@@ -68,8 +68,8 @@ def letterbox(img, new_shape=640, stride=32, auto=True, pad_value=114):
     return out
 
 
-def yolo_preprocess(img):
+def yolo_preprocess(img, new_shape=640):
     """u8 HxWx3 -> f32 1x3xhxw: letterbox, reverse channel order, CHW, /255."""
-    lb = letterbox(img)
+    lb = letterbox(img, new_shape)
     chw = np.ascontiguousarray(lb[..., ::-1].transpose(2, 0, 1))
     return (chw.astype(np.float32) / 255.0)[None]

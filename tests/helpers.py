@@ -34,3 +34,31 @@ def run(plan):
     torch.cuda.synchronize()          # buffer fills ran on the default stream
     plan.run_eager()
     plan.stream.synchronize()
+
+
+def err_stats(got, ref):
+    """(max |err|, rms err, std of the reference) as floats -- tolerances in the whole-model tests are stated RELATIVE to the
+    reference's standard deviation, so they keep biting whatever the scale of the synthetic activations is."""
+    d = (got.float() - ref.float())
+    return float(d.abs().max()), float(d.pow(2).mean().sqrt()), float(ref.float().std())
+
+
+def assert_rel(name, got, ref, max_rel, rms_rel, report=None, absolute=False):
+    """max |err| <= max_rel * std(ref) and rms err <= rms_rel * std(ref); absolute=True: the bounds are absolute."""
+    mx, rms, sd = err_stats(got, ref)
+    if absolute:
+        max_rel, rms_rel = max_rel / sd, rms_rel / sd
+    line = f"{name}: max|err| {mx:.3e} ({mx / sd:.2e} std), rms {rms:.3e} ({rms / sd:.2e} std), std(ref) {sd:.3f}"
+    print(line)
+    if report is not None:
+        report.append(line)
+    assert sd > 0 and mx <= max_rel * sd and rms <= rms_rel * sd, line
+
+
+def save_converted_yolo(path, params, scale, nc, imgsz=None):
+    """The converted-checkpoint format `YOLO(path)` reads ({'state_dict', 'names', 'scale'[, 'imgsz']})."""
+    ck = {"state_dict": params.state_dict(), "names": {i: f"class{i}" for i in range(nc)}, "scale": scale}
+    if imgsz is not None:
+        ck["imgsz"] = imgsz
+    torch.save(ck, path)
+    return path

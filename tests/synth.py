@@ -54,3 +54,55 @@ def nms_stress_pred(B, nc=62, hw=(640, 640), seed=0, frac_logit=-4.0):
             cls[:, nb] = cls[:, a:a + 1] * torch.empty(1, 8).uniform_(0.6, 1.0, generator=g)
         out.append(torch.cat((torch.stack((cx, cy, w, h)), cls), 0))
     return torch.stack(out).float().contiguous()
+
+
+def calibrated_yolo_params(scale, nc, seed, x, cand_per_image=45, spread=2.0, conf=0.25):
+    """Seeded synthetic YOLO11 weights that DETECT something on the images `x` ([B,3,H,W] f32, letterboxed).
+
+    Seeded random weights leave every class score below ~0.02 and contract the activations to near-constants (neck features of
+    std 0.09), so NMS, scale_boxes and the Results plumbing would be compared on empty lists and loose absolute tolerances would
+    not bite.  Two calibration steps, both on the CPU oracle:
+      1. BatchNorm statistics: one pass over `x` with every BN in cumulative-average training mode sets running_mean / running_var
+         to the statistics the layer actually sees, so activations stay O(1) through all 24 layers (as in a trained network);
+      2. class branch: the final class conv of each level (model.23.cv3.<i>.2) is rescaled so its logits have standard deviation
+         `spread`, and its bias shifted so that about cand_per_image / 3 anchors per image and level clear `conf` -- the threshold is
+         placed in the middle of the widest gap between neighbouring best-class logits near that rank, so rounding noise cannot
+         move an anchor across it.
+    Returns SyntheticParams (its state_dict() loads strictly into oracle.yolo11.YOLO11).  TEST INFRASTRUCTURE: uses the oracle."""
+    import math
+    from circuitvision_amd._lib import F32
+    from circuitvision_amd.yolo11 import SyntheticParams, Yolo11Weights
+    from oracle.yolo11 import YOLO11
+    params = SyntheticParams(seed=seed, nc=nc)
+    Yolo11Weights(scale, nc, params, F32, device="cpu")           # walks the graph: fills params.sd with every tensor
+    m = YOLO11(scale, nc).eval()
+    m.load_state_dict(params.state_dict(), strict=True)
+    bns = [mod for mod in m.modules() if isinstance(mod, torch.nn.BatchNorm2d)]
+    for bn in bns:
+        bn.reset_running_stats()
+        bn.momentum = None                                        # cumulative average: after one pass, running stats = batch stats
+        bn.train()
+    with torch.no_grad():
+        m(x)
+    m.eval()
+    for k, v in m.state_dict().items():
+        if k.endswith("running_mean") or k.endswith("running_var"):
+            params.sd[k].copy_(v)
+    with torch.no_grad():
+        _, raw, _ = m(x, return_feats=True)
+    B = x.shape[0]
+    thr = math.log(conf / (1 - conf))
+    for i, r in enumerate(raw):
+        w, b = params.sd[f"model.23.cv3.{i}.2.weight"], params.sd[f"model.23.cv3.{i}.2.bias"]
+        z = r[:, 64:] - b.view(1, -1, 1, 1)                      # W u  (no bias)
+        g = spread / float(z.std())
+        w.mul_(g)
+        b.copy_(b - b.mean())                                     # keep the per-class offsets (class variety), drop the -6 mean
+        best = (z * g + b.view(1, -1, 1, 1)).amax(1).flatten().sort(descending=True).values
+        k = max(2, min(int(round(cand_per_image * B / 3)), best.numel() // 3))
+        lo, hi = max(1, k // 2), min(best.numel() - 1, 2 * k + 1)
+        gaps = best[lo - 1:hi - 1] - best[lo:hi]                 # gap between rank j-1 and j for j in [lo, hi)
+        j = lo + int(gaps.argmax())
+        assert float(gaps.max()) > 2e-3, "degenerate logits: no usable gap for the confidence threshold"
+        b.add_(thr - float(best[j - 1] + best[j]) / 2)
+    return params

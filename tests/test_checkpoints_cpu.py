@@ -69,3 +69,42 @@ def test_restricted_unpickler_does_not_execute_payloads(tmp_path):
     with pytest.raises(Exception):
         load_ultralytics_pt(path)
     assert not os.path.exists("/tmp/cvmi_pwned")
+
+
+def _payload_file(tmp_path, name, reduce_fn, args):
+    """A zip checkpoint whose 'model' entry pickles as `reduce_fn(*args)` (GLOBAL + REDUCE), written with the stock pickler."""
+    class Payload:
+        def __reduce__(self):
+            return (reduce_fn, args)
+    path = str(tmp_path / name)
+    torch.save({"model": Payload()}, path)
+    return path
+
+
+def test_allow_list_blocks_submodule_gadgets(tmp_path):
+    """prefix allow-lists let `numpy.testing._private.utils.runstring` (exec) and
+    `torch.storage._load_from_bytes` (nested unrestricted torch.load) through.  Both must now resolve to inert stubs."""
+    import io
+    from numpy.testing._private.utils import runstring
+    from circuitvision_amd.checkpoints import RestrictedUnpickler, _Stub
+    marker = "/tmp/cvmi_pwned2"
+    for fn, args in ((runstring, (f"open('{marker}','w').write('x')", {})),
+                     (torch.storage._load_from_bytes, (b"not a checkpoint",)),
+                     (eval, (f"open('{marker}','w').write('x')",)),
+                     (getattr, ("abc", "upper"))):
+        if os.path.exists(marker):
+            os.remove(marker)
+        path = _payload_file(tmp_path, "gadget.pt", fn, args)
+        with pytest.raises(Exception):
+            load_ultralytics_pt(path)               # the stub result holds no module tree -> ValueError, nothing ran
+        assert not os.path.exists(marker), fn
+    for mod, name in (("numpy.testing._private.utils", "runstring"), ("torch.storage", "_load_from_bytes"), ("torch.serialization", "load"),
+                      ("builtins", "eval"), ("builtins", "getattr"), ("os", "system"), ("torch._utils", "_import_dotted_name")):
+        cls = RestrictedUnpickler(io.BytesIO(b"")).find_class(mod, name)
+        assert isinstance(cls, type) and issubclass(cls, _Stub), (mod, name)
+
+
+def test_checkpoint_imgsz_is_returned(tmp_path):
+    path = str(tmp_path / "best.pt")
+    _fake_ultralytics_checkpoint(path)
+    assert load_ultralytics_pt(path)["imgsz"] == 640

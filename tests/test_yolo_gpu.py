@@ -1,6 +1,7 @@
 """GPU parity of the detector path: decode, NMS (bit-exact), letterbox (bit-exact), whole YOLO11
 forward vs the CPU fp32 oracle, and the `YOLO.predict` boundary."""
 import ctypes as C
+import math
 
 import numpy as np
 import pytest
@@ -14,7 +15,8 @@ from circuitvision_amd.yolo11 import SyntheticParams, Yolo11Plan, Yolo11Weights
 from oracle import nms as onms
 from oracle import preprocess as opre
 from oracle.yolo11 import YOLO11
-from synth import circuit_image, nms_stress_pred
+from helpers import assert_rel
+from synth import calibrated_yolo_params, circuit_image, nms_stress_pred
 
 pytestmark = pytest.mark.gpu
 
@@ -132,14 +134,60 @@ def _oracle_from(params, scale, nc):
     return m
 
 
-@pytest.mark.parametrize("dtype,scale", [(F32, "n"), (F16, "n"), (F32, "l")])
-def test_yolo11_forward_matches_oracle(dtype, scale):
-    nc, B, H, W = 62, 2, 96, 160
-    params = SyntheticParams(seed=3, nc=nc)
+def _test_images(B, H, W, dtype, seed=0):
+    """Letterboxed circuit drawings as the network sees them: [B,3,H,W] in [0,1], rounded to the storage dtype."""
+    imgs = np.stack([circuit_image(H, W, seed=900 + seed * 50 + i) for i in range(B)])
+    x = torch.from_numpy(imgs[..., ::-1].copy()).permute(0, 3, 1, 2).float().div(255)
+    return x.to(TORCH_DTYPE[dtype]).float()
+
+
+def _match_detections(name, plan, ref_det, ref_idx, exact):
+    """GPU detections (plan.det / det_idx / det_count) vs the oracle's NMS on the ORACLE's predictions.
+    exact (f32 mode): same kept anchor indices in the same order, same classes, conf within 1e-3, boxes within 0.05 px.
+    otherwise (f16): report the identical-box rate |common anchors| / |union| (>= 0.8 required); on the common ones the class
+    is the same, conf within 3e-2 and boxes within 1.5 px."""
+    cnt = plan.det_count.cpu()
+    tot_i = tot_u = 0
+    for b in range(len(ref_det)):
+        n = int(cnt[b])
+        g_idx, g = plan.det_idx[b, :n].cpu().long(), plan.det[b, :n].cpu()
+        r_idx, r = ref_idx[b], ref_det[b]
+        if exact:
+            assert g_idx.tolist() == r_idx.tolist(), (name, b, g_idx.tolist(), r_idx.tolist())
+            assert g[:, 5].tolist() == r[:, 5].tolist(), (name, b)
+            torch.testing.assert_close(g[:, 4], r[:, 4], rtol=0, atol=1e-3)
+            torch.testing.assert_close(g[:, :4], r[:, :4], rtol=0, atol=5e-2)
+            continue
+        gm = {int(a): i for i, a in enumerate(g_idx)}
+        rm = {int(a): i for i, a in enumerate(r_idx)}
+        common = sorted(set(gm) & set(rm))
+        tot_i += len(common); tot_u += len(set(gm) | set(rm))
+        gi, ri = [gm[a] for a in common], [rm[a] for a in common]
+        assert g[gi, 5].tolist() == r[ri, 5].tolist(), (name, b)
+        torch.testing.assert_close(g[gi, 4], r[ri, 4], rtol=0, atol=3e-2)
+        torch.testing.assert_close(g[gi, :4], r[ri, :4], rtol=0, atol=1.5)
+    if not exact:
+        rate = tot_i / max(tot_u, 1)
+        print(f"{name}: identical-box rate {tot_i}/{tot_u} = {rate:.3f}")
+        assert rate >= 0.8, (name, rate)
+
+
+# (dtype, scale, B, H, W): the small shape for every (mode, scale) incl. YOLO11-l in fp16 (configs[3]'s detector), and the
+# BASELINE 640 x 640 input for YOLO11-n in both modes
+WHOLE_MODEL_CASES = [(F32, "n", 2, 96, 160), (F16, "n", 2, 96, 160), (F32, "l", 2, 96, 160), (F16, "l", 2, 96, 160),
+                     (F32, "n", 2, 640, 640), (F16, "n", 2, 640, 640)]
+
+
+@pytest.mark.parametrize("dtype,scale,B,H,W", WHOLE_MODEL_CASES)
+def test_yolo11_forward_matches_oracle(dtype, scale, B, H, W):
+    """Whole network + decode + NMS vs the CPU fp32 oracle on calibrated synthetic weights (activations O(1) in every layer,
+    30-50 detections per image).  Tolerances: f32 mode 1e-3 absolute on neck features, RAW head logits (std 2) and class scores
+    -- the north_star bound; fp16 mode relative to each tensor's standard deviation (max 8 %, rms 1.5 %)."""
+    nc = 62
+    x = _test_images(B, H, W, dtype)
+    params = calibrated_yolo_params(scale, nc, 3, x)
     wt = Yolo11Weights(scale, nc, params, dtype)
     oracle = _oracle_from(params, scale, nc)
-    g = torch.Generator().manual_seed(0)
-    x = torch.rand(B, 3, H, W, generator=g).to(TORCH_DTYPE[dtype]).float()
     with torch.no_grad():
         ref, raw, feats = oracle(x, return_feats=True)
     plan = Yolo11Plan(wt, B, H, W, torch.cuda.Stream())
@@ -148,54 +196,145 @@ def test_yolo11_forward_matches_oracle(dtype, scale):
     plan.plan.run_eager()
     torch.cuda.synchronize()
     got = plan.pred.cpu()
-    # neck features first (localises a failure), then the decoded predictions
+    tag = f"yolo11{scale}-{'f32' if dtype == F32 else 'f16'}-{H}x{W}"
+    mx, rm = (1e-3, 2e-4) if dtype == F32 else (8e-2, 1.5e-2)
+    # neck features first (localises a failure), then the raw head outputs, then the decoded predictions
     for name, v, r in zip(("h16", "h19", "h22"), plan.feats, feats):
-        gv = v.tensor().float().permute(0, 3, 1, 2).cpu()
-        tol = dict(rtol=1e-3, atol=1e-3) if dtype == F32 else dict(rtol=5e-2, atol=5e-2)
-        torch.testing.assert_close(gv, r, **tol, msg=lambda m: f"{name}: {m}")
+        assert_rel(f"{tag} {name}", v.tensor().float().permute(0, 3, 1, 2).cpu(), r, mx, rm, absolute=dtype == F32)
+    for i, (bx, cl, r) in enumerate(zip(plan.box_bufs, plan.cls_bufs, raw)):
+        gb = bx.tensor().float().permute(0, 3, 1, 2).cpu()
+        gc = cl.t[..., :nc].float().permute(0, 3, 1, 2).cpu()
+        for what, g_, r_ in (("dfl-logits", gb, r[:, :64]), ("class-logits", gc, r[:, 64:])):
+            assert_rel(f"{tag} level{i} {what}", g_, r_, mx, rm, absolute=dtype == F32)
+    assert float(ref[:, 4:].amax(1).max()) > 0.9 and float((ref[:, 4:].amax(1) > 0.25).float().mean()) < 0.2      # the head is alive, and selective
     if dtype == F32:
-        # north_star tolerance: 1e-3 on logits/scores; boxes in pixels
-        torch.testing.assert_close(got[:, 4:], ref[:, 4:], rtol=0, atol=1e-3)
-        torch.testing.assert_close(got[:, :4], ref[:, :4], rtol=1e-4, atol=1e-2)
+        torch.testing.assert_close(got[:, 4:], ref[:, 4:], rtol=0, atol=1e-3)          # north_star: 1e-3 on scores
+        torch.testing.assert_close(got[:, :4], ref[:, :4], rtol=1e-4, atol=2e-2)       # boxes in pixels
     else:
-        torch.testing.assert_close(got[:, 4:], ref[:, 4:], rtol=0, atol=2e-2)
-        torch.testing.assert_close(got[:, :4], ref[:, :4], rtol=2e-2, atol=1.0)
-    # the GPU NMS on the GPU predictions == the oracle NMS on the same tensor (bit-exact)
+        torch.testing.assert_close(got[:, 4:], ref[:, 4:], rtol=0, atol=3e-2)
+        torch.testing.assert_close(got[:, :4], ref[:, :4], rtol=2e-2, atol=1.5)
+    # the GPU NMS on the GPU predictions == the oracle NMS on the same tensor (bit-exact, both modes) ...
     ref_det, ref_idx = onms.yolo_nms(got, 0.25, 0.7, 300, return_indices=True)
     cnt = plan.det_count.cpu()
     for b in range(B):
         n = int(cnt[b])
-        assert n == ref_det[b].shape[0]
+        assert n == ref_det[b].shape[0] and n >= 10, (tag, b, n)
         assert torch.equal(plan.det_idx[b, :n].cpu().long(), ref_idx[b])
         assert torch.equal(plan.det[b, :n].cpu(), ref_det[b])
+    # ... and against the oracle end to end (oracle network -> oracle NMS): identical integer anchor indices in f32
+    o_det, o_idx = onms.yolo_nms(ref, 0.25, 0.7, 300, return_indices=True)
+    _match_detections(tag, plan, o_det, o_idx, exact=dtype == F32)
 
 
-def test_predict_boundary_matches_oracle_pipeline():
-    """`YOLO(path).predict(img)[0].boxes` as circuit_analyzer.py:268-287 consumes it, f32 mode,
-    vs oracle letterbox -> oracle network -> oracle NMS -> scale_boxes -> round -> stage-2 NMS."""
-    from circuitvision_amd.detector import non_max_suppression_by_confidence
-    det = YOLO("synthetic:n:62:3", dtype="f32")
-    oracle = _oracle_from(det.params, "n", 62)
-    img = circuit_image(360, 500, seed=7)
-    r = det.predict(img, verbose=False)[0]
+def _boundary_case(tmp_path, dtype, img, seed=3, scale="n", nc=62):
+    """A calibrated synthetic checkpoint on disk -> `YOLO(path)` (the reference's constructor call) + the matching oracle."""
+    from helpers import save_converted_yolo
+    x = torch.from_numpy(opre.yolo_preprocess(img))
+    params = calibrated_yolo_params(scale, nc, seed, x)
+    path = save_converted_yolo(str(tmp_path / f"yolo11{scale}.pt"), params, scale, nc)
+    return YOLO(path, dtype=dtype), _oracle_from(params, scale, nc), x
+
+
+def _reference_glue(r):
+    """circuit_analyzer.py:268-287: tensors -> lists -> dicts with python round() and the persistent uid."""
     cls = r.boxes.cls.cpu().numpy().tolist()
     conf = r.boxes.conf.cpu().numpy().tolist()
     xyxy = r.boxes.xyxy.cpu().numpy().tolist()
+    return cls, conf, xyxy, onms.boxes_to_dicts(xyxy, conf, cls, r.names)
+
+
+@pytest.mark.parametrize("hw", [(360, 500), (500, 360)])
+def test_predict_boundary_matches_oracle_pipeline(tmp_path, hw):
+    """`YOLO(path).predict(img)[0].boxes` as circuit_analyzer.py:268-287 consumes it, f32 mode, vs oracle letterbox -> oracle
+    network -> oracle NMS -> scale_boxes -> round -> stage-2 NMS (analysis_pipeline.py:106), on >= 20 detections: landscape
+    (vertical letterbox padding) and portrait (horizontal padding) so both pad terms of scale_boxes are exercised."""
+    from circuitvision_amd.detector import non_max_suppression_by_confidence
+    img = circuit_image(*hw, seed=7)
+    det, oracle, x = _boundary_case(tmp_path, "f32", img)
+    r = det.predict(img, verbose=False)[0]
+    cls, conf, xyxy, got_d = _reference_glue(r)
     assert all(conf[i] >= conf[i + 1] for i in range(len(conf) - 1))
-    x = torch.from_numpy(opre.yolo_preprocess(img))
     with torch.no_grad():
         pred = oracle(x)
-    ref = onms.yolo_nms(pred, 0.25, 0.7, 300)[0]
+    ref, ref_idx = onms.yolo_nms(pred, 0.25, 0.7, 300, return_indices=True)
+    ref, ref_idx = ref[0], ref_idx[0]
+    unscaled = ref[:, :4].clone()
     ref[:, :4] = onms.scale_boxes(x.shape[2:], ref[:, :4], img.shape[:2])
-    assert len(cls) == ref.shape[0]
+    assert ref.shape[0] >= 20, ref.shape                                          # the comparison below is not about empty lists
+    assert float((ref[:, :4] - unscaled).abs().max()) > 5.0                        # scale_boxes does move these boxes
+    assert r.anchor_idx.cpu().tolist() == ref_idx.tolist()                         # identical integer anchor indices
     assert cls == ref[:, 5].tolist()
     np.testing.assert_allclose(conf, ref[:, 4].numpy(), atol=1e-3)
     np.testing.assert_allclose(np.asarray(xyxy).reshape(-1, 4), ref[:, :4].numpy().reshape(-1, 4), atol=0.05)
-    got_d = onms.boxes_to_dicts(xyxy, conf, cls, r.names)
+    assert np.asarray(xyxy).min() >= 0 and np.asarray(xyxy)[:, [0, 2]].max() <= hw[1] and np.asarray(xyxy)[:, [1, 3]].max() <= hw[0]   # clip_boxes
     ref_d = onms.boxes_to_dicts(ref[:, :4].tolist(), ref[:, 4].tolist(), ref[:, 5].tolist(), r.names)
-    a = [b["persistent_uid"] for b in non_max_suppression_by_confidence(got_d, 0.6)]
+    # round(): a coordinate within 0.05 px of a .5 boundary may round differently; everything else must agree exactly
+    for g_, r_, rb in zip(got_d, ref_d, ref[:, :4].tolist()):
+        for key, v in zip(("xmin", "ymin", "xmax", "ymax"), rb):
+            assert g_[key] == r_[key] or abs(abs(v - math.floor(v)) - 0.5) < 0.05, (key, g_[key], r_[key], v)
+    a = [b["persistent_uid"] for b in non_max_suppression_by_confidence(ref_d, 0.6)]
     b = [b["persistent_uid"] for b in onms.nms_by_confidence(ref_d, 0.6)]
-    assert a == b
+    assert a == b and 0 < len(a) < len(ref_d)                                       # stage 2 does suppress some of them
+    if all(g_["persistent_uid"] == r_["persistent_uid"] for g_, r_ in zip(got_d, ref_d)):
+        assert [b["persistent_uid"] for b in non_max_suppression_by_confidence(got_d, 0.6)] == b
+
+
+def test_predict_boundary_f16_identical_box_rate(tmp_path):
+    """Same boundary in fp16 storage mode: the identical-box rate against the fp32 oracle is REPORTED and must stay >= 0.8;
+    the common boxes agree to 1.5 px / 3e-2 confidence with the same class."""
+    img = circuit_image(360, 500, seed=7)
+    det, oracle, x = _boundary_case(tmp_path, "f16", img)
+    r = det.predict(img, verbose=False)[0]
+    with torch.no_grad():
+        ref, ref_idx = onms.yolo_nms(oracle(x), 0.25, 0.7, 300, return_indices=True)
+    ref, ref_idx = ref[0], ref_idx[0]
+    ref[:, :4] = onms.scale_boxes(x.shape[2:], ref[:, :4], img.shape[:2])
+    gm = {int(a): i for i, a in enumerate(r.anchor_idx.cpu())}
+    rm = {int(a): i for i, a in enumerate(ref_idx)}
+    common = sorted(set(gm) & set(rm))
+    rate = len(common) / len(set(gm) | set(rm))
+    print(f"predict f16: {len(r)} boxes vs {ref.shape[0]} oracle boxes, identical-box rate {rate:.3f}")
+    assert ref.shape[0] >= 20 and rate >= 0.8
+    g = r.boxes.data.cpu()
+    gi, ri = [gm[a] for a in common], [rm[a] for a in common]
+    assert g[gi, 5].tolist() == ref[ri, 5].tolist()
+    torch.testing.assert_close(g[gi, 4], ref[ri, 4], rtol=0, atol=3e-2)
+    torch.testing.assert_close(g[gi, :4], ref[ri, :4], rtol=0, atol=1.5)
+
+
+def test_predict_honours_checkpoint_imgsz_and_large_inputs(tmp_path):
+    """ultralytics' predict() inherits train_args['imgsz'] from the checkpoint; a model trained at 1024 must letterbox
+    to 1024 (A = 21504 anchors: the NMS keeps its sort keys in the workspace beyond 16384), and predict(imgsz=...) overrides it."""
+    from helpers import save_converted_yolo
+    img = circuit_image(700, 1000, seed=11)
+    x = torch.from_numpy(opre.yolo_preprocess(img, 1024))
+    assert x.shape[2:] == (736, 1024)
+    params = calibrated_yolo_params("n", 62, 5, x)
+    path = save_converted_yolo(str(tmp_path / "y1024.pt"), params, "n", 62, imgsz=1024)
+    det = YOLO(path, dtype="f32")
+    assert det.imgsz == 1024
+    r = det.predict(img, verbose=False)[0]
+    oracle = _oracle_from(params, "n", 62)
+    with torch.no_grad():
+        ref, ref_idx = onms.yolo_nms(oracle(x), 0.25, 0.7, 300, return_indices=True)
+    assert ref[0].shape[0] >= 20 and r.anchor_idx.cpu().tolist() == ref_idx[0].tolist()
+    r640 = det.predict(img, verbose=False, imgsz=640)[0]
+    assert next(k for k in det._plans if k[1:3] == (448, 640))
+    assert len(r640) != len(r) or not torch.equal(r640.boxes.data, r.boxes.data)
+    with pytest.raises(ValueError):
+        YOLO(path, dtype="f32", imgsz=4096)
+
+
+def test_nms_beyond_lds_capacity_bit_exact():
+    """A > 16384 anchors (imgsz 1024 -> 21504): keys sorted in the workspace instead of LDS; same bit-exact contract."""
+    pred = nms_stress_pred(2, 12, (1024, 1024), seed=6)
+    assert pred.shape[2] == 21504
+    ref, ref_idx = onms.yolo_nms(pred, 0.25, 0.7, 300, return_indices=True)
+    det, idx, cnt = _gpu_nms(pred)
+    for b in range(2):
+        n = int(cnt[b])
+        assert n == ref[b].shape[0] and n > 0
+        assert torch.equal(idx[b, :n].long(), ref_idx[b]) and torch.equal(det[b, :n], ref[b])
 
 
 @pytest.mark.parametrize("hw", [(96, 160), (160, 224)])
