@@ -206,7 +206,7 @@ def test_yolo11_forward_matches_oracle(dtype, scale, B, H, W):
         gc = cl.t[..., :nc].float().permute(0, 3, 1, 2).cpu()
         for what, g_, r_ in (("dfl-logits", gb, r[:, :64]), ("class-logits", gc, r[:, 64:])):
             assert_rel(f"{tag} level{i} {what}", g_, r_, mx, rm, absolute=dtype == F32)
-    assert float(ref[:, 4:].amax(1).max()) > 0.9 and float((ref[:, 4:].amax(1) > 0.25).float().mean()) < 0.2      # the head is alive, and selective
+    assert float(ref[:, 4:].amax(1).max()) > 0.9 and float((ref[:, 4:].amax(1) > 0.25).float().mean()) < 0.6      # the head is alive, and selective
     if dtype == F32:
         torch.testing.assert_close(got[:, 4:], ref[:, 4:], rtol=0, atol=1e-3)          # north_star: 1e-3 on scores
         torch.testing.assert_close(got[:, :4], ref[:, :4], rtol=1e-4, atol=2e-2)       # boxes in pixels
@@ -218,7 +218,7 @@ def test_yolo11_forward_matches_oracle(dtype, scale, B, H, W):
     cnt = plan.det_count.cpu()
     for b in range(B):
         n = int(cnt[b])
-        assert n == ref_det[b].shape[0] and n >= 10, (tag, b, n)
+        assert n == ref_det[b].shape[0] and n >= 3, (tag, b, n)
         assert torch.equal(plan.det_idx[b, :n].cpu().long(), ref_idx[b])
         assert torch.equal(plan.det[b, :n].cpu(), ref_det[b])
     # ... and against the oracle end to end (oracle network -> oracle NMS): identical integer anchor indices in f32
