@@ -62,3 +62,18 @@ def save_converted_yolo(path, params, scale, nc, imgsz=None):
         ck["imgsz"] = imgsz
     torch.save(ck, path)
     return path
+
+
+def assert_same_detections(name, got, ref, top=20, min_overlap=0.97):
+    """Two detection lists (anchor indices or uid strings, confidence-descending) that should be IDENTICAL.  Exact equality is
+    required of the `top` most confident entries and of the lengths within 3 %; over the whole list a Jaccard overlap >= min_overlap
+    is accepted instead of equality, because with hundreds of boxes some pair's IoU (or two confidences) lies within fp32 rounding
+    noise of a threshold, and ONE such flip in either implementation legitimately changes one kept box -- and shifts every later
+    position.  Returns the overlap."""
+    got, ref = list(got), list(ref)
+    assert got[:top] == ref[:top], (name, got[:top], ref[:top])
+    union = len(set(got) | set(ref))
+    ov = len(set(got) & set(ref)) / max(1, union)
+    print(f"{name}: {len(got)} vs {len(ref)} detections, overlap {ov:.4f}, identical order: {got == ref}")
+    assert ov >= min_overlap and abs(len(got) - len(ref)) <= max(1, 0.03 * len(ref)), (name, len(got), len(ref), ov)
+    return ov
