@@ -1,0 +1,196 @@
+// Fused MLP half of a Hiera block:   x <- x + fc2( GELU( fc1( LayerNorm(x) ) ) )   in place on the f32 residual stream
+// (sam2 hieradet MultiScaleBlock.forward: `x = x + self.drop_path(self.mlp(self.norm2(x)))`, behind
+//  /root/reference/src/sam2_infer.py:226 `self.sam2_model.image_encoder(images)`).
+//
+// Why one kernel: unfused, the 4C-wide hidden activation is written and re-read (fp16), the normalised copy is written and
+// re-read, and the stream is read three times -- 4.8 GB per stage-1 block at B = 16 against 1.2 GB for "read x, write x".
+//
+// Token-stationary formulation on 32x32x16 MFMA, weights as the A operand, nothing crosses lanes:
+//   * a wave owns 32 tokens (token = MFMA column = lane & 31).  LayerNorm runs on the lane's half row in registers and leaves
+//     the normalised row as the B fragments of fc1 (K = C, fp16), resident for the whole kernel;
+//   * the hidden dimension is walked in chunks of 32 units:  H^T[32 hidden][32 tokens] = W1_chunk . Xn^T  (C/16 MFMAs + one
+//     extra k-step that carries the fc1 bias as a (hi + lo) fp16 pair against constant-1 columns of Xn);
+//   * GELU is applied to the accumulator, which converted to fp16 IS the B operand of fc2 (the MFMA C/D layout has the token on
+//     the lane and the hidden unit in the register: "accumulator tile as the next MFMA's operand"):
+//                        Y^T[C][32 tokens] += W2^T_chunk[C][32 hidden] . H^T          (2 * ceil(C/32) MFMAs)
+//     with W2's fragment packed in the permuted k order that layout implies (include/cvmi355.h, cvmi_hiera_mlp);
+//   * the weight chunks (both matrices, fragment order, 1 KiB per MFMA operand) stream L2 -> LDS by global_load_lds into a
+//     two-slot ring, one barrier per chunk; every ds_read_b128 is lane-linear (conflict-free);
+//   * epilogue: + fc2 bias + the old x, 16-byte f32 stores.
+// C = 144 (stage 1): 8 waves / workgroup, two waves per SIMD (the GELU VALU of one overlaps the MFMAs of the other).
+// C = 288 (stage 2): the Y^T accumulator (144 registers) + Xn (76) leave room for one wave per SIMD only: 4 waves.
+#include "common.hpp"
+
+namespace {
+
+template <int C> struct MlpCfg {
+  static constexpr int KS = C / 16;                 // k-steps of fc1
+  static constexpr int KS1 = KS + 1;                // + the bias step
+  static constexpr int NT = (C + 31) / 32;          // 32-channel output tiles of fc2
+  static constexpr int NCH = 4 * C / 32;            // hidden chunks
+  static constexpr int FR = KS1 + 2 * NT;           // 1 KiB fragments per chunk
+  static constexpr int CHB = FR * 1024;             // bytes per chunk
+  static constexpr int NW = C <= 144 ? 8 : 4;       // waves per workgroup
+  static constexpr int WPS = C <= 144 ? 2 : 1;      // waves per SIMD the register budget is set for
+  static constexpr int LDS = 2 * CHB;
+};
+
+template <int C>
+__global__ __launch_bounds__(MlpCfg<C>::NW * 64, MlpCfg<C>::WPS) void hiera_mlp_kernel(float* __restrict__ x, int x_ld, const float* __restrict__ gamma,
+                                                                                      const float* __restrict__ beta, float eps,
+                                                                                      const char* __restrict__ wp, const float* __restrict__ b2,
+                                                                                      long long rows) {
+  using Cfg = MlpCfg<C>;
+  constexpr int KS = Cfg::KS, KS1 = Cfg::KS1, NT = Cfg::NT, NCH = Cfg::NCH, FR = Cfg::FR, CHB = Cfg::CHB, NW = Cfg::NW;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int lr = lane & 31, lh = lane >> 5;
+  const long long row_raw = ((long long)blockIdx.x * NW + wv) * 32 + lr;
+  const bool row_ok = row_raw < rows;
+  float* const xr = x + (row_ok ? row_raw : rows - 1) * (long long)x_ld;
+
+  // ---- weight stream: chunk j -> ring slot j & 1; wave w moves fragments w, w + NW, ...
+  auto issue_chunk = [&](int j) {
+    const char* src = wp + (size_t)j * CHB + lane * 16;
+    char* dst = smem + (j & 1) * CHB;
+#pragma unroll
+    for (int f = 0; f < (FR + NW - 1) / NW; ++f) {
+      const int fi = f * NW + wv;
+      if (fi < FR)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)fi * 1024),
+                                         (__attribute__((address_space(3))) void*)(dst + fi * 1024), 16, 0, 0);
+    }
+  };
+  issue_chunk(0);
+
+  // ---- LayerNorm of this lane's half row -> B fragments of fc1 (lane (token lr, half lh) holds channels 16 s + 8 lh .. + 7)
+  u32x4 xn[KS1];
+  {
+    float v[KS][8];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < KS; ++k) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(xr + 16 * k + 8 * lh), b = *reinterpret_cast<const f32x4*>(xr + 16 * k + 8 * lh + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { v[k][e] = a[e]; v[k][4 + e] = b[e]; s += a[e] + b[e]; }
+    }
+    s += __shfl_xor(s, 32);
+    const float mean = s / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < KS; ++k)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const float d = v[k][e] - mean; q += d * d; }
+    q += __shfl_xor(q, 32);
+    const float rstd = 1.0f / sqrtf(q / (float)C + eps);
+#pragma unroll
+    for (int k = 0; k < KS; ++k) {
+      const float* gp = gamma + 16 * k + 8 * lh;
+      const float* bp = beta + 16 * k + 8 * lh;
+      const f32x4 g0 = *reinterpret_cast<const f32x4*>(gp), g1 = *reinterpret_cast<const f32x4*>(gp + 4);
+      const f32x4 b0 = *reinterpret_cast<const f32x4*>(bp), b1 = *reinterpret_cast<const f32x4*>(bp + 4);
+      f16x8 h;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        h[e] = (f16)((v[k][e] - mean) * rstd * g0[e] + b0[e]);
+        h[4 + e] = (f16)((v[k][4 + e] - mean) * rstd * g1[e] + b1[e]);
+      }
+      xn[k] = __builtin_bit_cast(u32x4, h);
+    }
+    // bias step: k = C and C + 1 are constant-1 columns (lanes of half 0 hold k = C .. C + 7)
+    const u32x4 one = {lh == 0 ? 0x3C003C00u : 0u, 0u, 0u, 0u};
+    xn[KS] = one;
+  }
+
+  f32x16 yacc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) yacc[t][r] = 0.f;
+
+#pragma unroll 1
+  for (int j = 0; j < NCH; ++j) {
+    __syncthreads();                       // (vmcnt(0) +) barrier: chunk j has landed; slot (j + 1) & 1 is no longer being read
+    if (j + 1 < NCH) issue_chunk(j + 1);
+    const char* const buf = smem + (j & 1) * CHB + lane * 16;
+    // The chunk's FR operand fragments are consumed in one fixed order (fc1's KS1, then fc2's 2 NT); a ring of PF registers
+    // keeps PF ds_read_b128 in flight ahead of the MFMA that consumes them -- across the GELU as well, so that fc2's first
+    // operands arrive while the VALU works.  (Left to itself hipcc emits read -> lgkmcnt(0) -> MFMA per step.)
+    constexpr int PF = 6;
+    u32x4 ring[PF];
+#pragma unroll
+    for (int f = 0; f < PF; ++f) ring[f] = *reinterpret_cast<const u32x4*>(buf + f * 1024);
+    f32x16 hacc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) hacc[r] = 0.f;
+    f16x8 pf[2];
+#pragma unroll
+    for (int f = 0; f < FR; ++f) {
+      const f16x8 a = __builtin_bit_cast(f16x8, ring[f % PF]);
+      if (f + PF < FR) ring[f % PF] = *reinterpret_cast<const u32x4*>(buf + (f + PF) * 1024);
+      if (f < KS1) {
+        hacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, __builtin_bit_cast(f16x8, xn[f]), hacc, 0, 0, 0);
+        if (f == KS1 - 1) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) pf[r >> 3][r & 7] = (f16)gelu_fast(hacc[r]);
+        }
+      } else {
+        const int t = (f - KS1) >> 1, s2 = (f - KS1) & 1;
+        yacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, pf[s2], yacc[t], 0, 0, 0);
+      }
+    }
+  }
+
+  // ---- epilogue: x += y + b2; lane (token lr, half lh) owns channels 32 t + 8 g + 4 lh .. + 3
+  if (row_ok) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int c0 = 32 * t + 8 * g + 4 * lh;
+        if (c0 < C) {
+          const f32x4 bb = *reinterpret_cast<const f32x4*>(b2 + c0);
+          f32x4 o = *reinterpret_cast<const f32x4*>(xr + c0);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] += yacc[t][4 * g + e] + bb[e];
+          *reinterpret_cast<f32x4*>(xr + c0) = o;
+        }
+      }
+  }
+}
+
+template <int C>
+int launch_mlp(float* x, int x_ld, const float* gamma, const float* beta, float eps, const void* wp, const float* b2, long long rows, hipStream_t s) {
+  using Cfg = MlpCfg<C>;
+  static hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&hiera_mlp_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
+  CVMI_HIP(attr);
+  const long long per = (long long)Cfg::NW * 32;
+  hipLaunchKernelGGL((hiera_mlp_kernel<C>), dim3((unsigned)((rows + per - 1) / per)), dim3(Cfg::NW * 64), Cfg::LDS, s, x, x_ld, gamma, beta, eps,
+                     (const char*)wp, b2, rows);
+  CVMI_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace
+
+// C = 576 (stage 3) is not built: its Y^T accumulator alone is 288 registers per lane and, with the 148 of the resident Xn fragments,
+// leaves no room to keep LDS reads in flight (hipcc spills 1.8 KB per lane); stage 3 / 4 stay on the tiled GEMM kernels.
+extern "C" int cvmi_hiera_mlp_supported(int C) { return C == 144 || C == 288; }
+
+extern "C" size_t cvmi_hiera_mlp_packed_bytes(int C) {
+  if (!cvmi_hiera_mlp_supported(C)) return 0;
+  const size_t fr = (size_t)(C / 16 + 1) + 2 * (size_t)((C + 31) / 32);
+  return (size_t)(4 * C / 32) * fr * 1024;
+}
+
+extern "C" int cvmi_hiera_mlp(void* x, int x_ld, const float* gamma, const float* beta, float eps, const void* w_packed, const float* b2,
+                              long long rows, int C, cvmi_stream_t stream_) {
+  CVMI_CHECK(x && gamma && beta && w_packed && b2 && rows > 0, "hiera_mlp: bad arguments");
+  CVMI_CHECK(cvmi_hiera_mlp_supported(C), "hiera_mlp: C=%d is not built (144, 288)", C);
+  CVMI_CHECK(x_ld >= C && x_ld % 4 == 0 && (((uintptr_t)x | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)w_packed | (uintptr_t)b2) & 15) == 0,
+             "hiera_mlp: pointers / ld must be 16-byte aligned");
+  hipStream_t s = (hipStream_t)stream_;
+  float* xf = (float*)x;
+  if (C == 144) return launch_mlp<144>(xf, x_ld, gamma, beta, eps, w_packed, b2, rows, s);
+  return launch_mlp<288>(xf, x_ld, gamma, beta, eps, w_packed, b2, rows, s);
+}

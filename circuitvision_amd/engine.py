@@ -481,3 +481,47 @@ def op_call(plan, label, kind, fn, args, keep=(), bytes_=0, flops=0):
         _lib.check(fn(*args, sp), label)
 
     plan.add(label, kind, thunk, bytes_, flops)
+
+
+# ---- fused Hiera MLP (hiera_mlp.hip) ---------------------------------------------------------------------------------------
+def hiera_mlp_supported(C_, dtype):
+    return dtype == F16 and bool(_lib.load().cvmi_hiera_mlp_supported(C_))
+
+
+class PackedHieraMlp:
+    """fc1 / fc2 of one Hiera block in the MFMA-fragment order cvmi_hiera_mlp streams (include/cvmi355.h)."""
+
+    def __init__(self, w1, b1, w2, b2, device="cuda"):
+        # w1 [4C, C], b1 [4C], w2 [C, 4C], b2 [C]  (float32, LoRA already merged)
+        Hd, C_ = w1.shape
+        assert Hd == 4 * C_ and tuple(w2.shape) == (C_, Hd) and C_ % 16 == 0
+        ks1, nt, nch = C_ // 16 + 1, (C_ + 31) // 32, Hd // 32
+        b_hi = b1.to(torch.float16).float()
+        b_lo = (b1 - b_hi).to(torch.float16).float()
+        w1x = torch.cat((w1, b_hi[:, None], b_lo[:, None], torch.zeros(Hd, 14)), 1)              # [4C, C + 16]
+        f1 = w1x.view(nch, 32, ks1, 2, 8).permute(0, 2, 3, 1, 4)                                   # (j, s, h, r, e)
+        w2p = torch.zeros(nt * 32, Hd)
+        w2p[:C_] = w2
+        f2 = w2p.view(nt, 32, nch, 2, 2, 2, 4).permute(2, 0, 3, 5, 1, 4, 6)                        # (j, t, s2, h, r, e_hi, e_lo)
+        packed = torch.cat((f1.reshape(nch, -1), f2.reshape(nch, -1)), 1).contiguous()
+        assert packed.numel() * 2 == _lib.load().cvmi_hiera_mlp_packed_bytes(C_)
+        self.w = packed.to(torch.float16).to(device)
+        self.bias = b2.float().contiguous().to(device)          # (.w / .bias: what distributed.packed_tensors broadcasts)
+        self.C = C_
+        self.param_bytes = 2 * Hd * C_ * 2
+
+
+def op_hiera_mlp(plan, label, pm, x, gamma, beta, eps=1e-6):
+    """x <- x + fc2(GELU(fc1(LayerNorm(x)))) in place; x: f32 View (full rows)."""
+    lib = _lib.load()
+    assert x.dtype == F32 and x.c == pm.C and x.c0 == 0
+    rows = x.B * x.H * x.W
+    args = (x.ptr, x.ld, gamma.data_ptr(), beta.data_ptr(), float(eps), pm.w.data_ptr(), pm.bias.data_ptr(), rows, pm.C)
+    plan.keep.append((pm, x, gamma, beta))
+    sp0, fn = plan.sptr, lib.cvmi_hiera_mlp
+
+    def thunk(sp=None):
+        sp = sp0 if sp is None else sp
+        _lib.check(fn(*args, sp), label)
+
+    plan.add(label, "mlp_fused", thunk, rows * pm.C * 8, 2 * rows * 2 * 4 * pm.C * pm.C)

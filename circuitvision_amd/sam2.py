@@ -29,8 +29,8 @@ import torch.nn.functional as TF
 
 from . import _lib
 from ._lib import ACT_GELU, ACT_NONE, ACT_RELU, ACT_SIGMOID, F16, F32
-from .engine import (ESIZE, TORCH_DTYPE, Buf, PackedConv, Plan, Rows, make_attn_desc, op_attention, op_call, op_cast, op_conv,
-                     op_layernorm, op_maxpool2, require_gpu)
+from .engine import (ESIZE, TORCH_DTYPE, Buf, PackedConv, PackedHieraMlp, Plan, Rows, hiera_mlp_supported, make_attn_desc, op_attention, op_call,
+                     op_cast, op_conv, op_hiera_mlp, op_layernorm, op_maxpool2, require_gpu)
 
 HIERA_L = dict(embed_dim=144, num_heads=2, stages=(2, 6, 36, 4), global_att_blocks=(23, 33, 43), window_spec=(8, 4, 16, 8))
 HIERA_T = dict(embed_dim=96, num_heads=1, stages=(1, 2, 7, 2), global_att_blocks=(5, 7, 9), window_spec=(8, 4, 14, 7))
@@ -166,7 +166,8 @@ class Sam2Weights:
                  refinement_kernels=(3, 5, 7, 11), embedding_r=4):
         self.p, self.hiera, self.image_size, self.dtype, self.device = params, hiera, image_size, dtype, device
         self.use_refinement, self.kernels = use_refinement, tuple(refinement_kernels)
-        self.pc, self.ln, self.const = {}, {}, {}
+        self.pc, self.ln, self.const, self.mlp = {}, {}, {}, {}
+        self.fused_mlp = os.environ.get("CVMI_SAM_FUSED_MLP", "1") != "0"      # (the switch is for A/B measurements)
         self.param_bytes = 0
         self.flops_per_image = 0
         self._trunk()
@@ -222,8 +223,15 @@ class Sam2Weights:
             self._linear(f"b{i}.qkv", f"{b}.attn.qkv", 3 * dim_out, dim)
             self._linear(f"b{i}.proj", f"{b}.attn.proj", dim_out, dim_out)
             self._norm(f"b{i}.norm2", f"{b}.norm2", dim_out)
-            self._linear(f"b{i}.fc1", f"{b}.mlp.layers.0", 4 * dim_out, dim_out)
-            self._linear(f"b{i}.fc2", f"{b}.mlp.layers.1", dim_out, 4 * dim_out)
+            if self.fused_mlp and hiera_mlp_supported(dim_out, self.dtype):
+                # stages 1 / 2: norm2 + fc1 + GELU + fc2 + residual as ONE launch (hiera_mlp.hip); weights in fragment order
+                self.mlp[f"b{i}"] = PackedHieraMlp(self.p.weight(f"{b}.mlp.layers.0", (4 * dim_out, dim_out)), self.p.bias(f"{b}.mlp.layers.0", 4 * dim_out),
+                                                   self.p.weight(f"{b}.mlp.layers.1", (dim_out, 4 * dim_out)), self.p.bias(f"{b}.mlp.layers.1", dim_out),
+                                                   self.device)
+                self.param_bytes += self.mlp[f"b{i}"].param_bytes
+            else:
+                self._linear(f"b{i}.fc1", f"{b}.mlp.layers.0", 4 * dim_out, dim_out)
+                self._linear(f"b{i}.fc2", f"{b}.mlp.layers.1", dim_out, 4 * dim_out)
             if dim != dim_out:
                 self._linear(f"b{i}.dimproj", f"{b}.proj", dim_out, dim)
             self.blocks.append(dict(dim=dim, dim_out=dim_out, heads=heads, window=window, q_pool=i in q_pool_blocks))
@@ -485,11 +493,14 @@ class Sam2Plan:
         self.gemm(f"b{i}.proj", f"b{i}.proj", ao.view(), short.view(), res=short.view(), out_hw=(OH, OW) if padded else None)
         x = short
         gam, bet = wt.ln[f"b{i}.norm2"]
-        xn2 = self.buf(OH, OW, dout, tag="xn")
-        op_layernorm(self.plan, f"b{i}.norm2", x.view(), gam, bet, xn2.view(), 1e-6)
-        hid = self.buf(OH, OW, 4 * dout, tag="hid")
-        self.gemm(f"b{i}.fc1", f"b{i}.fc1", xn2.view(), hid.view(), act=ACT_GELU)
-        self.gemm(f"b{i}.fc2", f"b{i}.fc2", hid.view(), x.view(), res=x.view())
+        if f"b{i}" in wt.mlp:
+            op_hiera_mlp(self.plan, f"b{i}.mlp", wt.mlp[f"b{i}"], x.view(), gam, bet, 1e-6)
+        else:
+            xn2 = self.buf(OH, OW, dout, tag="xn")
+            op_layernorm(self.plan, f"b{i}.norm2", x.view(), gam, bet, xn2.view(), 1e-6)
+            hid = self.buf(OH, OW, 4 * dout, tag="hid")
+            self.gemm(f"b{i}.fc1", f"b{i}.fc1", xn2.view(), hid.view(), act=ACT_GELU)
+            self.gemm(f"b{i}.fc2", f"b{i}.fc2", hid.view(), x.view(), res=x.view())
         if i in self.wt.stage_ends and i != len(self.wt.blocks) - 1:
             # the next block writes its own shortcut buffer (dim change) -> x stays intact as the stage output
             pass

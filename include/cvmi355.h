@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define CVMI_VERSION 106
+#define CVMI_VERSION 107
 
 typedef void* cvmi_stream_t; /* hipStream_t */
 
@@ -218,6 +218,23 @@ int cvmi_layernorm(const void* x, int x_ld, int x_dtype, const float* gamma, con
  * reads: saves a cast pass over the stream; SAM 2 two-way transformer norm4, sam2_infer.py:252). */
 int cvmi_layernorm_dual(const void* x, int x_ld, const float* gamma, const float* beta, void* y, int y_ld, void* y2, int y2_ld,
                         long long rows, int C, float eps, cvmi_stream_t stream);
+
+/* Fused MLP half of a Hiera block, in place on the f32 residual stream (sam2 hieradet MultiScaleBlock: `x = x + mlp(norm2(x))`,
+ * behind sam2_infer.py:226):   x[r, :] += fc2( GELU( fc1( LayerNorm(x[r, :]; gamma, beta, eps) ) ) )   for r < rows, hidden = 4 C,
+ * fp16 operands / fp32 accumulation; the normalised copy and the hidden activation never reach HBM.  C in {144, 288} are built
+ * (cvmi_hiera_mlp_supported); stages with wider rows keep the separate LayerNorm + two cvmi_conv2d launches.
+ * w_packed: both weight matrices in MFMA-fragment order, hidden chunk by hidden chunk (32 hidden units each), every fragment 64 lanes
+ * x 8 fp16 = 1 KiB (lane l: r = l & 31, h = l >> 5):
+ *   chunk j = [ F1(j, s) for s = 0 .. C/16 ]  ++  [ F2(j, t, s2) for t = 0 .. ceil(C/32) - 1, s2 = 0, 1 ]
+ *   F1(j, s)[l][e]     = W1x[32 j + r][16 s + 8 h + e],  W1x = [ fc1.weight | fp16(b1) | fp16(b1 - fp16(b1)) | 0 ... ] (C + 16 columns:
+ *                        the fc1 bias rides on two constant-1 input columns as a hi + lo fp16 pair)
+ *   F2(j, t, s2)[l][e] = fc2.weight[32 t + r][32 j + 16 s2 + 8 (e >> 2) + 4 h + (e & 3)]   (0 for output rows >= C): the k order in
+ *                        which a 32x32 MFMA accumulator, converted in place, serves as the next MFMA's B operand.
+ * cvmi_hiera_mlp_packed_bytes(C) = (4 C / 32) * (C/16 + 1 + 2 ceil(C/32)) * 1024.  b2: fc2 bias, f32 [C]. */
+int cvmi_hiera_mlp_supported(int C);
+size_t cvmi_hiera_mlp_packed_bytes(int C);
+int cvmi_hiera_mlp(void* x, int x_ld, const float* gamma, const float* beta, float eps, const void* w_packed,
+                   const float* b2, long long rows, int C, cvmi_stream_t stream);
 
 /* 2x2 / stride 2 max-pool, NHWC (Hiera shortcut path of the q-pooling blocks: do_pool(proj(x))). */
 int cvmi_maxpool2x2(const void* x, int x_ld, void* y, int y_ld, int B, int H, int W, int C, int dtype,

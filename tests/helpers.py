@@ -43,16 +43,20 @@ def err_stats(got, ref):
     return float(d.abs().max()), float(d.pow(2).mean().sqrt()), float(ref.float().std())
 
 
-def assert_rel(name, got, ref, max_rel, rms_rel, report=None, absolute=False):
-    """max |err| <= max_rel * std(ref) and rms err <= rms_rel * std(ref); absolute=True: the bounds are absolute."""
+def assert_rel(name, got, ref, max_rel, rms_rel, failures=None, absolute=False):
+    """max |err| <= max_rel * std(ref) and rms err <= rms_rel * std(ref); absolute=True: the bounds are absolute.
+    With `failures` (a list) a violation is recorded there instead of raised, so one run reports every tensor."""
     mx, rms, sd = err_stats(got, ref)
     if absolute:
         max_rel, rms_rel = max_rel / sd, rms_rel / sd
     line = f"{name}: max|err| {mx:.3e} ({mx / sd:.2e} std), rms {rms:.3e} ({rms / sd:.2e} std), std(ref) {sd:.3f}"
     print(line)
-    if report is not None:
-        report.append(line)
-    assert sd > 0 and mx <= max_rel * sd and rms <= rms_rel * sd, line
+    ok = sd > 0 and mx <= max_rel * sd and rms <= rms_rel * sd
+    if failures is not None:
+        if not ok:
+            failures.append(line + f"  [bounds: max {max_rel:.2e} std, rms {rms_rel:.2e} std]")
+        return
+    assert ok, line
 
 
 def save_converted_yolo(path, params, scale, nc, imgsz=None):
@@ -77,3 +81,15 @@ def assert_same_detections(name, got, ref, top=20, min_overlap=0.97):
     print(f"{name}: {len(got)} vs {len(ref)} detections, overlap {ov:.4f}, identical order: {got == ref}")
     assert ov >= min_overlap and abs(len(got) - len(ref)) <= max(1, 0.03 * len(ref)), (name, len(got), len(ref), ov)
     return ov
+
+
+def box_match_rate(got, ref, iou_thr=0.85):
+    """Fraction of reference boxes (dicts with xmin/ymin/xmax/ymax/class) that some box of the same class in `got` overlaps with
+    IoU >= iou_thr -- the fp16-mode counterpart of list equality (rounded coordinates move by a pixel under fp16 noise)."""
+    def iou(a, b):
+        iw = max(min(a["xmax"], b["xmax"]) - max(a["xmin"], b["xmin"]), 0)
+        ih = max(min(a["ymax"], b["ymax"]) - max(a["ymin"], b["ymin"]), 0)
+        u = (a["xmax"] - a["xmin"]) * (a["ymax"] - a["ymin"]) + (b["xmax"] - b["xmin"]) * (b["ymax"] - b["ymin"]) - iw * ih
+        return iw * ih / u if u > 0 else 0.0
+    hit = sum(1 for r in ref if any(g["class"] == r["class"] and iou(g, r) >= iou_thr for g in got))
+    return hit / max(1, len(ref))

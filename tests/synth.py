@@ -56,7 +56,7 @@ def nms_stress_pred(B, nc=62, hw=(640, 640), seed=0, frac_logit=-4.0):
     return torch.stack(out).float().contiguous()
 
 
-def calibrated_yolo_params(scale, nc, seed, x, cand_per_image=45, spread=2.0, conf=0.25, box_decay=0.45):
+def calibrated_yolo_params(scale, nc, seed, x, cand_per_image=45, spread=2.0, conf=0.25, box_decay=0.45, bn_beta_shift=1.0):
     """Seeded synthetic YOLO11 weights that DETECT something on the images `x` ([B,3,H,W] f32, letterboxed).
 
     Seeded random weights leave every class score below ~0.02 and contract the activations to near-constants (neck features of
@@ -78,6 +78,11 @@ def calibrated_yolo_params(scale, nc, seed, x, cand_per_image=45, spread=2.0, co
     m = YOLO11(scale, nc).eval()
     m.load_state_dict(params.state_dict(), strict=True)
     bns = [mod for mod in m.modules() if isinstance(mod, torch.nn.BatchNorm2d)]
+    if bn_beta_shift:
+        for k in list(params.sd):
+            if k.endswith("bn.bias"):
+                params.sd[k].add_(bn_beta_shift)
+        m.load_state_dict(params.state_dict(), strict=True)
     for bn in bns:
         bn.reset_running_stats()
         bn.momentum = None                                        # cumulative average: after one pass, running stats = batch stats

@@ -417,3 +417,38 @@ def test_gemm_256_tile_counted_dma_pipeline(M, N, K, out_f32, act):
         yb.t.zero_()
         run(plan)
         assert torch.equal(yb.t, first)
+
+
+@pytest.mark.parametrize("C_,rows", [(144, 1000), (288, 777), (144, 256 * 37 + 5)])
+def test_hiera_mlp_fused_vs_torch(C_, rows):
+    """x + fc2(GELU(fc1(LayerNorm(x)))) in one launch (hiera_mlp.hip) vs fp32 torch on the same fp16-rounded weights:
+    the pre-activations are computed from fp16 operands and the hidden activation is rounded to fp16, as in the unfused chain.
+    Ragged row counts exercise the clamped last tile; rows beyond `rows` must stay untouched."""
+    import torch.nn.functional as TF
+    from circuitvision_amd.engine import PackedHieraMlp, op_hiera_mlp
+    g = torch.Generator().manual_seed(C_ + rows)
+    x = torch.randn(rows + 3, C_, generator=g) * 1.5 + 0.3
+    gam, bet = torch.rand(C_, generator=g) + 0.5, torch.randn(C_, generator=g) * 0.2
+    w1 = quant(torch.randn(4 * C_, C_, generator=g) / C_ ** 0.5, F16)
+    b1 = torch.randn(4 * C_, generator=g) * 0.3
+    w2 = quant(torch.randn(C_, 4 * C_, generator=g) / (4 * C_) ** 0.5, F16)
+    b2 = torch.randn(C_, generator=g) * 0.3
+    xn = quant(TF.layer_norm(x[:rows], (C_,), gam, bet, 1e-6), F16)
+    hid = quant(TF.gelu(xn @ w1.t() + b1), F16)
+    ref = x[:rows] + hid @ w2.t() + b2
+    pm = PackedHieraMlp(w1, b1, w2, b2)
+    xb = Buf(1, 1, rows + 3, C_, F32)
+    xb.t.copy_(x.view(1, 1, rows + 3, C_))
+    view = xb.images(0, 1).view()
+    view.buf.W = rows                                             # the op covers the first `rows` rows only
+    plan = Plan(stream())
+    op_hiera_mlp(plan, "mlp", pm, view, gam.cuda(), bet.cuda(), 1e-6)
+    run(plan)
+    got = xb.t.view(rows + 3, C_).cpu()
+    assert torch.equal(got[rows:], x[rows:])
+    err = (got[:rows] - ref).abs().max().item()
+    torch.testing.assert_close(got[:rows], ref, rtol=3e-3, atol=3e-3), err
+    # bit-identical reruns (a second pass on the SAME input)
+    xb.t.copy_(x.view(1, 1, rows + 3, C_))
+    run(plan)
+    assert torch.equal(xb.t.view(rows + 3, C_).cpu(), got)

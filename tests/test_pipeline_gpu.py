@@ -8,7 +8,7 @@ from circuitvision_amd.detector import YOLO
 from circuitvision_amd.pipeline import CircuitPipeline, results_to_bboxes
 from circuitvision_amd.sam2 import HIERA_L, LORA_TARGETS_REFERENCE, SamSyntheticParams
 from circuitvision_amd.sam2_infer import SAM2Model, SAM2Transforms
-from helpers import assert_rel, assert_same_detections, save_converted_yolo
+from helpers import assert_rel, assert_same_detections, box_match_rate, save_converted_yolo
 from oracle import nms as onms
 from oracle import preprocess as opre
 from oracle import sam2_model as osam
@@ -83,7 +83,7 @@ def test_pipeline_f32_matches_oracle_chain_and_sharding_is_exact(tmp_path):
 
 def test_pipeline_config3_shapes_yolo11l_sam2l_f16(tmp_path):
     """BASELINE configs[3] at B = 2: YOLO11-l (fp16) -> SAM 2.1 Hiera-L (fp16 operands) on 640 x 640 circuit images.
-    Detector: identical-box rate vs the fp32 oracle >= 0.8 (reported); segmenter: binary masks IoU >= 0.99 vs the oracle;
+    Detector: >= 0.8 of the fp32 oracle's boxes found again (same class, IoU >= 0.85) and vice versa, reported; segmenter: binary masks IoU >= 0.99 vs the oracle;
     box mode (configs[4] semantics, up to 32 prompts per image): mask IoU >= 0.98 on the SAME boxes."""
     images = [circuit_image(640, 640, seed=800 + i) for i in range(2)]
     x = torch.cat([torch.from_numpy(opre.yolo_preprocess(im)) for im in images])
@@ -100,11 +100,10 @@ def test_pipeline_config3_shapes_yolo11l_sam2l_f16(tmp_path):
     pipe = CircuitPipeline(det, seg, tr, max_prompts=32)
     res = pipe.run_batch(images, "learned")
     resb = pipe.run_batch(images, "boxes")
-    inter = union = 0
+    rates = []
     for (i, r), (_, rb), im in zip(res, resb, images):
         ref_b = _oracle_chain(yo, det.names, im)
-        got_u, ref_u = {b["persistent_uid"] for b in r["bboxes"]}, {b["persistent_uid"] for b in ref_b}
-        inter += len(got_u & ref_u); union += len(got_u | ref_u)
+        rates.append((box_match_rate(r["bboxes"], ref_b), box_match_rate(ref_b, r["bboxes"]), len(r["bboxes"]), len(ref_b)))
         assert len(ref_b) >= 10
         xs = osam.sam2_transform(np.ascontiguousarray(im[..., ::-1]), 1024)[None]
         with torch.no_grad():
@@ -120,5 +119,5 @@ def test_pipeline_config3_shapes_yolo11l_sam2l_f16(tmp_path):
             rm = osam.postprocess_masks(rlo[0].unsqueeze(1), im.shape[:2]).squeeze(1) > 0.0
         gm = rb["masks"].cpu() > 0
         assert k > 0 and (gm & rm).sum().item() / max(1, (gm | rm).sum().item()) >= 0.98, i
-    print(f"configs[3] B=2: identical detections (persistent uid) {inter}/{union} = {inter / max(union, 1):.3f}")
-    assert inter / max(union, 1) >= 0.6          # uid = class + four ROUNDED coordinates: a 0.5 px fp16 shift changes the string
+    print("configs[3] B=2 detector, fp16 vs fp32 oracle: (recall of oracle boxes, precision, n, n_oracle) per image =", rates)
+    assert all(rc >= 0.8 and pr >= 0.8 for rc, pr, _, _ in rates), rates          # same class, IoU >= 0.85
