@@ -110,7 +110,11 @@ __global__ __launch_bounds__(MlpCfg<C>::NW * 64, MlpCfg<C>::WPS) void hiera_mlp_
 
 #pragma unroll 1
   for (int j = 0; j < NCH; ++j) {
-    __syncthreads();                       // (vmcnt(0) +) barrier: chunk j has landed; slot (j + 1) & 1 is no longer being read
+    // Every wave waits for its OWN DMA pieces (hipcc puts no vmcnt wait in front of a barrier for LDS-DMA writes: without this
+    // explicit wait the chunk is read before it has landed -- rare, load-dependent wrong results), then the barrier publishes
+    // chunk j to the workgroup and retires the reads of slot (j + 1) & 1.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
     if (j + 1 < NCH) issue_chunk(j + 1);
     const char* const buf = smem + (j & 1) * CHB + lane * 16;
     // The chunk's FR operand fragments are consumed in one fixed order (fc1's KS1, then fc2's 2 NT); a ring of PF registers

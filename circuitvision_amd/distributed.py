@@ -62,7 +62,7 @@ def weight_tensors(weights):
     """Every device tensor of a prepared model (Yolo11Weights / Sam2Weights): packed convs, LayerNorm affine pairs, folded
     constants, refinement parameters -- what a rank needs to run without reading the checkpoint itself."""
     out = []
-    for name in ("packed", "pc", "mlp"):
+    for name in ("packed", "pc", "mlp", "tl"):
         d = getattr(weights, name, None)
         if d:
             out += packed_tensors(d)

@@ -525,3 +525,48 @@ def op_hiera_mlp(plan, label, pm, x, gamma, beta, eps=1e-6):
         _lib.check(fn(*args, sp), label)
 
     plan.add(label, "mlp_fused", thunk, rows * pm.C * 8, 2 * rows * 2 * 4 * pm.C * pm.C)
+
+
+# ---- token-stationary linear layer (tok_linear.hip) ------------------------------------------------------------------------
+def tok_linear_supported(K, dtype, rows):
+    return dtype == F16 and rows % 256 == 0 and bool(_lib.load().cvmi_tok_linear_supported(K))
+
+
+class PackedTokLinear:
+    """One linear layer in the MFMA-fragment order cvmi_tok_linear streams (include/cvmi355.h); the bias rides in the weights."""
+
+    def __init__(self, w, b, device="cuda"):
+        N, K = w.shape                                       # float32, LoRA already merged
+        assert K % 16 == 0
+        ks1, nch = K // 16 + 1, (N + 31) // 32
+        b = b if b is not None else torch.zeros(N)
+        b_hi = b.to(torch.float16).float()
+        b_lo = (b - b_hi).to(torch.float16).float()
+        wx = torch.zeros(nch * 32, K + 16)
+        wx[:N, :K], wx[:N, K], wx[:N, K + 1] = w, b_hi, b_lo
+        packed = wx.view(nch, 32, ks1, 2, 8).permute(0, 2, 3, 1, 4).contiguous()                  # (j, s, h, r, e)
+        assert packed.numel() * 2 == _lib.load().cvmi_tok_linear_packed_bytes(K, N)
+        self.w = packed.to(torch.float16).to(device)
+        self.bias = torch.zeros(4, device=device)             # (placeholder: distributed.packed_tensors expects .w / .bias)
+        self.N, self.K = N, K
+        self.param_bytes = N * K * 2
+
+
+def op_tok_linear(plan, label, pt, src, dst, ln=None, act=_lib.ACT_NONE, residual=False, kind="gemm"):
+    """src: f32 View with ln = (gamma, beta, eps), or an fp16 View.  dst: fp16 View, or (residual=True) the f32 View updated in place."""
+    lib = _lib.load()
+    src, dst = _as_rows(src), _as_rows(dst)
+    assert src.C == pt.K and dst.C == pt.N and src.rows == dst.rows and src.rows % 256 == 0, label
+    assert (src.dtype == F32) == (ln is not None) and (dst.dtype == F32) == bool(residual), label
+    gam, bet, eps = ln if ln is not None else (None, None, 0.0)
+    args = (src.ptr, src.ld, 1 if ln is not None else 0, gam.data_ptr() if ln is not None else None, bet.data_ptr() if ln is not None else None,
+            float(eps), pt.w.data_ptr(), dst.ptr, dst.ld, 1 if residual else 0, src.rows, pt.K, pt.N, act)
+    plan.keep.append((pt, src, dst, gam, bet))
+    sp0, fn = plan.sptr, lib.cvmi_tok_linear
+
+    def thunk(sp=None):
+        sp = sp0 if sp is None else sp
+        _lib.check(fn(*args, sp), label)
+
+    bytes_ = src.rows * (pt.K * ESIZE[src.dtype] + pt.N * ESIZE[dst.dtype] * (2 if residual else 1))
+    plan.add(label, kind, thunk, bytes_, 2 * src.rows * pt.N * pt.K)

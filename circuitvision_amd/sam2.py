@@ -29,8 +29,8 @@ import torch.nn.functional as TF
 
 from . import _lib
 from ._lib import ACT_GELU, ACT_NONE, ACT_RELU, ACT_SIGMOID, F16, F32
-from .engine import (ESIZE, TORCH_DTYPE, Buf, PackedConv, PackedHieraMlp, Plan, Rows, hiera_mlp_supported, make_attn_desc, op_attention, op_call,
-                     op_cast, op_conv, op_hiera_mlp, op_layernorm, op_maxpool2, require_gpu)
+from .engine import (ESIZE, TORCH_DTYPE, Buf, PackedConv, PackedHieraMlp, PackedTokLinear, Plan, Rows, hiera_mlp_supported, make_attn_desc, op_attention,
+                     op_call, op_cast, op_conv, op_hiera_mlp, op_layernorm, op_maxpool2, op_tok_linear, require_gpu, tok_linear_supported)
 
 HIERA_L = dict(embed_dim=144, num_heads=2, stages=(2, 6, 36, 4), global_att_blocks=(23, 33, 43), window_spec=(8, 4, 16, 8))
 HIERA_T = dict(embed_dim=96, num_heads=1, stages=(1, 2, 7, 2), global_att_blocks=(5, 7, 9), window_spec=(8, 4, 14, 7))
@@ -166,8 +166,9 @@ class Sam2Weights:
                  refinement_kernels=(3, 5, 7, 11), embedding_r=4):
         self.p, self.hiera, self.image_size, self.dtype, self.device = params, hiera, image_size, dtype, device
         self.use_refinement, self.kernels = use_refinement, tuple(refinement_kernels)
-        self.pc, self.ln, self.const, self.mlp = {}, {}, {}, {}
-        self.fused_mlp = os.environ.get("CVMI_SAM_FUSED_MLP", "1") != "0"      # (the switch is for A/B measurements)
+        self.pc, self.ln, self.const, self.mlp, self.tl = {}, {}, {}, {}, {}
+        self.fused_mlp = os.environ.get("CVMI_SAM_FUSED_MLP", "1") != "0"      # (the switches are for A/B measurements)
+        self.use_tok = os.environ.get("CVMI_SAM_TOKLIN", "1") != "0"
         self.param_bytes = 0
         self.flops_per_image = 0
         self._trunk()
@@ -182,8 +183,13 @@ class Sam2Weights:
         self.param_bytes += pc.param_bytes
         return pc
 
-    def _linear(self, key, mod, cout, cin):
-        return self._pack(key, _lin(self.p.weight(mod, (cout, cin))), self.p.bias(mod, cout))
+    def _linear(self, key, mod, cout, cin, tok=False):
+        w, b = self.p.weight(mod, (cout, cin)), self.p.bias(mod, cout)
+        if tok and self.use_tok and self.dtype == F16 and tok_linear_supported(cin, self.dtype, 256):
+            # short-K Hiera linears also in the token-stationary kernel's fragment order (tok_linear.hip); the plan picks it
+            # whenever its row count is a multiple of 256
+            self.tl[key] = PackedTokLinear(w, b, self.device)
+        return self._pack(key, _lin(w), b)
 
     def _norm(self, key, mod, c):
         self.ln[key] = (self.p.tensor(f"{mod}.weight", (c,), "gamma").float().to(self.device),
@@ -220,8 +226,8 @@ class Sam2Weights:
                 dim_out, heads, cur = dim * 2, heads * 2, cur + 1
             b = f"{T}.blocks.{i}"
             self._norm(f"b{i}.norm1", f"{b}.norm1", dim)
-            self._linear(f"b{i}.qkv", f"{b}.attn.qkv", 3 * dim_out, dim)
-            self._linear(f"b{i}.proj", f"{b}.attn.proj", dim_out, dim_out)
+            self._linear(f"b{i}.qkv", f"{b}.attn.qkv", 3 * dim_out, dim, tok=dim == dim_out)
+            self._linear(f"b{i}.proj", f"{b}.attn.proj", dim_out, dim_out, tok=True)
             self._norm(f"b{i}.norm2", f"{b}.norm2", dim_out)
             if self.fused_mlp and hiera_mlp_supported(dim_out, self.dtype):
                 # stages 1 / 2: norm2 + fc1 + GELU + fc2 + residual as ONE launch (hiera_mlp.hip); weights in fragment order
@@ -230,7 +236,7 @@ class Sam2Weights:
                                                    self.device)
                 self.param_bytes += self.mlp[f"b{i}"].param_bytes
             else:
-                self._linear(f"b{i}.fc1", f"{b}.mlp.layers.0", 4 * dim_out, dim_out)
+                self._linear(f"b{i}.fc1", f"{b}.mlp.layers.0", 4 * dim_out, dim_out, tok=True)
                 self._linear(f"b{i}.fc2", f"{b}.mlp.layers.1", dim_out, 4 * dim_out)
             if dim != dim_out:
                 self._linear(f"b{i}.dimproj", f"{b}.proj", dim_out, dim)
@@ -451,10 +457,12 @@ class Sam2Plan:
         padded = (Hp, Wp) != (H, W)
         if blk["q_pool"] and (ws == 0 or ws % 2 or Hp % 2 or Wp % 2):
             raise NotImplementedError("q-pool block needs an even window")
+        tok_rows = not padded and (B * H * W) % 256 == 0          # token-stationary linears (tok_linear.hip) take 256-row workgroups
+        tok_qkv = tok_rows and f"b{i}.qkv" in wt.tl                # ... and fuse norm1 into the qkv projection (dim == dim_out blocks)
         if padded:
             xn = self.buf(Hp, Wp, dim, tag="xn_padded", zero=True)
             op_layernorm(self.plan, f"b{i}.norm1", x.view(), gam, bet, xn.view(), 1e-6, pad=(H, W, Hp, Wp))
-        else:
+        elif not tok_qkv:
             xn = self.buf(H, W, dim, tag="xn")
             op_layernorm(self.plan, f"b{i}.norm1", x.view(), gam, bet, xn.view(), 1e-6)
         if dim != dout:
@@ -465,7 +473,10 @@ class Sam2Plan:
         else:
             short = x
         qkv = self.buf(Hp, Wp, 3 * dout, tag="qkv")
-        self.gemm(f"b{i}.qkv", f"b{i}.qkv", xn.view(), qkv.view())
+        if tok_qkv:
+            op_tok_linear(self.plan, f"b{i}.qkv", wt.tl[f"b{i}.qkv"], x.view(), qkv.view(), ln=(gam, bet, 1e-6))
+        else:
+            self.gemm(f"b{i}.qkv", f"b{i}.qkv", xn.view(), qkv.view())
         OH, OW = (H // 2, W // 2) if blk["q_pool"] else (H, W)
         OHp, OWp = (Hp // 2, Wp // 2) if blk["q_pool"] else (Hp, Wp)
         ao = self.buf(OHp, OWp, dout, tag="ao")
@@ -490,16 +501,23 @@ class Sam2Plan:
         op_attention(self.plan, f"b{i}.attn", desc, (qkv, ao), bytes_=qkv.nbytes + ao.nbytes, flops=fl)
         self.plan.ops[-1] = (self.plan.ops[-1][0], "attn_global" if ws == 0 else "attn_window") + self.plan.ops[-1][2:]
         # x = shortcut + proj(attn)   (in place on the f32 residual stream)
-        self.gemm(f"b{i}.proj", f"b{i}.proj", ao.view(), short.view(), res=short.view(), out_hw=(OH, OW) if padded else None)
+        tok_out = not padded and (B * OH * OW) % 256 == 0
+        if tok_out and f"b{i}.proj" in wt.tl:
+            op_tok_linear(self.plan, f"b{i}.proj", wt.tl[f"b{i}.proj"], ao.view(), short.view(), residual=True)
+        else:
+            self.gemm(f"b{i}.proj", f"b{i}.proj", ao.view(), short.view(), res=short.view(), out_hw=(OH, OW) if padded else None)
         x = short
         gam, bet = wt.ln[f"b{i}.norm2"]
         if f"b{i}" in wt.mlp:
             op_hiera_mlp(self.plan, f"b{i}.mlp", wt.mlp[f"b{i}"], x.view(), gam, bet, 1e-6)
         else:
-            xn2 = self.buf(OH, OW, dout, tag="xn")
-            op_layernorm(self.plan, f"b{i}.norm2", x.view(), gam, bet, xn2.view(), 1e-6)
             hid = self.buf(OH, OW, 4 * dout, tag="hid")
-            self.gemm(f"b{i}.fc1", f"b{i}.fc1", xn2.view(), hid.view(), act=ACT_GELU)
+            if tok_out and f"b{i}.fc1" in wt.tl:                   # norm2 fused into fc1 (+ GELU)
+                op_tok_linear(self.plan, f"b{i}.fc1", wt.tl[f"b{i}.fc1"], x.view(), hid.view(), ln=(gam, bet, 1e-6), act=ACT_GELU)
+            else:
+                xn2 = self.buf(OH, OW, dout, tag="xn")
+                op_layernorm(self.plan, f"b{i}.norm2", x.view(), gam, bet, xn2.view(), 1e-6)
+                self.gemm(f"b{i}.fc1", f"b{i}.fc1", xn2.view(), hid.view(), act=ACT_GELU)
             self.gemm(f"b{i}.fc2", f"b{i}.fc2", hid.view(), x.view(), res=x.view())
         if i in self.wt.stage_ends and i != len(self.wt.blocks) - 1:
             # the next block writes its own shortcut buffer (dim change) -> x stays intact as the stage output

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define CVMI_VERSION 107
+#define CVMI_VERSION 108
 
 typedef void* cvmi_stream_t; /* hipStream_t */
 
@@ -235,6 +235,22 @@ int cvmi_hiera_mlp_supported(int C);
 size_t cvmi_hiera_mlp_packed_bytes(int C);
 int cvmi_hiera_mlp(void* x, int x_ld, const float* gamma, const float* beta, float eps, const void* w_packed,
                    const float* b2, long long rows, int C, cvmi_stream_t stream);
+
+/* Token-stationary linear layer for Hiera's short-K GEMMs (sam2 hieradet MultiScaleBlock: qkv(norm1(x)), x = shortcut + proj(attn),
+ * mlp.layers[0](norm2(x)) + GELU; behind sam2_infer.py:226):
+ *   y[r, n] = act( sum_k in[r, k] * W[n, k] + b[n] ),   r < rows (a multiple of 256), n < N, K in {144, 288, 576}
+ *   in_f32_layernorm = 1: in is the f32 residual stream, normalised on the fly with gamma / beta / eps (the separate LayerNorm pass
+ *                         and its fp16 copy disappear); 0: in is an fp16 matrix
+ *   out_f32_residual = 1: out is the f32 residual stream, updated in place (out[r, n] += y[r, n], act must be NONE);
+ *                      0: out is fp16 (act NONE or GELU)
+ * w_packed: ceil(N/32) chunks of (K/16 + 1) MFMA fragments of 1 KiB, fragment (j, s), lane l (r = l & 31, h = l >> 5), element e:
+ *   Wx[32 j + r][16 s + 8 h + e],  Wx = [ W | fp16(b) | fp16(b - fp16(b)) | 0 ... ]  (K + 16 columns, rows >= N zero).
+ * cvmi_tok_linear_packed_bytes(K, N) = ceil(N/32) * (K/16 + 1) * 1024. */
+int cvmi_tok_linear_supported(int K);
+size_t cvmi_tok_linear_packed_bytes(int K, int N);
+int cvmi_tok_linear(const void* in, int in_ld, int in_f32_layernorm, const float* gamma, const float* beta, float eps,
+                    const void* w_packed, void* out, int out_ld, int out_f32_residual, long long rows, int K, int N, int act,
+                    cvmi_stream_t stream);
 
 /* 2x2 / stride 2 max-pool, NHWC (Hiera shortcut path of the q-pooling blocks: do_pool(proj(x))). */
 int cvmi_maxpool2x2(const void* x, int x_ld, void* y, int y_ld, int B, int H, int W, int C, int dtype,

@@ -452,3 +452,49 @@ def test_hiera_mlp_fused_vs_torch(C_, rows):
     xb.t.copy_(x.view(1, 1, rows + 3, C_))
     run(plan)
     assert torch.equal(xb.t.view(rows + 3, C_).cpu(), got)
+
+
+@pytest.mark.parametrize("K,N,ln,res,act", [(144, 432, True, False, ACT_NONE), (288, 864, True, False, ACT_NONE), (576, 1728, True, False, ACT_NONE),
+                                            (576, 2304, True, False, ACT_GELU), (576, 576, False, True, ACT_NONE), (144, 144, False, True, ACT_NONE),
+                                            (288, 100, False, False, ACT_GELU), (576, 40, True, True, ACT_NONE)])
+def test_tok_linear_vs_torch(K, N, ln, res, act):
+    """Token-stationary linear layer (tok_linear.hip): optional fused LayerNorm of the f32 stream on the way in, fp16 output with
+    optional GELU or in-place f32 residual update, N not a multiple of 32 (masked last chunk), vs fp32 torch on fp16-rounded weights."""
+    import torch.nn.functional as TF
+    from circuitvision_amd.engine import PackedTokLinear, Rows, op_tok_linear
+    rows = 512
+    g = torch.Generator().manual_seed(K + N)
+    w = quant(torch.randn(N, K, generator=g) / K ** 0.5, F16)
+    b = torch.randn(N, generator=g) * 0.3
+    gam, bet = torch.rand(K, generator=g) + 0.5, torch.randn(K, generator=g) * 0.2
+    if ln:
+        x = torch.randn(rows, K, generator=g) * 1.5 + 0.7
+        x[:, 3] += 40.0                                     # an outlier channel: the shifted single-pass variance must cope
+        xin = quant(TF.layer_norm(x, (K,), gam, bet, 1e-6), F16)
+        src_t = x.cuda()
+    else:
+        x = quant(torch.randn(rows, K, generator=g), F16)
+        xin = x
+        src_t = x.half().cuda()
+    y = xin @ w.t() + b
+    if act == ACT_GELU:
+        y = TF.gelu(y)
+    Np = (N + 3) // 4 * 4
+    if res:
+        r0 = torch.randn(rows, Np, generator=g)
+        ref = r0.clone(); ref[:, :N] += y
+        dst_t = r0.cuda()
+    else:
+        ref = None
+        dst_t = torch.full((rows, Np), 7.0, dtype=torch.float16, device="cuda")
+    pt = PackedTokLinear(w, b)
+    plan = Plan(stream())
+    op_tok_linear(plan, "tl", pt, Rows(src_t, rows, K), Rows(dst_t, rows, N, ld=Np), ln=(gam.cuda(), bet.cuda(), 1e-6) if ln else None,
+                  act=act, residual=res)
+    run(plan)
+    got = dst_t.float().cpu()
+    if res:
+        torch.testing.assert_close(got, ref, rtol=3e-3, atol=3e-3)
+    else:
+        torch.testing.assert_close(got[:, :N], y, rtol=4e-3, atol=4e-3)
+        assert bool((got[:, N:] == 7.0).all())               # columns beyond N untouched
