@@ -538,7 +538,7 @@ class PackedTokLinear:
     def __init__(self, w, b, device="cuda"):
         N, K = w.shape                                       # float32, LoRA already merged
         assert K % 16 == 0
-        ks1, nch = K // 16 + 1, (N + 31) // 32
+        ks1, nch = K // 16 + 1, ((N + 31) // 32 + 1) // 2 * 2       # chunk count padded to even (the kernel may take two per barrier)
         b = b if b is not None else torch.zeros(N)
         b_hi = b.to(torch.float16).float()
         b_lo = (b - b_hi).to(torch.float16).float()
