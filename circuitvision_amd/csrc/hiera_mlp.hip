@@ -120,27 +120,40 @@ __global__ __launch_bounds__(MlpCfg<C>::NW * 64, MlpCfg<C>::WPS) void hiera_mlp_
     // The chunk's FR operand fragments are consumed in one fixed order (fc1's KS1, then fc2's 2 NT); a ring of PF registers
     // keeps PF ds_read_b128 in flight ahead of the MFMA that consumes them -- across the GELU as well, so that fc2's first
     // operands arrive while the VALU works.  (Left to itself hipcc emits read -> lgkmcnt(0) -> MFMA per step.)
+    // (The reads and their COUNTED waits are inline asm: hipcc answers the same source with read -> lgkmcnt(0) -> MFMA groups.  LDS
+    // returns data in issue order, so before fragment f is used at most min(PF - 1, FR - 1 - f) younger reads may be outstanding;
+    // the loop holds no other LDS / scalar-memory traffic.)
     constexpr int PF = 6;
     u32x4 ring[PF];
+    const unsigned lbase = (unsigned)(size_t)((const __attribute__((address_space(3))) char*)buf);
 #pragma unroll
-    for (int f = 0; f < PF; ++f) ring[f] = *reinterpret_cast<const u32x4*>(buf + f * 1024);
+    for (int f = 0; f < PF; ++f) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(ring[f]) : "v"(lbase), "i"(f * 1024));
     f32x16 hacc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) hacc[r] = 0.f;
     f16x8 pf[2];
 #pragma unroll
     for (int f = 0; f < FR; ++f) {
+      const int young = (FR - 1 - f) < (PF - 1) ? (FR - 1 - f) : (PF - 1);
+      switch (young) {                                         // (compile-time after unrolling)
+        case 0: asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ring[f % PF])); break;
+        case 1: asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(ring[f % PF])); break;
+        case 2: asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(ring[f % PF])); break;
+        case 3: asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(ring[f % PF])); break;
+        case 4: asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(ring[f % PF])); break;
+        default: asm volatile("s_waitcnt lgkmcnt(5)" : "+v"(ring[f % PF])); break;
+      }
       const f16x8 a = __builtin_bit_cast(f16x8, ring[f % PF]);
-      if (f + PF < FR) ring[f % PF] = *reinterpret_cast<const u32x4*>(buf + (f + PF) * 1024);
       if (f < KS1) {
         hacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, __builtin_bit_cast(f16x8, xn[f]), hacc, 0, 0, 0);
-        if (f == KS1 - 1) {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) pf[r >> 3][r & 7] = (f16)gelu_fast(hacc[r]);
-        }
       } else {
         const int t = (f - KS1) >> 1, s2 = (f - KS1) & 1;
         yacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, pf[s2], yacc[t], 0, 0, 0);
+      }
+      if (f + PF < FR) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(ring[f % PF]) : "v"(lbase), "i"((f + PF) * 1024));
+      if (f == KS1 - 1) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) pf[r >> 3][r & 7] = (f16)gelu_fast(hacc[r]);
       }
     }
   }

@@ -13,43 +13,30 @@
 // lane = row, registers = 4 consecutive channels per group -> 8-byte fp16 / 16-byte f32 stores.
 // 8 waves per workgroup (two per SIMD: one wave's epilogue VALU and stores overlap the other's MFMAs), 256 rows per workgroup.
 #include "common.hpp"
-#include <stdlib.h>
 
 namespace {
 
-constexpr int TL_NW = 8;                                        // waves per workgroup: 256 rows
-constexpr int TL_STG = 32 * 144 + 256;                          // per-wave transposition stage: 32 rows x (128 B + 16 B pad) + a (mean, rstd) table
+constexpr int TL_NW = 8;
 
 template <int K> struct TlCfg {
   static constexpr int KS = K / 16, KS1 = KS + 1;
-  static constexpr int CHB = KS1 * 1024;                        // bytes per 32-channel weight chunk
-  static constexpr int SLOTS = 3;                                // ring depth
-  static constexpr int LDS = SLOTS * CHB + TL_NW * TL_STG;
+  static constexpr int CHB = KS1 * 1024;                       // bytes per 32-channel weight chunk
+  static constexpr int SLOTS = K <= 288 ? 4 : 3;                // ring depth
+  static constexpr int LDS = SLOTS * CHB;
 };
-
-__device__ __forceinline__ float red8(float v) {                // sum over the 8 lanes that share a row in the coalesced pattern
-  v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4);
-  return v;
-}
 
 // LN = true: `in` is the f32 stream (ld in_ld), normalised with gamma / beta / eps.  LN = false: `in` is fp16 [rows, in_ld].
 // RES = true: out is f32 (ld out_ld), out[r, n] += y.  RES = false: out is fp16.
-//
-// Global traffic is issued in the COALESCED pattern -- 8 (f32) or 4 (fp16) lanes per 128-/64-byte row piece, 8 / 16 rows per
-// wave-instruction -- and transposed to / from the MFMA's "lane = row" layout through a 4.5 KB wave-private LDS stage.  Issued
-// directly in the fragment layout every lane of a load / store touches a different cache line (64 lines per instruction: measured,
-// the texture-address path was then busy for ~40 % of the launch and the MFMA pipe for 30 %).
-template <int K, bool LN, bool RES>
+template <int K, bool LN, bool RES, bool GELU>
 __global__ __launch_bounds__(TL_NW * 64, 2) void tok_linear_kernel(const void* __restrict__ in, int in_ld, const float* __restrict__ gamma,
                                                                    const float* __restrict__ beta, float eps, const char* __restrict__ wp,
-                                                                   void* __restrict__ out, int out_ld, long long rows, int N, int act) {
+                                                                   void* __restrict__ out, int out_ld, long long rows, int N) {
   using Cfg = TlCfg<K>;
-  constexpr int KS = Cfg::KS, KS1 = Cfg::KS1, CHB = Cfg::CHB, SLOTS = Cfg::SLOTS, NW = TL_NW;
+  constexpr int KS = Cfg::KS, KS1 = Cfg::KS1, CHB = Cfg::CHB, SLOTS = Cfg::SLOTS;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int lr = lane & 31, lh = lane >> 5;
-  const long long wrow0 = ((long long)blockIdx.x * NW + wv) * 32;                  // first row of this wave (rows % 256 == 0: all valid)
-  char* const stage = smem + SLOTS * CHB + wv * TL_STG;
+  const long long row = ((long long)blockIdx.x * TL_NW + wv) * 32 + lr;          // rows % 256 == 0 (checked by the host): every row exists
   const int nch = (N + 31) / 32;
 
   // chunk j -> ring slot j % SLOTS; wave w moves fragments w, w + 8, ...
@@ -57,8 +44,8 @@ __global__ __launch_bounds__(TL_NW * 64, 2) void tok_linear_kernel(const void* _
     const char* src = wp + (size_t)j * CHB + lane * 16;
     char* dst = smem + (j % SLOTS) * CHB;
 #pragma unroll
-    for (int f = 0; f < (KS1 + NW - 1) / NW; ++f) {
-      const int fi = f * NW + wv;
+    for (int f = 0; f < (KS1 + TL_NW - 1) / TL_NW; ++f) {
+      const int fi = f * TL_NW + wv;
       if (fi < KS1)
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)fi * 1024),
                                          (__attribute__((address_space(3))) void*)(dst + fi * 1024), 16, 0, 0);
@@ -71,81 +58,48 @@ __global__ __launch_bounds__(TL_NW * 64, 2) void tok_linear_kernel(const void* _
   // ---- B fragments: lane (row lr, half lh) holds in[row][16 s + 8 lh .. + 7]
   u32x4 xn[KS1];
   if constexpr (LN) {
-    // Coalesced pattern: lane -> (sub-row sr = lane >> 3, 16-byte piece pc = lane & 7); instruction i of a 32-channel slab covers rows
-    // 8 i + sr.  Pass 1: row means.  Pass 2: row variances about the mean.  Pass 3: each slab is parked in the stage and read back in the
-    // fragment layout, normalised and rounded to fp16 once.  (Passes 2 and 3 re-read the rows from L2.)
-    constexpr int NSL = (K + 31) / 32;                          // slabs (the last one of K = 144 is half a slab)
-    const int sr = lane >> 3, pc = lane & 7;
-    const float* xb = reinterpret_cast<const float*>(in) + (wrow0 + sr) * (long long)in_ld + pc * 4;
-    float mean[4], rstd[4];
-    {
-      float sm[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 3
-      for (int sl = 0; sl < NSL; ++sl) {
-        if (sl * 32 + pc * 4 < K) {
+    // Two passes over the row instead of K/2 live f32 registers per lane (K = 576 would need 288 of the 256 available at two
+    // waves per SIMD): pass 1 accumulates sum and sum of squares of (x - x0), x0 = the row's first element (a shift that keeps
+    // the single-pass variance formula well conditioned: what cancels is (mean - x0)^2, bounded by the row's own spread);
+    // pass 2 re-reads the row -- from L1 / L2, the workgroup's 256 rows were touched a few hundred cycles earlier -- and writes
+    // the fp16 fragments.
+    const float* xr = reinterpret_cast<const float*>(in) + row * (long long)in_ld;
+    const float x0 = xr[0];
+    float s = 0.f, q = 0.f;
+#pragma unroll 6
+    for (int k = 0; k < KS; ++k) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(xr + 16 * k + 8 * lh), b = *reinterpret_cast<const f32x4*>(xr + 16 * k + 8 * lh + 4);
 #pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(xb + (long long)(8 * i) * in_ld + sl * 32);
-            sm[i] += (v[0] + v[1]) + (v[2] + v[3]);
-          }
-        }
+      for (int e = 0; e < 4; ++e) {
+        const float da = a[e] - x0, db = b[e] - x0;
+        s += da + db;
+        q = fmaf(da, da, fmaf(db, db, q));
       }
-#pragma unroll
-      for (int i = 0; i < 4; ++i) mean[i] = red8(sm[i]) / (float)K;
-      float sq[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 3
-      for (int sl = 0; sl < NSL; ++sl) {
-        if (sl * 32 + pc * 4 < K) {
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(xb + (long long)(8 * i) * in_ld + sl * 32);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { const float d = v[e] - mean[i]; sq[i] = fmaf(d, d, sq[i]); }
-          }
-        }
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i) rstd[i] = 1.0f / sqrtf(red8(sq[i]) / (float)K + eps);
     }
-    // (mean, rstd) of row lr for the fragment layout: through a 32-entry table at the end of the stage
-    float* const tab = reinterpret_cast<float*>(stage + 32 * 144);
-    if (pc == 0) {
+    s += __shfl_xor(s, 32);
+    q += __shfl_xor(q, 32);
+    const float dm = s / (float)K;                           // mean - x0
+    const float mean = x0 + dm;
+    const float var = fmaxf(q / (float)K - dm * dm, 0.f);
+    const float rstd = 1.0f / sqrtf(var + eps);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) { tab[2 * (8 * i + sr)] = mean[i]; tab[2 * (8 * i + sr) + 1] = rstd[i]; }
-    }
-    const float my_mean = tab[2 * lr], my_rstd = tab[2 * lr + 1];
-    __builtin_amdgcn_sched_barrier(0);
+    for (int k = 0; k < KS; ++k) {
+      if (k % 3 == 0) __builtin_amdgcn_sched_barrier(0);      // at most 3 steps' loads in flight: no hoisting of all K/16 of them
+      const f32x4 a = *reinterpret_cast<const f32x4*>(xr + 16 * k + 8 * lh), b = *reinterpret_cast<const f32x4*>(xr + 16 * k + 8 * lh + 4);
+      const float* gp = gamma + 16 * k + 8 * lh;
+      const float* bp = beta + 16 * k + 8 * lh;
+      const f32x4 g0 = *reinterpret_cast<const f32x4*>(gp), g1 = *reinterpret_cast<const f32x4*>(gp + 4);
+      const f32x4 b0 = *reinterpret_cast<const f32x4*>(bp), b1 = *reinterpret_cast<const f32x4*>(bp + 4);
+      f16x8 h;
 #pragma unroll
-    for (int sl = 0; sl < NSL; ++sl) {
-      __builtin_amdgcn_sched_barrier(0);                       // one slab's loads in flight at a time (register budget)
-      const bool full = sl * 32 + 32 <= K;                     // compile-time after unrolling
-      if (sl * 32 + pc * 4 < K) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const f32x4 v = *reinterpret_cast<const f32x4*>(xb + (long long)(8 * i) * in_ld + sl * 32);
-          *reinterpret_cast<f32x4*>(stage + (8 * i + sr) * 144 + pc * 16) = v;
-        }
+      for (int e = 0; e < 4; ++e) {
+        h[e] = (f16)((a[e] - mean) * rstd * g0[e] + b0[e]);
+        h[4 + e] = (f16)((b[e] - mean) * rstd * g1[e] + b1[e]);
       }
-#pragma unroll
-      for (int s2 = 0; s2 < (full ? 2 : 1); ++s2) {
-        const int k = 2 * sl + s2;
-        const f32x4 a = *reinterpret_cast<const f32x4*>(stage + lr * 144 + (16 * s2 + 8 * lh) * 4);
-        const f32x4 b = *reinterpret_cast<const f32x4*>(stage + lr * 144 + (16 * s2 + 8 * lh) * 4 + 16);
-        const float* gp = gamma + 16 * k + 8 * lh;
-        const float* bp = beta + 16 * k + 8 * lh;
-        const f32x4 g0 = *reinterpret_cast<const f32x4*>(gp), g1 = *reinterpret_cast<const f32x4*>(gp + 4);
-        const f32x4 b0 = *reinterpret_cast<const f32x4*>(bp), b1 = *reinterpret_cast<const f32x4*>(bp + 4);
-        f16x8 h;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          h[e] = (f16)((a[e] - my_mean) * my_rstd * g0[e] + b0[e]);
-          h[4 + e] = (f16)((b[e] - my_mean) * my_rstd * g1[e] + b1[e]);
-        }
-        xn[k] = __builtin_bit_cast(u32x4, h);
-      }
+      xn[k] = __builtin_bit_cast(u32x4, h);
     }
   } else {
-    const f16* xr = reinterpret_cast<const f16*>(in) + (wrow0 + lr) * (long long)in_ld;
+    const f16* xr = reinterpret_cast<const f16*>(in) + row * (long long)in_ld;
 #pragma unroll
     for (int k = 0; k < KS; ++k) xn[k] = *reinterpret_cast<const u32x4*>(xr + 16 * k + 8 * lh);
   }
@@ -154,54 +108,44 @@ __global__ __launch_bounds__(TL_NW * 64, 2) void tok_linear_kernel(const void* _
     xn[KS] = one;
   }
 
-  // epilogue of chunk `ch`: the accumulator (lane = row lr, register group g -> channels 8 g + 4 lh .. + 3) goes through the stage and
-  // leaves as whole 64-byte (fp16) / 128-byte (f32) row pieces
-  auto epilogue = [&](const f32x16& acc, int ch) {
+  // Epilogue of chunk j: lane (row lr, half lh), register group g -> channels 32 j + 8 g + 4 lh .. + 3.
+  // RES: the four residual loads of a chunk are issued together, as inline asm, BEFORE the weight prefetch of the interval, and waited
+  // for with ONE counted s_waitcnt that leaves that prefetch in flight (`young` = the DMA pieces this wave issued after them; every wave
+  // issues at least KS1 / 8 per chunk).  Written as ordinary loads hipcc answers each with vmcnt(0) beside in-flight LDS-DMA: four
+  // dependent memory round trips per chunk, each also draining the prefetch.
+  f32x4 r4[4];
+  auto res_load = [&](int j) {
+    const float* o = reinterpret_cast<const float*>(out) + row * (long long)out_ld + 32 * j + 4 * lh;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(r4[g]) : "v"(o), "i"(g * 32));
+  };
+  auto epilogue = [&](const f32x16& acc, int j, bool dma_young) {
     if constexpr (RES) {
+      if (dma_young) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(r4[0]), "+v"(r4[1]), "+v"(r4[2]), "+v"(r4[3]) : "i"(KS1 / TL_NW));
+      else asm volatile("s_waitcnt vmcnt(0)" : "+v"(r4[0]), "+v"(r4[1]), "+v"(r4[2]), "+v"(r4[3]));
+      float* o = reinterpret_cast<float*>(out) + row * (long long)out_ld + 32 * j + 4 * lh;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const f32x4 v = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
-        *reinterpret_cast<f32x4*>(stage + lr * 144 + (8 * g + 4 * lh) * 4) = v;
-      }
-      const int sr = lane >> 3, pc = lane & 7;
-      const int c0 = 32 * ch + pc * 4;
-      if (c0 < N) {
+        if (32 * j + 8 * g + 4 * lh < N) {
+          f32x4 v = r4[g];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const f32x4 v = *reinterpret_cast<const f32x4*>(stage + (8 * i + sr) * 144 + pc * 16);
-          float* o = reinterpret_cast<float*>(out) + (wrow0 + 8 * i + sr) * (long long)out_ld + c0;
-          f32x4 r4 = *reinterpret_cast<const f32x4*>(o);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) r4[e] += v[e];
-          *reinterpret_cast<f32x4*>(o) = r4;
+          for (int e = 0; e < 4; ++e) v[e] += acc[4 * g + e];
+          *reinterpret_cast<f32x4*>(o + 8 * g) = v;
         }
       }
     } else {
+      f16* o = reinterpret_cast<f16*>(out) + row * (long long)out_ld + 32 * j + 4 * lh;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         f16x4 h4;
-        if (act == CVMI_ACT_GELU) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) h4[e] = (f16)gelu_fast(acc[4 * g + e]);
-        } else {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) h4[e] = (f16)acc[4 * g + e];
-        }
-        *reinterpret_cast<f16x4*>(stage + lr * 80 + (8 * g + 4 * lh) * 2) = h4;
-      }
-      const int sr = lane >> 2, pc = lane & 3;
-      const int c0 = 32 * ch + pc * 8;
-      if (c0 < N) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          const u32x4 v = *reinterpret_cast<const u32x4*>(stage + (16 * i + sr) * 80 + pc * 16);
-          *reinterpret_cast<u32x4*>(reinterpret_cast<f16*>(out) + (wrow0 + 16 * i + sr) * (long long)out_ld + c0) = v;
-        }
+        for (int e = 0; e < 4; ++e) h4[e] = (f16)(GELU ? gelu_fast(acc[4 * g + e]) : acc[4 * g + e]);
+        if (32 * j + 8 * g + 4 * lh < N) *reinterpret_cast<f16x4*>(o + 8 * g) = h4;
       }
     }
   };
 
-  constexpr int PF = K >= 576 ? 6 : 8;                          // ds_read_b128 kept in flight ahead of their MFMA
+  constexpr int PF = K >= 576 ? 6 : 8;          // ring depth (K = 576: the 148 Xn registers leave less room)
   f32x16 prev;
 #pragma unroll
   for (int r = 0; r < 16; ++r) prev[r] = 0.f;
@@ -212,45 +156,73 @@ __global__ __launch_bounds__(TL_NW * 64, 2) void tok_linear_kernel(const void* _
     // why the epilogue of chunk j - 1 is issued AFTER this barrier: its stores then have a whole chunk of MFMAs to complete in.
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (j + SLOTS - 1 < nch) issue_chunk(j + SLOTS - 1);
+    if constexpr (RES) { if (j > 0) res_load(j - 1); }
+    const bool dma = j + SLOTS - 1 < nch;
+    if (dma) issue_chunk(j + SLOTS - 1);
     const char* const buf = smem + (j % SLOTS) * CHB + lane * 16;
+    // A-fragment ring: PF ds_read_b128 stay in flight ahead of the MFMA that consumes them.  The reads and their COUNTED waits are
+    // inline asm: left to hipcc the same source becomes read -> lgkmcnt(0) -> MFMA (every MFMA then waits a full LDS round trip, and the
+    // matrix pipe idles two thirds of the time).  LDS returns data in issue order, so before MFMA f at most min(PF - 1, KS1 - 1 - f)
+    // younger reads may still be outstanding.  The epilogue of the previous chunk touches no LDS, so these reads are the wave's only
+    // lgkm traffic inside the loop.
     u32x4 ring[PF];
+    const unsigned lbase = (unsigned)(size_t)((const __attribute__((address_space(3))) char*)buf);
 #pragma unroll
-    for (int f = 0; f < PF; ++f) ring[f] = *reinterpret_cast<const u32x4*>(buf + f * 1024);
-    if (j > 0) epilogue(prev, j - 1);
+    for (int f = 0; f < PF; ++f) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(ring[f]) : "v"(lbase), "i"(f * 1024));
+    if (j > 0) epilogue(prev, j - 1, dma);
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
     for (int f = 0; f < KS1; ++f) {
+      constexpr int dummy = 0; (void)dummy;
+      const int young = (KS1 - 1 - f) < (PF - 1) ? (KS1 - 1 - f) : (PF - 1);
+      switch (young) {                                         // (f is a compile-time constant after unrolling)
+        case 0: asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ring[f % PF])); break;
+        case 1: asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(ring[f % PF])); break;
+        case 2: asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(ring[f % PF])); break;
+        case 3: asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(ring[f % PF])); break;
+        case 4: asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(ring[f % PF])); break;
+        case 5: asm volatile("s_waitcnt lgkmcnt(5)" : "+v"(ring[f % PF])); break;
+        case 6: asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(ring[f % PF])); break;
+        default: asm volatile("s_waitcnt lgkmcnt(7)" : "+v"(ring[f % PF])); break;
+      }
       const f16x8 a = __builtin_bit_cast(f16x8, ring[f % PF]);
-      if (f + PF < KS1) ring[f % PF] = *reinterpret_cast<const u32x4*>(buf + (f + PF) * 1024);
       acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, __builtin_bit_cast(f16x8, xn[f]), acc, 0, 0, 0);
+      if (f + PF < KS1) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(ring[f % PF]) : "v"(lbase), "i"((f + PF) * 1024));
     }
     prev = acc;
   }
-  epilogue(prev, nch - 1);
+  if constexpr (RES) res_load(nch - 1);
+  epilogue(prev, nch - 1, false);
 }
 
-template <int K, bool LN, bool RES>
+template <int K, bool LN, bool RES, bool GELU>
 int launch_tl(const void* in, int in_ld, const float* gamma, const float* beta, float eps, const void* wp, void* out, int out_ld, long long rows,
-              int N, int act, hipStream_t s) {
+              int N, hipStream_t s) {
   using Cfg = TlCfg<K>;
-  static hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&tok_linear_kernel<K, LN, RES>), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
+  static hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&tok_linear_kernel<K, LN, RES, GELU>), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
   CVMI_HIP(attr);
-  hipLaunchKernelGGL((tok_linear_kernel<K, LN, RES>), dim3((unsigned)(rows / 256)), dim3(TL_NW * 64), Cfg::LDS, s, in, in_ld, gamma, beta, eps,
-                     (const char*)wp, out, out_ld, rows, N, act);
+  hipLaunchKernelGGL((tok_linear_kernel<K, LN, RES, GELU>), dim3((unsigned)(rows / 256)), dim3(TL_NW * 64), Cfg::LDS, s, in, in_ld, gamma, beta, eps,
+                     (const char*)wp, out, out_ld, rows, N);
   CVMI_LAUNCH_CHECK();
   return 0;
 }
 
 template <int K>
-int dispatch_tl(bool ln, bool res, const void* in, int in_ld, const float* gamma, const float* beta, float eps, const void* wp, void* out, int out_ld,
-                long long rows, int N, int act, hipStream_t s) {
-  if (ln && !res) return launch_tl<K, true, false>(in, in_ld, gamma, beta, eps, wp, out, out_ld, rows, N, act, s);
-  if (!ln && res) return launch_tl<K, false, true>(in, in_ld, gamma, beta, eps, wp, out, out_ld, rows, N, act, s);
-  if (!ln && !res) return launch_tl<K, false, false>(in, in_ld, gamma, beta, eps, wp, out, out_ld, rows, N, act, s);
-  return launch_tl<K, true, true>(in, in_ld, gamma, beta, eps, wp, out, out_ld, rows, N, act, s);
+int dispatch_tl(bool ln, bool res, int act, const void* in, int in_ld, const float* gamma, const float* beta, float eps, const void* wp, void* out,
+                int out_ld, long long rows, int N, hipStream_t s) {
+  const bool gelu = act == CVMI_ACT_GELU;
+  if (res) {
+    if (ln) return launch_tl<K, true, true, false>(in, in_ld, gamma, beta, eps, wp, out, out_ld, rows, N, s);
+    return launch_tl<K, false, true, false>(in, in_ld, gamma, beta, eps, wp, out, out_ld, rows, N, s);
+  }
+  if (ln) {
+    if (gelu) return launch_tl<K, true, false, true>(in, in_ld, gamma, beta, eps, wp, out, out_ld, rows, N, s);
+    return launch_tl<K, true, false, false>(in, in_ld, gamma, beta, eps, wp, out, out_ld, rows, N, s);
+  }
+  if (gelu) return launch_tl<K, false, false, true>(in, in_ld, gamma, beta, eps, wp, out, out_ld, rows, N, s);
+  return launch_tl<K, false, false, false>(in, in_ld, gamma, beta, eps, wp, out, out_ld, rows, N, s);
 }
 
 }  // namespace
@@ -275,10 +247,9 @@ extern "C" int cvmi_tok_linear(const void* in, int in_ld, int in_f32_layernorm, 
              "tok_linear: pointers / ld not aligned (in_ld=%d out_ld=%d N=%d)", in_ld, out_ld, N);
   hipStream_t s = (hipStream_t)stream_;
   const bool ln = in_f32_layernorm != 0, res = out_f32_residual != 0;
-  CVMI_CHECK(out_f32_residual || (N % 8 == 0 && out_ld % 8 == 0), "tok_linear: fp16 output needs N and out_ld to be multiples of 8");
   switch (K) {
-    case 144: return dispatch_tl<144>(ln, res, in, in_ld, gamma, beta, eps, w_packed, out, out_ld, rows, N, act, s);
-    case 288: return dispatch_tl<288>(ln, res, in, in_ld, gamma, beta, eps, w_packed, out, out_ld, rows, N, act, s);
-    default: return dispatch_tl<576>(ln, res, in, in_ld, gamma, beta, eps, w_packed, out, out_ld, rows, N, act, s);
+    case 144: return dispatch_tl<144>(ln, res, act, in, in_ld, gamma, beta, eps, w_packed, out, out_ld, rows, N, s);
+    case 288: return dispatch_tl<288>(ln, res, act, in, in_ld, gamma, beta, eps, w_packed, out, out_ld, rows, N, s);
+    default: return dispatch_tl<576>(ln, res, act, in, in_ld, gamma, beta, eps, w_packed, out, out_ld, rows, N, s);
   }
 }

@@ -456,7 +456,7 @@ def test_hiera_mlp_fused_vs_torch(C_, rows):
 
 @pytest.mark.parametrize("K,N,ln,res,act", [(144, 432, True, False, ACT_NONE), (288, 864, True, False, ACT_NONE), (576, 1728, True, False, ACT_NONE),
                                             (576, 2304, True, False, ACT_GELU), (576, 576, False, True, ACT_NONE), (144, 144, False, True, ACT_NONE),
-                                            (288, 104, False, False, ACT_GELU), (576, 40, True, True, ACT_NONE), (144, 432, True, False, ACT_GELU)])
+                                            (288, 104, False, False, ACT_GELU), (576, 40, True, True, ACT_NONE), (144, 432, True, False, ACT_GELU), (288, 288, True, True, ACT_NONE)])
 def test_tok_linear_vs_torch(K, N, ln, res, act):
     """Token-stationary linear layer (tok_linear.hip): optional fused LayerNorm of the f32 stream on the way in, fp16 output with
     optional GELU or in-place f32 residual update, N not a multiple of 32 (masked last chunk), vs fp32 torch on fp16-rounded weights."""
