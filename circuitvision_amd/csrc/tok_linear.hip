@@ -109,20 +109,18 @@ __global__ __launch_bounds__(TL_NW * 64, 2) void tok_linear_kernel(const void* _
   }
 
   // Epilogue of chunk j: lane (row lr, half lh), register group g -> channels 32 j + 8 g + 4 lh .. + 3.
-  // RES: the four residual loads of a chunk are issued together, as inline asm, BEFORE the weight prefetch of the interval, and waited
-  // for with ONE counted s_waitcnt that leaves that prefetch in flight (`young` = the DMA pieces this wave issued after them; every wave
-  // issues at least KS1 / 8 per chunk).  Written as ordinary loads hipcc answers each with vmcnt(0) beside in-flight LDS-DMA: four
-  // dependent memory round trips per chunk, each also draining the prefetch.
+  // RES: the four residual loads of chunk j - 1 are ordinary loads issued right after the barrier of interval j; their first use sits in
+  // the MIDDLE of the interval's MFMA sequence.  Beside in-flight LDS-DMA hipcc answers an ordinary load's first use with vmcnt(0):
+  // placed there the wait finds the loads and the interval's weight prefetch long landed, and the stores that follow have the second
+  // half of the MFMAs to complete in before the next barrier's vmcnt(0).
   f32x4 r4[4];
   auto res_load = [&](int j) {
     const float* o = reinterpret_cast<const float*>(out) + row * (long long)out_ld + 32 * j + 4 * lh;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(r4[g]) : "v"(o), "i"(g * 32));
+    for (int g = 0; g < 4; ++g) r4[g] = *reinterpret_cast<const f32x4*>(o + 8 * g);
   };
-  auto epilogue = [&](const f32x16& acc, int j, bool dma_young) {
+  auto epilogue = [&](const f32x16& acc, int j) {
     if constexpr (RES) {
-      if (dma_young) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(r4[0]), "+v"(r4[1]), "+v"(r4[2]), "+v"(r4[3]) : "i"(KS1 / TL_NW));
-      else asm volatile("s_waitcnt vmcnt(0)" : "+v"(r4[0]), "+v"(r4[1]), "+v"(r4[2]), "+v"(r4[3]));
       float* o = reinterpret_cast<float*>(out) + row * (long long)out_ld + 32 * j + 4 * lh;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
@@ -157,8 +155,7 @@ __global__ __launch_bounds__(TL_NW * 64, 2) void tok_linear_kernel(const void* _
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if constexpr (RES) { if (j > 0) res_load(j - 1); }
-    const bool dma = j + SLOTS - 1 < nch;
-    if (dma) issue_chunk(j + SLOTS - 1);
+    if (j + SLOTS - 1 < nch) issue_chunk(j + SLOTS - 1);
     const char* const buf = smem + (j % SLOTS) * CHB + lane * 16;
     // A-fragment ring: PF ds_read_b128 stay in flight ahead of the MFMA that consumes them.  The reads and their COUNTED waits are
     // inline asm: left to hipcc the same source becomes read -> lgkmcnt(0) -> MFMA (every MFMA then waits a full LDS round trip, and the
@@ -169,7 +166,7 @@ __global__ __launch_bounds__(TL_NW * 64, 2) void tok_linear_kernel(const void* _
     const unsigned lbase = (unsigned)(size_t)((const __attribute__((address_space(3))) char*)buf);
 #pragma unroll
     for (int f = 0; f < PF; ++f) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(ring[f]) : "v"(lbase), "i"(f * 1024));
-    if (j > 0) epilogue(prev, j - 1, dma);
+    if constexpr (!RES) { if (j > 0) epilogue(prev, j - 1); }
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -190,11 +187,12 @@ __global__ __launch_bounds__(TL_NW * 64, 2) void tok_linear_kernel(const void* _
       const f16x8 a = __builtin_bit_cast(f16x8, ring[f % PF]);
       acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, __builtin_bit_cast(f16x8, xn[f]), acc, 0, 0, 0);
       if (f + PF < KS1) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(ring[f % PF]) : "v"(lbase), "i"((f + PF) * 1024));
+      if constexpr (RES) { if (f == KS1 / 2 && j > 0) epilogue(prev, j - 1); }
     }
     prev = acc;
   }
   if constexpr (RES) res_load(nch - 1);
-  epilogue(prev, nch - 1, false);
+  epilogue(prev, nch - 1);
 }
 
 template <int K, bool LN, bool RES, bool GELU>
