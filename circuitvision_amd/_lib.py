@@ -7,7 +7,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcvmi355.so")
 
-F16, F32 = 0, 1
+F16, F32, BF16 = 0, 1, 2
 ACT_NONE, ACT_SILU, ACT_RELU, ACT_GELU, ACT_SIGMOID = 0, 1, 2, 3, 4
 
 
@@ -93,13 +93,13 @@ SIGNATURES = {
     "cvmi_nchw_to_nhwc": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "cvmi_nhwc_to_nchw_f32": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _i, _vp]),
     "cvmi_layernorm": (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _i, C.c_longlong, _i, _f, _i, _i, _i, _i, _i, _vp]),
-    "cvmi_layernorm_dual": (_i, [_vp, _i, _vp, _vp, _vp, _i, _vp, _i, C.c_longlong, _i, _f, _vp]),
+    "cvmi_layernorm_dual": (_i, [_vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, C.c_longlong, _i, _f, _vp]),
     "cvmi_hiera_mlp_supported": (_i, [_i]),
     "cvmi_hiera_mlp_packed_bytes": (C.c_size_t, [_i]),
-    "cvmi_hiera_mlp": (_i, [_vp, _i, _vp, _vp, _f, _vp, _vp, C.c_longlong, _i, _vp]),
+    "cvmi_hiera_mlp": (_i, [_vp, _i, _vp, _vp, _f, _vp, _vp, C.c_longlong, _i, _i, _vp]),
     "cvmi_tok_linear_supported": (_i, [_i]),
     "cvmi_tok_linear_packed_bytes": (C.c_size_t, [_i, _i]),
-    "cvmi_tok_linear": (_i, [_vp, _i, _i, _vp, _vp, _f, _vp, _vp, _i, _i, C.c_longlong, _i, _i, _i, _vp]),
+    "cvmi_tok_linear": (_i, [_vp, _i, _i, _vp, _vp, _f, _vp, _vp, _i, _i, C.c_longlong, _i, _i, _i, _i, _vp]),
     "cvmi_maxpool2x2": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "cvmi_space_to_depth4": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "cvmi_cast": (_i, [_vp, _i, _i, _vp, _i, _i, C.c_longlong, _i, _vp]),

@@ -95,7 +95,7 @@ __global__ __launch_bounds__(256) void attn_f16_kernel(const AttnArgs p) {
           const int py = qi / qwin, px = qi - py * qwin;
           f16x8 m;
 #pragma unroll
-          for (int e = 0; e < 8; ++e) m[e] = (f16)(-65504.f);
+          for (int e = 0; e < 8; ++e) m[e] = (f16)(CVMI_LOWEST16);
 #pragma unroll
           for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
@@ -240,7 +240,7 @@ __global__ __launch_bounds__(256) void attn_f16_kernel(const AttnArgs p) {
 #pragma unroll
     for (int s = 0; s < QS; ++s) {
       const f16x8 kf = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(Ks + lr * KROW + s * 32 + lh * 16));
-      sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, __builtin_bit_cast(f16x8, qf[s]), sacc, 0, 0, 0);
+      sacc = CVMI_MFMA_32X32X16(kf, __builtin_bit_cast(f16x8, qf[s]), sacc, 0, 0, 0);
     }
     // mask keys past Nk, running max
     if (kt * 32 + 32 > p.Nk) {                    // ragged last tile only (wave-uniform)
@@ -285,7 +285,7 @@ __global__ __launch_bounds__(256) void attn_f16_kernel(const AttnArgs p) {
         const u32x2 lo = *reinterpret_cast<const u32x2*>(vp);
         const u32x2 hi = *reinterpret_cast<const u32x2*>(vp + 16);
         const u32x4 vv = {lo[0], lo[1], hi[0], hi[1]};
-        oacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, vv), pf[s], oacc[t], 0, 0, 0);
+        oacc[t] = CVMI_MFMA_32X32X16(__builtin_bit_cast(f16x8, vv), pf[s], oacc[t], 0, 0, 0);
       }
     }
     if constexpr (PREFETCH) {
@@ -370,7 +370,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn64_kernel(const 
       } else {
         f16x8 m;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) m[e] = (f16)(-65504.f);
+        for (int e = 0; e < 8; ++e) m[e] = (f16)(CVMI_LOWEST16);
 #pragma unroll
         for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
@@ -487,7 +487,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn64_kernel(const 
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         const f16x8 kf = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(kq + u * 32 * KROW + s * 32));
-        sacc[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, __builtin_bit_cast(f16x8, qf[s]), sacc[u], 0, 0, 0);
+        sacc[u] = CVMI_MFMA_32X32X16(kf, __builtin_bit_cast(f16x8, qf[s]), sacc[u], 0, 0, 0);
       }
     if (kt * 64 + 64 > p.Nk) {                             // ragged last tile only (wave-uniform)
 #pragma unroll
@@ -537,7 +537,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn64_kernel(const 
           const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0 + 8 * VRS));
           const u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
           const u32x4 vv = {l2[0], l2[1], h2[0], h2[1]};
-          oacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, vv), pf[u][s], oacc[t], 0, 0, 0);
+          oacc[t] = CVMI_MFMA_32X32X16(__builtin_bit_cast(f16x8, vv), pf[u][s], oacc[t], 0, 0, 0);
         }
     __syncthreads();
     if (kt + 1 < nkt) commit();
@@ -650,7 +650,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_res256_kernel(const AttnArgs 
       } else {
         f16x8 m;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) m[e] = (f16)(-65504.f);
+        for (int e = 0; e < 8; ++e) m[e] = (f16)(CVMI_LOWEST16);
 #pragma unroll
         for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
@@ -689,7 +689,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_res256_kernel(const AttnArgs 
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         const f16x8 kf = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(kq + (kc * 64 + u * 32) * ROW + s * 32));
-        sacc[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, __builtin_bit_cast(f16x8, qf[s]), sacc[u], 0, 0, 0);
+        sacc[u] = CVMI_MFMA_32X32X16(kf, __builtin_bit_cast(f16x8, qf[s]), sacc[u], 0, 0, 0);
       }
     float mx = fmaxf(sacc[0][0], sacc[1][0]);
 #pragma unroll
@@ -729,7 +729,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_res256_kernel(const AttnArgs 
           const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0 + 8 * ROW));
           const u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
           const u32x4 vv = {l2[0], l2[1], h2[0], h2[1]};
-          oacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, vv), pf[u][s], oacc[t], 0, 0, 0);
+          oacc[t] = CVMI_MFMA_32X32X16(__builtin_bit_cast(f16x8, vv), pf[u][s], oacc[t], 0, 0, 0);
         }
   }
   if (q_ok) {
@@ -825,7 +825,7 @@ __global__ __launch_bounds__(QT * 128, 4) void attn_res64_kernel(const AttnArgs 
       } else {
         f16x8 m;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) m[e] = (f16)(-65504.f);
+        for (int e = 0; e < 8; ++e) m[e] = (f16)(CVMI_LOWEST16);
 #pragma unroll
         for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
@@ -864,7 +864,7 @@ __global__ __launch_bounds__(QT * 128, 4) void attn_res64_kernel(const AttnArgs 
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         const f16x8 kf = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(kq + (kc * 64 + u * 32) * ROW + s * 32));
-        sacc[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, __builtin_bit_cast(f16x8, qf[s]), sacc[u], 0, 0, 0);
+        sacc[u] = CVMI_MFMA_32X32X16(kf, __builtin_bit_cast(f16x8, qf[s]), sacc[u], 0, 0, 0);
       }
     float mx = fmaxf(sacc[0][0], sacc[1][0]);
 #pragma unroll
@@ -904,7 +904,7 @@ __global__ __launch_bounds__(QT * 128, 4) void attn_res64_kernel(const AttnArgs 
           const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0 + 8 * ROW));
           const u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
           const u32x4 vv = {l2[0], l2[1], h2[0], h2[1]};
-          oacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, vv), pf[u][s], oacc[t], 0, 0, 0);
+          oacc[t] = CVMI_MFMA_32X32X16(__builtin_bit_cast(f16x8, vv), pf[u][s], oacc[t], 0, 0, 0);
         }
   }
   if (q_ok) {
@@ -1014,7 +1014,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_dma72_kernel(const AttnArgs p
       } else {
         f16x8 m;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) m[e] = (f16)(-65504.f);
+        for (int e = 0; e < 8; ++e) m[e] = (f16)(CVMI_LOWEST16);
 #pragma unroll
         for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
@@ -1057,7 +1057,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_dma72_kernel(const AttnArgs p
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         const f16x8 kf = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(kq + (kc * 64 + u * 32) * ROW + s * 32));
-        sacc[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, __builtin_bit_cast(f16x8, qf[s]), sacc[u], 0, 0, 0);
+        sacc[u] = CVMI_MFMA_32X32X16(kf, __builtin_bit_cast(f16x8, qf[s]), sacc[u], 0, 0, 0);
       }
     if (kt * TK + TK > p.Nk) {                              // ragged last tile only (wave-uniform)
 #pragma unroll
@@ -1106,7 +1106,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_dma72_kernel(const AttnArgs p
           const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0 + 8 * ROW));
           const u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
           const u32x4 vv = {l2[0], l2[1], h2[0], h2[1]};
-          oacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, vv), pf[u][s], oacc[t], 0, 0, 0);
+          oacc[t] = CVMI_MFMA_32X32X16(__builtin_bit_cast(f16x8, vv), pf[u][s], oacc[t], 0, 0, 0);
         }
     __syncthreads();                                        // tile kt fully read; tile kt + 1 landed in every wave
   }
@@ -1221,7 +1221,7 @@ __global__ __launch_bounds__(128) void attn_win16_kernel(const AttnArgs p) {
       } else {
         f16x8 m;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) m[e] = (f16)(-65504.f);
+        for (int e = 0; e < 8; ++e) m[e] = (f16)(CVMI_LOWEST16);
 #pragma unroll
         for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
@@ -1236,7 +1236,6 @@ __global__ __launch_bounds__(128) void attn_win16_kernel(const AttnArgs p) {
     }
   }
   __syncthreads();
-  typedef f16 f16x2 __attribute__((ext_vector_type(2)));
   const char* const kr = Kl + (ti < IPW ? ti : 0) * ITEM_B;
   const char* const vr = Vl + (ti < IPW ? ti : 0) * ITEM_B;
   // ---- scores
@@ -1253,7 +1252,7 @@ __global__ __launch_bounds__(128) void attn_win16_kernel(const AttnArgs p) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const f16x2 a2 = {qh[2 * e], qh[2 * e + 1]}, b2 = {kh[2 * e], kh[2 * e + 1]};
-        acc = __builtin_amdgcn_fdot2(a2, b2, acc, false);
+        acc = CVMI_FDOT2(a2, b2, acc, false);
       }
     }
     sc[k] = acc * c2;
@@ -1395,9 +1394,16 @@ int launch_f16_gs(const AttnArgs& a, hipStream_t stream) {
 
 }  // namespace
 
-extern "C" int cvmi_attention(const cvmi_attn_desc* d, cvmi_stream_t stream_) {
+#ifndef CVMI_OPERAND_BF16
+extern "C" int cvmi_attention_bf16(const cvmi_attn_desc* d, cvmi_stream_t stream_);
+#endif
+
+extern "C" int CVMI_ENTRY(cvmi_attention)(const cvmi_attn_desc* d, cvmi_stream_t stream_) {
   CVMI_CHECK(d && d->q && d->k && d->v && d->o, "attention: null pointer");
-  CVMI_CHECK(d->dtype == CVMI_F16 || d->dtype == CVMI_F32, "attention: bad dtype");
+#ifndef CVMI_OPERAND_BF16
+  if (d->dtype == CVMI_BF16) return cvmi_attention_bf16(d, stream_);
+#endif
+  CVMI_CHECK(d->dtype == CVMI_T16 || d->dtype == CVMI_F32, "attention: bad dtype");
   CVMI_CHECK(d->B > 0 && d->heads > 0 && d->Nq > 0 && d->Nk > 0 && d->dqk > 0 && d->dv > 0, "attention: bad shape");
   AttnArgs a;
   a.q = (const char*)d->q; a.k = (const char*)d->k; a.v = (const char*)d->v; a.o = (char*)d->o;
@@ -1407,7 +1413,7 @@ extern "C" int cvmi_attention(const cvmi_attn_desc* d, cvmi_stream_t stream_) {
   a.win = d->win; a.grid_h = d->grid_h; a.grid_w = d->grid_w; a.q_pool = d->q_pool;
   a.q_bdiv = d->q_bdiv > 1 ? d->q_bdiv : 1; a.kv_bdiv = d->kv_bdiv > 1 ? d->kv_bdiv : 1;
   const bool shared = a.q_bdiv > 1 || a.kv_bdiv > 1;
-  CVMI_CHECK(!shared || (d->win == 0 && d->dtype == CVMI_F16 && d->dqk <= 64 && d->dv <= 64 && d->B % a.q_bdiv == 0 && d->B % a.kv_bdiv == 0),
+  CVMI_CHECK(!shared || (d->win == 0 && d->dtype == CVMI_T16 && d->dqk <= 64 && d->dv <= 64 && d->B % a.q_bdiv == 0 && d->B % a.kv_bdiv == 0),
              "attention: batch sharing (q_bdiv / kv_bdiv) needs fp16, no window, head dims <= 64 and B a multiple of the divisor");
   a.qtiles = (d->Nq + 31) / 32;
   a.div_win.init(d->win > 0 ? (unsigned)d->win : 1u);

@@ -7,8 +7,31 @@
 
 #include "../../include/cvmi355.h"
 
+// ---- the 16-bit operand type of a translation unit -----------------------------------------------
+// Every kernel source that computes on 16-bit operands is compiled TWICE: as is (fp16) and with -DCVMI_OPERAND_BF16 (Makefile: *_bf16.o),
+// where `f16` names __bf16, the MFMA / dot builtins are the bf16 forms, CVMI_T16 is CVMI_BF16 and every exported entry point carries the
+// suffix _bf16 -- the fp16 build's entry point forwards to it when its dtype argument says CVMI_BF16.  fp32 accumulation, LayerNorm
+// statistics, softmax and the residual stream are the same code in both builds.
+#ifdef CVMI_OPERAND_BF16
+typedef __bf16 f16;
+#define CVMI_MFMA_32X32X16 __builtin_amdgcn_mfma_f32_32x32x16_bf16
+#define CVMI_FDOT2 __builtin_amdgcn_fdot2_f32_bf16
+#define CVMI_T16 CVMI_BF16
+#define CVMI_ENTRY(name) name##_bf16
+#define CVMI_ONE16X2 0x3F803F80u                 /* two 1.0 in the 16-bit operand type */
+#define CVMI_LOWEST16 (-3.38e38f)
+#else
 typedef _Float16 f16;
+#define CVMI_MFMA_32X32X16 __builtin_amdgcn_mfma_f32_32x32x16_f16
+#define CVMI_FDOT2 __builtin_amdgcn_fdot2
+#define CVMI_T16 CVMI_F16
+#define CVMI_ENTRY(name) name
+#define CVMI_ONE16X2 0x3C003C00u
+#define CVMI_LOWEST16 (-65504.f)
+#endif
+#define CVMI_IS16(dt) ((dt) == CVMI_F16 || (dt) == CVMI_BF16)
 typedef f16 f16x8 __attribute__((ext_vector_type(8)));
+typedef f16 f16x2 __attribute__((ext_vector_type(2)));
 typedef f16 f16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));

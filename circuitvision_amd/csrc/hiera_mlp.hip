@@ -98,7 +98,7 @@ __global__ __launch_bounds__(MlpCfg<C>::NW * 64, MlpCfg<C>::WPS) void hiera_mlp_
       xn[k] = __builtin_bit_cast(u32x4, h);
     }
     // bias step: k = C and C + 1 are constant-1 columns (lanes of half 0 hold k = C .. C + 7)
-    const u32x4 one = {lh == 0 ? 0x3C003C00u : 0u, 0u, 0u, 0u};
+    const u32x4 one = {lh == 0 ? CVMI_ONE16X2 : 0u, 0u, 0u, 0u};
     xn[KS] = one;
   }
 
@@ -145,10 +145,10 @@ __global__ __launch_bounds__(MlpCfg<C>::NW * 64, MlpCfg<C>::WPS) void hiera_mlp_
       }
       const f16x8 a = __builtin_bit_cast(f16x8, ring[f % PF]);
       if (f < KS1) {
-        hacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, __builtin_bit_cast(f16x8, xn[f]), hacc, 0, 0, 0);
+        hacc = CVMI_MFMA_32X32X16(a, __builtin_bit_cast(f16x8, xn[f]), hacc, 0, 0, 0);
       } else {
         const int t = (f - KS1) >> 1, s2 = (f - KS1) & 1;
-        yacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, pf[s2], yacc[t], 0, 0, 0);
+        yacc[t] = CVMI_MFMA_32X32X16(a, pf[s2], yacc[t], 0, 0, 0);
       }
       if (f + PF < FR) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(ring[f % PF]) : "v"(lbase), "i"((f + PF) * 1024));
       if (f == KS1 - 1) {
@@ -190,6 +190,7 @@ int launch_mlp(float* x, int x_ld, const float* gamma, const float* beta, float 
 
 }  // namespace
 
+#ifndef CVMI_OPERAND_BF16
 // C = 576 (stage 3) is not built: its Y^T accumulator alone is 288 registers per lane and, with the 148 of the resident Xn fragments,
 // leaves no room to keep LDS reads in flight (hipcc spills 1.8 KB per lane); stage 3 / 4 stay on the tiled GEMM kernels.
 extern "C" int cvmi_hiera_mlp_supported(int C) { return C == 144 || C == 288; }
@@ -199,11 +200,18 @@ extern "C" size_t cvmi_hiera_mlp_packed_bytes(int C) {
   const size_t fr = (size_t)(C / 16 + 1) + 2 * (size_t)((C + 31) / 32);
   return (size_t)(4 * C / 32) * fr * 1024;
 }
+extern "C" int cvmi_hiera_mlp_bf16(void* x, int x_ld, const float* gamma, const float* beta, float eps, const void* w_packed, const float* b2,
+                                   long long rows, int C, int dtype, cvmi_stream_t stream_);
+#endif
 
-extern "C" int cvmi_hiera_mlp(void* x, int x_ld, const float* gamma, const float* beta, float eps, const void* w_packed, const float* b2,
-                              long long rows, int C, cvmi_stream_t stream_) {
+extern "C" int CVMI_ENTRY(cvmi_hiera_mlp)(void* x, int x_ld, const float* gamma, const float* beta, float eps, const void* w_packed, const float* b2,
+                                          long long rows, int C, int dtype, cvmi_stream_t stream_) {
+#ifndef CVMI_OPERAND_BF16
+  if (dtype == CVMI_BF16) return cvmi_hiera_mlp_bf16(x, x_ld, gamma, beta, eps, w_packed, b2, rows, C, dtype, stream_);
+#endif
+  CVMI_CHECK(dtype == CVMI_T16, "hiera_mlp: dtype must be CVMI_F16 or CVMI_BF16");
   CVMI_CHECK(x && gamma && beta && w_packed && b2 && rows > 0, "hiera_mlp: bad arguments");
-  CVMI_CHECK(cvmi_hiera_mlp_supported(C), "hiera_mlp: C=%d is not built (144, 288)", C);
+  CVMI_CHECK(C == 144 || C == 288, "hiera_mlp: C=%d is not built (144, 288)", C);
   CVMI_CHECK(x_ld >= C && x_ld % 4 == 0 && (((uintptr_t)x | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)w_packed | (uintptr_t)b2) & 15) == 0,
              "hiera_mlp: pointers / ld must be 16-byte aligned");
   hipStream_t s = (hipStream_t)stream_;

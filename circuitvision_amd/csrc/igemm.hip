@@ -42,7 +42,7 @@ struct ConvKArgs {
 template <typename T> struct Mma;
 template <> struct Mma<f16> {
   __device__ static __forceinline__ void run(const u32x4& a, const u32x4& b, f32x16& c) {
-    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    c = CVMI_MFMA_32X32X16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
   }
 };
 template <> struct Mma<float> {
@@ -1524,12 +1524,18 @@ int launch_typed(ConvKArgs& a, hipStream_t stream) {
 }  // namespace
 
 int cvmi_conv_tile_try(const cvmi_conv_desc* d, hipStream_t stream);   // conv_tile.hip
+#ifndef CVMI_OPERAND_BF16
+extern "C" int cvmi_conv2d_bf16(const cvmi_conv_desc* d, cvmi_stream_t stream_);
+#endif
 
-extern "C" int cvmi_conv2d(const cvmi_conv_desc* d, cvmi_stream_t stream_) {
+extern "C" int CVMI_ENTRY(cvmi_conv2d)(const cvmi_conv_desc* d, cvmi_stream_t stream_) {
   CVMI_CHECK(d != nullptr, "conv2d: null descriptor");
+#ifndef CVMI_OPERAND_BF16
+  if (d->dtype == CVMI_BF16) return cvmi_conv2d_bf16(d, stream_);
+#endif
   CVMI_CHECK(d->x0 && d->w && d->bias && d->y, "conv2d: null pointer");
-  CVMI_CHECK(d->dtype == CVMI_F16 || d->dtype == CVMI_F32, "conv2d: bad dtype %d", d->dtype);
-  const int es = d->dtype == CVMI_F16 ? 2 : 4;
+  CVMI_CHECK(d->dtype == CVMI_T16 || d->dtype == CVMI_F32, "conv2d: bad dtype %d", d->dtype);
+  const int es = d->dtype == CVMI_T16 ? 2 : 4;
   const int vec = 16 / es;
   const int oes = (d->dtype == CVMI_F32 || d->out_f32) ? 4 : 2;
   const int ovec = 16 / oes;
@@ -1568,7 +1574,7 @@ extern "C" int cvmi_conv2d(const cvmi_conv_desc* d, cvmi_stream_t stream_) {
   a.plain = (d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0 && d->c1 == 0 && d->up0 == 0 && !d->scalar_gather &&
              d->OH == d->H && d->OW == d->W) ? 1 : 0;
   a.rows2 = (!a.plain && d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0 && !d->scalar_gather && d->OH == d->H && d->OW == d->W &&
-             d->c1 > 0 && d->c0 % 64 == 0 && ctot % 64 == 0 && d->dtype == CVMI_F16) ? 1 : 0;
+             d->c1 > 0 && d->c0 % 64 == 0 && ctot % 64 == 0 && d->dtype == CVMI_T16) ? 1 : 0;
   CVMI_CHECK(d->res_mod >= 0 && d->shuffle_cout >= 0, "conv2d: negative res_mod / shuffle_cout");
   CVMI_CHECK(d->res_rep <= 1 || (d->res && d->B % d->res_rep == 0 && (d->shuffle_cout > 0 || d->res_mod == d->OH * d->OW)),
              "conv2d: res_rep needs a residual, B %% res_rep == 0 and either shuffle_cout or res_mod == OH * OW");
@@ -1579,11 +1585,15 @@ extern "C" int cvmi_conv2d(const cvmi_conv_desc* d, cvmi_stream_t stream_) {
   }
   a.div_ctot.init((unsigned)ctot); a.div_kw.init((unsigned)d->KW);
   hipStream_t stream = (hipStream_t)stream_;
+#ifndef CVMI_OPERAND_BF16
   if (d->KH > 1 && d->y_ld >= d->N) {
     const int rc = cvmi_conv_tile_try(d, stream);
     if (rc >= 0) return rc;
   }
   if (d->dtype == CVMI_F32) return launch_typed<float, float>(a, stream);
+#else
+  CVMI_CHECK(d->dtype == CVMI_BF16, "conv2d (bf16 build): dtype %d", d->dtype);
+#endif
   if (d->out_f32) return launch_typed<f16, float>(a, stream);
   return launch_typed<f16, f16>(a, stream);
 }

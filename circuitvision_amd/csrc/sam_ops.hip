@@ -580,11 +580,18 @@ int launch_ln(const void* x, int x_ld, const float* gamma, const float* beta, vo
 
 }  // namespace
 
-extern "C" int cvmi_layernorm(const void* x, int x_ld, int x_dtype, const float* gamma, const float* beta, void* y, int y_ld, int y_dtype,
+#ifndef CVMI_OPERAND_BF16
+extern "C" int cvmi_layernorm_bf16(const void* x, int x_ld, int x_dtype, const float* gamma, const float* beta, void* y, int y_ld, int y_dtype,
+                              long long rows, int C, float eps, int act, int pad_h, int pad_w, int pad_hp, int pad_wp, cvmi_stream_t stream_);
+#endif
+extern "C" int CVMI_ENTRY(cvmi_layernorm)(const void* x, int x_ld, int x_dtype, const float* gamma, const float* beta, void* y, int y_ld, int y_dtype,
                               long long rows, int C, float eps, int act, int pad_h, int pad_w, int pad_hp, int pad_wp, cvmi_stream_t stream_) {
+#ifndef CVMI_OPERAND_BF16
+  if (x_dtype == CVMI_BF16 || y_dtype == CVMI_BF16) return cvmi_layernorm_bf16(x, x_ld, x_dtype, gamma, beta, y, y_ld, y_dtype, rows, C, eps, act, pad_h, pad_w, pad_hp, pad_wp, stream_);
+#endif
   CVMI_CHECK(x && gamma && beta && y && rows > 0 && C > 0, "layernorm: bad arguments");
-  const int vi = x_dtype == CVMI_F16 ? 8 : 4;
-  CVMI_CHECK((x_dtype == CVMI_F16 || x_dtype == CVMI_F32) && (y_dtype == CVMI_F16 || y_dtype == CVMI_F32), "layernorm: bad dtype");
+  const int vi = x_dtype == CVMI_T16 ? 8 : 4;
+  CVMI_CHECK((x_dtype == CVMI_T16 || x_dtype == CVMI_F32) && (y_dtype == CVMI_T16 || y_dtype == CVMI_F32), "layernorm: bad dtype");
   CVMI_CHECK(C % vi == 0 && x_ld % vi == 0 && y_ld % vi == 0 && (((uintptr_t)x | (uintptr_t)y | (uintptr_t)gamma | (uintptr_t)beta) & 15) == 0 && x_ld >= C && y_ld >= C, "layernorm: C=%d / ld not 16-byte aligned", C);
   int pw = 0, pwp = 0, phw = 0, phpwp = 0;
   if (pad_w > 0) {
@@ -593,53 +600,79 @@ extern "C" int cvmi_layernorm(const void* x, int x_ld, int x_dtype, const float*
   }
   hipStream_t s = (hipStream_t)stream_;
   if (x_dtype == CVMI_F32 && y_dtype == CVMI_F32) return launch_ln<float, float>(x, x_ld, gamma, beta, y, y_ld, rows, C, eps, act, pw, pwp, phw, phpwp, s);
-  if (x_dtype == CVMI_F32 && y_dtype == CVMI_F16) return launch_ln<float, f16>(x, x_ld, gamma, beta, y, y_ld, rows, C, eps, act, pw, pwp, phw, phpwp, s);
-  if (x_dtype == CVMI_F16 && y_dtype == CVMI_F16) return launch_ln<f16, f16>(x, x_ld, gamma, beta, y, y_ld, rows, C, eps, act, pw, pwp, phw, phpwp, s);
+  if (x_dtype == CVMI_F32 && y_dtype == CVMI_T16) return launch_ln<float, f16>(x, x_ld, gamma, beta, y, y_ld, rows, C, eps, act, pw, pwp, phw, phpwp, s);
+  if (x_dtype == CVMI_T16 && y_dtype == CVMI_T16) return launch_ln<f16, f16>(x, x_ld, gamma, beta, y, y_ld, rows, C, eps, act, pw, pwp, phw, phpwp, s);
   return launch_ln<f16, float>(x, x_ld, gamma, beta, y, y_ld, rows, C, eps, act, pw, pwp, phw, phpwp, s);
 }
 
-extern "C" int cvmi_layernorm_dual(const void* x, int x_ld, const float* gamma, const float* beta, void* y, int y_ld, void* y2, int y2_ld,
+#ifndef CVMI_OPERAND_BF16
+extern "C" int cvmi_layernorm_dual_bf16(const void* x, int x_ld, const float* gamma, const float* beta, void* y, int y_ld, void* y2, int y2_ld, int y2_dtype,
+                                   long long rows, int C, float eps, cvmi_stream_t stream_);
+#endif
+extern "C" int CVMI_ENTRY(cvmi_layernorm_dual)(const void* x, int x_ld, const float* gamma, const float* beta, void* y, int y_ld, void* y2, int y2_ld, int y2_dtype,
                                    long long rows, int C, float eps, cvmi_stream_t stream_) {
-  CVMI_CHECK(x && gamma && beta && y && y2 && rows > 0 && C > 0, "layernorm_dual: bad arguments");
+#ifndef CVMI_OPERAND_BF16
+  if (y2_dtype == CVMI_BF16) return cvmi_layernorm_dual_bf16(x, x_ld, gamma, beta, y, y_ld, y2, y2_ld, y2_dtype, rows, C, eps, stream_);
+#endif
+  CVMI_CHECK(x && gamma && beta && y && y2 && rows > 0 && C > 0 && y2_dtype == CVMI_T16, "layernorm_dual: bad arguments (y2_dtype must be a 16-bit type)");
   CVMI_CHECK(C % 8 == 0 && x_ld % 4 == 0 && y_ld % 4 == 0 && y2_ld % 8 == 0 && x_ld >= C && y_ld >= C && y2_ld >= C &&
              (((uintptr_t)x | (uintptr_t)y | (uintptr_t)y2 | (uintptr_t)gamma | (uintptr_t)beta) & 15) == 0, "layernorm_dual: C=%d / ld not 16-byte aligned", C);
   return launch_ln<float, float>(x, x_ld, gamma, beta, y, y_ld, rows, C, eps, CVMI_ACT_NONE, 0, 0, 0, 0, (hipStream_t)stream_, y2, y2_ld);
 }
 
-extern "C" int cvmi_maxpool2x2(const void* x, int x_ld, void* y, int y_ld, int B, int H, int W, int C, int dtype, cvmi_stream_t stream_) {
+#ifndef CVMI_OPERAND_BF16
+extern "C" int cvmi_maxpool2x2_bf16(const void* x, int x_ld, void* y, int y_ld, int B, int H, int W, int C, int dtype, cvmi_stream_t stream_);
+#endif
+extern "C" int CVMI_ENTRY(cvmi_maxpool2x2)(const void* x, int x_ld, void* y, int y_ld, int B, int H, int W, int C, int dtype, cvmi_stream_t stream_) {
+#ifndef CVMI_OPERAND_BF16
+  if (dtype == CVMI_BF16) return cvmi_maxpool2x2_bf16(x, x_ld, y, y_ld, B, H, W, C, dtype, stream_);
+#endif
   CVMI_CHECK(x && y && B > 0 && H > 0 && W > 0 && C > 0 && H % 2 == 0 && W % 2 == 0, "maxpool2x2: bad shape");
-  CVMI_CHECK(dtype == CVMI_F16 || dtype == CVMI_F32, "maxpool2x2: bad dtype");
-  const int vec = dtype == CVMI_F16 ? 8 : 4;
+  CVMI_CHECK(dtype == CVMI_T16 || dtype == CVMI_F32, "maxpool2x2: bad dtype");
+  const int vec = dtype == CVMI_T16 ? 8 : 4;
   CVMI_CHECK(C % vec == 0 && x_ld % vec == 0 && y_ld % vec == 0 && (((uintptr_t)x | (uintptr_t)y) & 15) == 0, "maxpool2x2: not 16-byte aligned");
   const long long total = (long long)B * (H / 2) * (W / 2) * (C / vec);
   hipStream_t s = (hipStream_t)stream_;
-  if (dtype == CVMI_F16) hipLaunchKernelGGL(maxpool2_kernel<f16>, dim3(grid_for(total)), dim3(256), 0, s, (const char*)x, x_ld, (char*)y, y_ld, B, H, W, C);
+  if (dtype == CVMI_T16) hipLaunchKernelGGL(maxpool2_kernel<f16>, dim3(grid_for(total)), dim3(256), 0, s, (const char*)x, x_ld, (char*)y, y_ld, B, H, W, C);
   else hipLaunchKernelGGL(maxpool2_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, (const char*)x, x_ld, (char*)y, y_ld, B, H, W, C);
   CVMI_LAUNCH_CHECK();
   return 0;
 }
 
-extern "C" int cvmi_cast(const void* x, int x_ld, int x_dtype, void* y, int y_ld, int y_dtype, long long rows, int C, cvmi_stream_t stream_) {
+#ifndef CVMI_OPERAND_BF16
+extern "C" int cvmi_cast_bf16(const void* x, int x_ld, int x_dtype, void* y, int y_ld, int y_dtype, long long rows, int C, cvmi_stream_t stream_);
+#endif
+extern "C" int CVMI_ENTRY(cvmi_cast)(const void* x, int x_ld, int x_dtype, void* y, int y_ld, int y_dtype, long long rows, int C, cvmi_stream_t stream_) {
+#ifndef CVMI_OPERAND_BF16
+  if (x_dtype == CVMI_BF16 || y_dtype == CVMI_BF16) return cvmi_cast_bf16(x, x_ld, x_dtype, y, y_ld, y_dtype, rows, C, stream_);
+#endif
   CVMI_CHECK(x && y && rows > 0 && C > 0 && x_ld >= C && y_ld >= C, "cast: bad arguments");
   hipStream_t s = (hipStream_t)stream_;
   const dim3 g(grid_for(rows * C)), b(256);
-  if (x_dtype == CVMI_F32 && y_dtype == CVMI_F16) hipLaunchKernelGGL((cast_kernel<float, f16>), g, b, 0, s, (const float*)x, x_ld, (f16*)y, y_ld, rows, C);
-  else if (x_dtype == CVMI_F16 && y_dtype == CVMI_F32) hipLaunchKernelGGL((cast_kernel<f16, float>), g, b, 0, s, (const f16*)x, x_ld, (float*)y, y_ld, rows, C);
+  if (x_dtype == CVMI_F32 && y_dtype == CVMI_T16) hipLaunchKernelGGL((cast_kernel<float, f16>), g, b, 0, s, (const float*)x, x_ld, (f16*)y, y_ld, rows, C);
+  else if (x_dtype == CVMI_T16 && y_dtype == CVMI_F32) hipLaunchKernelGGL((cast_kernel<f16, float>), g, b, 0, s, (const f16*)x, x_ld, (float*)y, y_ld, rows, C);
   else if (x_dtype == CVMI_F32 && y_dtype == CVMI_F32) hipLaunchKernelGGL((cast_kernel<float, float>), g, b, 0, s, (const float*)x, x_ld, (float*)y, y_ld, rows, C);
-  else if (x_dtype == CVMI_F16 && y_dtype == CVMI_F16) hipLaunchKernelGGL((cast_kernel<f16, f16>), g, b, 0, s, (const f16*)x, x_ld, (f16*)y, y_ld, rows, C);
+  else if (x_dtype == CVMI_T16 && y_dtype == CVMI_T16) hipLaunchKernelGGL((cast_kernel<f16, f16>), g, b, 0, s, (const f16*)x, x_ld, (f16*)y, y_ld, rows, C);
   else CVMI_FAIL("cast: bad dtypes");
   CVMI_LAUNCH_CHECK();
   return 0;
 }
 
-extern "C" int cvmi_prompt_tokens(const float* coords, const int* labels, const float* gauss, const float* out_tokens, const float* table,
+#ifndef CVMI_OPERAND_BF16
+extern "C" int cvmi_prompt_tokens_bf16(const float* coords, const int* labels, const float* gauss, const float* out_tokens, const float* table,
+                                  float image_size, float* tokens_f32, void* tokens_lp, int dtype, int n, int K, int T0, cvmi_stream_t stream_);
+#endif
+extern "C" int CVMI_ENTRY(cvmi_prompt_tokens)(const float* coords, const int* labels, const float* gauss, const float* out_tokens, const float* table,
                                   float image_size, float* tokens_f32, void* tokens_lp, int dtype, int n, int K, int T0, cvmi_stream_t stream_) {
+#ifndef CVMI_OPERAND_BF16
+  if (dtype == CVMI_BF16) return cvmi_prompt_tokens_bf16(coords, labels, gauss, out_tokens, table, image_size, tokens_f32, tokens_lp, dtype, n, K, T0, stream_);
+#endif
   CVMI_CHECK(coords && labels && gauss && out_tokens && table && tokens_f32 && n > 0 && K > 0 && T0 >= 0 && image_size > 0.f, "prompt_tokens: bad arguments");
-  CVMI_CHECK(!tokens_lp || dtype == CVMI_F16 || dtype == CVMI_F32, "prompt_tokens: bad dtype");
+  CVMI_CHECK(!tokens_lp || dtype == CVMI_T16 || dtype == CVMI_F32, "prompt_tokens: bad dtype");
   hipStream_t s = (hipStream_t)stream_;
   const dim3 g(n), b(256);
   const float inv = image_size;
-  if (tokens_lp && dtype == CVMI_F16)
+  if (tokens_lp && dtype == CVMI_T16)
     hipLaunchKernelGGL(prompt_tokens_kernel<f16>, g, b, 0, s, coords, labels, gauss, out_tokens, table, inv, tokens_f32, (f16*)tokens_lp, K, T0);
   else
     hipLaunchKernelGGL(prompt_tokens_kernel<float>, g, b, 0, s, coords, labels, gauss, out_tokens, table, inv, tokens_f32, (float*)tokens_lp, K, T0);
@@ -647,6 +680,7 @@ extern "C" int cvmi_prompt_tokens(const float* coords, const int* labels, const 
   return 0;
 }
 
+#ifndef CVMI_OPERAND_BF16
 extern "C" int cvmi_repeat_images(const void* src, void* dst, long long bytes_per_image, int B, int rep, cvmi_stream_t stream_) {
   CVMI_CHECK(src && dst && bytes_per_image > 0 && bytes_per_image % 16 == 0 && B > 0 && B <= 65535 && rep > 0, "repeat_images: bad arguments");
   CVMI_CHECK((((uintptr_t)src | (uintptr_t)dst) & 15) == 0, "repeat_images: pointers must be 16-byte aligned");
@@ -656,21 +690,30 @@ extern "C" int cvmi_repeat_images(const void* src, void* dst, long long bytes_pe
   CVMI_LAUNCH_CHECK();
   return 0;
 }
+#endif
 
-extern "C" int cvmi_hyper_masks(const float* hyper, int hyper_ld, const void* up, int up_ld, int up_dtype, int C, float* masks, int* areas, int B,
+#ifndef CVMI_OPERAND_BF16
+extern "C" int cvmi_hyper_masks_bf16(const float* hyper, int hyper_ld, const void* up, int up_ld, int up_dtype, int C, float* masks, int* areas, int B,
+                                int P, float delta, cvmi_stream_t stream_);
+#endif
+extern "C" int CVMI_ENTRY(cvmi_hyper_masks)(const float* hyper, int hyper_ld, const void* up, int up_ld, int up_dtype, int C, float* masks, int* areas, int B,
                                 int P, float delta, cvmi_stream_t stream_) {
+#ifndef CVMI_OPERAND_BF16
+  if (up_dtype == CVMI_BF16) return cvmi_hyper_masks_bf16(hyper, hyper_ld, up, up_ld, up_dtype, C, masks, areas, B, P, delta, stream_);
+#endif
   CVMI_CHECK(hyper && up && masks && areas && B > 0 && P > 0 && C > 0 && C <= 64 && hyper_ld >= C && up_ld >= C, "hyper_masks: bad arguments");
-  CVMI_CHECK(up_dtype == CVMI_F16 || up_dtype == CVMI_F32, "hyper_masks: bad dtype");
+  CVMI_CHECK(up_dtype == CVMI_T16 || up_dtype == CVMI_F32, "hyper_masks: bad dtype");
   hipStream_t s = (hipStream_t)stream_;
   // a kernel, not hipMemsetAsync: a memset node of this small size did not replay reliably inside a captured graph
   hipLaunchKernelGGL(zero_i32_kernel, dim3((2 * B + 255) / 256), dim3(256), 0, s, areas, 2 * B);
   const dim3 g(grid_for(P, 256, 64), B), b(256);
-  if (up_dtype == CVMI_F16) hipLaunchKernelGGL(hyper_masks_kernel<f16>, g, b, 0, s, hyper, hyper_ld, (const f16*)up, up_ld, C, masks, areas, P, delta);
+  if (up_dtype == CVMI_T16) hipLaunchKernelGGL(hyper_masks_kernel<f16>, g, b, 0, s, hyper, hyper_ld, (const f16*)up, up_ld, C, masks, areas, P, delta);
   else hipLaunchKernelGGL(hyper_masks_kernel<float>, g, b, 0, s, hyper, hyper_ld, (const float*)up, up_ld, C, masks, areas, P, delta);
   CVMI_LAUNCH_CHECK();
   return 0;
 }
 
+#ifndef CVMI_OPERAND_BF16
 extern "C" int cvmi_select_mask(const float* masks, const int* areas, const float* iou, int iou_ld, int dynamic, float thresh, float* low_res,
                                 float* iou_out, int* sel, int B, int P, cvmi_stream_t stream_) {
   CVMI_CHECK(masks && areas && iou && low_res && iou_out && sel && B > 0 && P > 0 && iou_ld >= 4, "select_mask: bad arguments");
@@ -679,7 +722,9 @@ extern "C" int cvmi_select_mask(const float* masks, const int* areas, const floa
   CVMI_LAUNCH_CHECK();
   return 0;
 }
+#endif
 
+#ifndef CVMI_OPERAND_BF16
 extern "C" int cvmi_bilinear_f32(const float* x, int N, int h, int w, float* y, int H, int W, uint8_t* mask_u8, float thresh, cvmi_stream_t stream_) {
   CVMI_CHECK(x && (y || mask_u8) && N > 0 && N <= 65535 && h > 0 && w > 0 && H > 0 && W > 0, "bilinear: bad arguments");
   hipLaunchKernelGGL(bilinear_kernel, dim3(grid_for((long long)H * W, 256, 1024), N), dim3(256), 0, (hipStream_t)stream_, x, h, w, y, H, W, mask_u8,
@@ -687,7 +732,9 @@ extern "C" int cvmi_bilinear_f32(const float* x, int N, int h, int w, float* y, 
   CVMI_LAUNCH_CHECK();
   return 0;
 }
+#endif
 
+#ifndef CVMI_OPERAND_BF16
 extern "C" int cvmi_mask_postprocess(const float* x, int N, int h, int w, int H, int W, float thresh, uint8_t* mask_u8, int* extent,
                                      cvmi_stream_t stream_) {
   CVMI_CHECK(x && mask_u8 && extent && N > 0 && N <= 65535 && h > 0 && w > 0 && H > 0 && W > 0, "mask_postprocess: bad arguments");
@@ -698,18 +745,26 @@ extern "C" int cvmi_mask_postprocess(const float* x, int N, int h, int w, int H,
   CVMI_LAUNCH_CHECK();
   return 0;
 }
+#endif
 
-extern "C" int cvmi_space_to_depth4(const void* x, void* y, int B, int H, int W, int dtype, cvmi_stream_t stream_) {
+#ifndef CVMI_OPERAND_BF16
+extern "C" int cvmi_space_to_depth4_bf16(const void* x, void* y, int B, int H, int W, int dtype, cvmi_stream_t stream_);
+#endif
+extern "C" int CVMI_ENTRY(cvmi_space_to_depth4)(const void* x, void* y, int B, int H, int W, int dtype, cvmi_stream_t stream_) {
+#ifndef CVMI_OPERAND_BF16
+  if (dtype == CVMI_BF16) return cvmi_space_to_depth4_bf16(x, y, B, H, W, dtype, stream_);
+#endif
   CVMI_CHECK(x && y && B > 0 && H > 0 && W > 0 && H % 4 == 0 && W % 4 == 0, "space_to_depth4: bad shape");
-  CVMI_CHECK(dtype == CVMI_F16 || dtype == CVMI_F32, "space_to_depth4: bad dtype");
+  CVMI_CHECK(dtype == CVMI_T16 || dtype == CVMI_F32, "space_to_depth4: bad dtype");
   const long long blocks = (long long)B * (H / 4) * (W / 4);
   const dim3 g(grid_for(blocks * 4)), b(256);
-  if (dtype == CVMI_F16) hipLaunchKernelGGL(s2d4_kernel<f16>, g, b, 0, (hipStream_t)stream_, (const f16*)x, (f16*)y, blocks, H, W);
+  if (dtype == CVMI_T16) hipLaunchKernelGGL(s2d4_kernel<f16>, g, b, 0, (hipStream_t)stream_, (const f16*)x, (f16*)y, blocks, H, W);
   else hipLaunchKernelGGL(s2d4_kernel<float>, g, b, 0, (hipStream_t)stream_, (const float*)x, (float*)y, blocks, H, W);
   CVMI_LAUNCH_CHECK();
   return 0;
 }
 
+#ifndef CVMI_OPERAND_BF16
 extern "C" int cvmi_mask_extent(const uint8_t* mask, int N, int H, int W, int* extent, cvmi_stream_t stream_) {
   CVMI_CHECK(mask && extent && N > 0 && N <= 65535 && H > 0 && W > 0, "mask_extent: bad arguments");
   hipStream_t s = (hipStream_t)stream_;
@@ -718,7 +773,9 @@ extern "C" int cvmi_mask_extent(const uint8_t* mask, int N, int H, int W, int* e
   CVMI_LAUNCH_CHECK();
   return 0;
 }
+#endif
 
+#ifndef CVMI_OPERAND_BF16
 extern "C" int cvmi_upsample_refine(const float* low, int N, int h, int w, float* high, int H, int W, const float* params, const int* ks, int nk,
                                     int ic, cvmi_stream_t stream_) {
   CVMI_CHECK(low && high && params && ks && N > 0 && h > 0 && w > 0 && H > 0 && W > 0, "upsample_refine: bad arguments");
@@ -748,15 +805,22 @@ extern "C" int cvmi_upsample_refine(const float* low, int N, int h, int w, float
   CVMI_LAUNCH_CHECK();
   return 0;
 }
+#endif
 
-extern "C" int cvmi_sam2_transform(const uint8_t* src, int H, int W, void* dst, int R, int dst_dtype, cvmi_stream_t stream_) {
+#ifndef CVMI_OPERAND_BF16
+extern "C" int cvmi_sam2_transform_bf16(const uint8_t* src, int H, int W, void* dst, int R, int dst_dtype, cvmi_stream_t stream_);
+#endif
+extern "C" int CVMI_ENTRY(cvmi_sam2_transform)(const uint8_t* src, int H, int W, void* dst, int R, int dst_dtype, cvmi_stream_t stream_) {
+#ifndef CVMI_OPERAND_BF16
+  if (dst_dtype == CVMI_BF16) return cvmi_sam2_transform_bf16(src, H, W, dst, R, dst_dtype, stream_);
+#endif
   CVMI_CHECK(src && dst && H > 0 && W > 0 && R > 0, "sam2_transform: bad arguments");
-  CVMI_CHECK(dst_dtype == CVMI_F16 || dst_dtype == CVMI_F32, "sam2_transform: bad dtype");
+  CVMI_CHECK(dst_dtype == CVMI_T16 || dst_dtype == CVMI_F32, "sam2_transform: bad dtype");
   const float sy = (float)H / (float)R, sx = (float)W / (float)R;
   CVMI_CHECK(2.f * (sy > 1.f ? sy : 1.f) + 2.f <= AA_MAXTAPS && 2.f * (sx > 1.f ? sx : 1.f) + 2.f <= AA_MAXTAPS, "sam2_transform: down-scale factor too large");
   hipStream_t s = (hipStream_t)stream_;
   const dim3 g(grid_for((long long)R * R)), b(256);
-  if (dst_dtype == CVMI_F16) hipLaunchKernelGGL(sam2_transform_kernel<f16>, g, b, 0, s, src, H, W, (f16*)dst, R, sy, sx);
+  if (dst_dtype == CVMI_T16) hipLaunchKernelGGL(sam2_transform_kernel<f16>, g, b, 0, s, src, H, W, (f16*)dst, R, sy, sx);
   else hipLaunchKernelGGL(sam2_transform_kernel<float>, g, b, 0, s, src, H, W, (float*)dst, R, sy, sx);
   CVMI_LAUNCH_CHECK();
   return 0;

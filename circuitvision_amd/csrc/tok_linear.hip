@@ -104,7 +104,7 @@ __global__ __launch_bounds__(TL_NW * 64, 2) void tok_linear_kernel(const void* _
     for (int k = 0; k < KS; ++k) xn[k] = *reinterpret_cast<const u32x4*>(xr + 16 * k + 8 * lh);
   }
   {
-    const u32x4 one = {lh == 0 ? 0x3C003C00u : 0u, 0u, 0u, 0u};   // bias step: constant-1 columns k = K, K + 1
+    const u32x4 one = {lh == 0 ? CVMI_ONE16X2 : 0u, 0u, 0u, 0u};   // bias step: constant-1 columns k = K, K + 1
     xn[KS] = one;
   }
 
@@ -117,7 +117,10 @@ __global__ __launch_bounds__(TL_NW * 64, 2) void tok_linear_kernel(const void* _
   auto res_load = [&](int j) {
     const float* o = reinterpret_cast<const float*>(out) + row * (long long)out_ld + 32 * j + 4 * lh;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) r4[g] = *reinterpret_cast<const f32x4*>(o + 8 * g);
+    for (int g = 0; g < 4; ++g) {                              // (the last chunk of N = 144 is half a chunk: no read past the row's end --
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};                     //  for the buffer's last row that would be a read past the allocation)
+      r4[g] = 32 * j + 8 * g + 4 * lh < N ? *reinterpret_cast<const f32x4*>(o + 8 * g) : z;
+    }
   };
   auto epilogue = [&](const f32x16& acc, int j) {
     if constexpr (RES) {
@@ -185,7 +188,7 @@ __global__ __launch_bounds__(TL_NW * 64, 2) void tok_linear_kernel(const void* _
         default: asm volatile("s_waitcnt lgkmcnt(7)" : "+v"(ring[f % PF])); break;
       }
       const f16x8 a = __builtin_bit_cast(f16x8, ring[f % PF]);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, __builtin_bit_cast(f16x8, xn[f]), acc, 0, 0, 0);
+      acc = CVMI_MFMA_32X32X16(a, __builtin_bit_cast(f16x8, xn[f]), acc, 0, 0, 0);
       if (f + PF < KS1) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(ring[f % PF]) : "v"(lbase), "i"((f + PF) * 1024));
       if constexpr (RES) { if (f == KS1 / 2 && j > 0) epilogue(prev, j - 1); }
     }
@@ -225,20 +228,30 @@ int dispatch_tl(bool ln, bool res, int act, const void* in, int in_ld, const flo
 
 }  // namespace
 
+#ifndef CVMI_OPERAND_BF16
 extern "C" int cvmi_tok_linear_supported(int K) { return K == 144 || K == 288 || K == 576; }
 
 extern "C" size_t cvmi_tok_linear_packed_bytes(int K, int N) {
   if (!cvmi_tok_linear_supported(K) || N <= 0) return 0;
   return (size_t)(((N + 31) / 32 + 1) / 2 * 2) * (size_t)(K / 16 + 1) * 1024;        // chunk count padded to even
 }
+extern "C" int cvmi_tok_linear_bf16(const void* in, int in_ld, int in_f32_layernorm, const float* gamma, const float* beta, float eps,
+                                    const void* w_packed, void* out, int out_ld, int out_f32_residual, long long rows, int K, int N, int act,
+                                    int dtype, cvmi_stream_t stream_);
+#endif
 
-extern "C" int cvmi_tok_linear(const void* in, int in_ld, int in_f32_layernorm, const float* gamma, const float* beta, float eps,
-                               const void* w_packed, void* out, int out_ld, int out_f32_residual, long long rows, int K, int N, int act,
-                               cvmi_stream_t stream_) {
+extern "C" int CVMI_ENTRY(cvmi_tok_linear)(const void* in, int in_ld, int in_f32_layernorm, const float* gamma, const float* beta, float eps,
+                                           const void* w_packed, void* out, int out_ld, int out_f32_residual, long long rows, int K, int N, int act,
+                                           int dtype, cvmi_stream_t stream_) {
+#ifndef CVMI_OPERAND_BF16
+  if (dtype == CVMI_BF16)
+    return cvmi_tok_linear_bf16(in, in_ld, in_f32_layernorm, gamma, beta, eps, w_packed, out, out_ld, out_f32_residual, rows, K, N, act, dtype, stream_);
+#endif
+  CVMI_CHECK(dtype == CVMI_T16, "tok_linear: dtype must be CVMI_F16 or CVMI_BF16");
   CVMI_CHECK(in && w_packed && out && rows > 0 && rows % 256 == 0 && N > 0, "tok_linear: bad arguments (rows must be a multiple of 256)");
-  CVMI_CHECK(cvmi_tok_linear_supported(K), "tok_linear: K=%d is not built (144, 288, 576)", K);
+  CVMI_CHECK(K == 144 || K == 288 || K == 576, "tok_linear: K=%d is not built (144, 288, 576)", K);
   CVMI_CHECK(!in_f32_layernorm || (gamma && beta), "tok_linear: LayerNorm input needs gamma / beta");
-  CVMI_CHECK(act == CVMI_ACT_NONE || (act == CVMI_ACT_GELU && !out_f32_residual), "tok_linear: act must be NONE, or GELU with fp16 output");
+  CVMI_CHECK(act == CVMI_ACT_NONE || (act == CVMI_ACT_GELU && !out_f32_residual), "tok_linear: act must be NONE, or GELU with 16-bit output");
   CVMI_CHECK(in_ld >= K && in_ld % (in_f32_layernorm ? 4 : 8) == 0 && out_ld >= N && out_ld % 4 == 0 && N % 4 == 0 &&
                  (((uintptr_t)in | (uintptr_t)w_packed | (uintptr_t)out) & 15) == 0 &&
                  (!in_f32_layernorm || (((uintptr_t)gamma | (uintptr_t)beta) & 15) == 0),

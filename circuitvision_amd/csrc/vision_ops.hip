@@ -389,6 +389,7 @@ inline int grid_for(long long total, int block = 256) {
 
 }  // namespace
 
+#ifndef CVMI_OPERAND_BF16
 extern "C" int cvmi_dwconv3x3(const void* x, int x_ld, const void* w, const float* bias, const void* res, int res_ld, void* y, int y_ld,
                               int B, int H, int W, int C, int act, int dtype, cvmi_stream_t stream_) {
   CVMI_CHECK(x && w && bias && y, "dwconv3x3: null pointer");
@@ -410,7 +411,9 @@ extern "C" int cvmi_dwconv3x3(const void* x, int x_ld, const void* w, const floa
   CVMI_LAUNCH_CHECK();
   return 0;
 }
+#endif
 
+#ifndef CVMI_OPERAND_BF16
 extern "C" int cvmi_sppf_pool(void* buf, int ld, int B, int H, int W, int C, int dtype, cvmi_stream_t stream_) {
   CVMI_CHECK(buf, "sppf_pool: null pointer");
   CVMI_CHECK(dtype == CVMI_F16 || dtype == CVMI_F32, "sppf_pool: bad dtype");
@@ -431,7 +434,9 @@ extern "C" int cvmi_sppf_pool(void* buf, int ld, int B, int H, int W, int C, int
   CVMI_LAUNCH_CHECK();
   return 0;
 }
+#endif
 
+#ifndef CVMI_OPERAND_BF16
 extern "C" int cvmi_detect_decode(const void* const* box, const int* box_ld, const void* const* cls, const int* cls_ld, const int* hs,
                                   const int* ws, const float* strides, int nlevels, int B, int nc, int dtype, float* pred,
                                   float* best_score, int* best_cls, int write_cls, cvmi_stream_t stream_) {
@@ -468,7 +473,9 @@ extern "C" int cvmi_detect_decode(const void* const* box, const int* box_ld, con
   CVMI_LAUNCH_CHECK();
   return 0;
 }
+#endif
 
+#ifndef CVMI_OPERAND_BF16
 extern "C" int cvmi_letterbox(const uint8_t* src, int H, int W, void* dst, int out_h, int out_w, int new_h, int new_w, int top, int left,
                               int dtype, int s2d, cvmi_stream_t stream_) {
   CVMI_CHECK(!s2d || (out_h % 2 == 0 && out_w % 2 == 0), "letterbox: space-to-depth output needs even out_h, out_w");
@@ -485,22 +492,34 @@ extern "C" int cvmi_letterbox(const uint8_t* src, int H, int W, void* dst, int o
   CVMI_LAUNCH_CHECK();
   return 0;
 }
+#endif
 
-extern "C" int cvmi_nchw_to_nhwc(const void* src, int src_dtype, void* dst, int dst_dtype, int dst_ld, int B, int C, int H, int W,
+#ifndef CVMI_OPERAND_BF16
+#ifndef CVMI_OPERAND_BF16
+extern "C" int cvmi_nchw_to_nhwc_bf16(const void* src, int src_dtype, void* dst, int dst_dtype, int dst_ld, int B, int C, int H, int W,
+                                      cvmi_stream_t stream_);
+#endif
+#endif
+
+extern "C" int CVMI_ENTRY(cvmi_nchw_to_nhwc)(const void* src, int src_dtype, void* dst, int dst_dtype, int dst_ld, int B, int C, int H, int W,
                                  cvmi_stream_t stream_) {
+#ifndef CVMI_OPERAND_BF16
+  if (src_dtype == CVMI_BF16 || dst_dtype == CVMI_BF16) return cvmi_nchw_to_nhwc_bf16(src, src_dtype, dst, dst_dtype, dst_ld, B, C, H, W, stream_);
+#endif
   CVMI_CHECK(src && dst && B > 0 && C > 0 && H > 0 && W > 0 && dst_ld >= C, "nchw_to_nhwc: bad arguments");
   hipStream_t stream = (hipStream_t)stream_;
   const long long total = (long long)B * C * H * W;
   const dim3 g(grid_for(total)), b(256);
-  if (src_dtype == CVMI_F32 && dst_dtype == CVMI_F16) hipLaunchKernelGGL((nchw_to_nhwc_kernel<float, f16>), g, b, 0, stream, (const float*)src, (f16*)dst, dst_ld, B, C, H, W);
+  if (src_dtype == CVMI_F32 && dst_dtype == CVMI_T16) hipLaunchKernelGGL((nchw_to_nhwc_kernel<float, f16>), g, b, 0, stream, (const float*)src, (f16*)dst, dst_ld, B, C, H, W);
   else if (src_dtype == CVMI_F32 && dst_dtype == CVMI_F32) hipLaunchKernelGGL((nchw_to_nhwc_kernel<float, float>), g, b, 0, stream, (const float*)src, (float*)dst, dst_ld, B, C, H, W);
-  else if (src_dtype == CVMI_F16 && dst_dtype == CVMI_F16) hipLaunchKernelGGL((nchw_to_nhwc_kernel<f16, f16>), g, b, 0, stream, (const f16*)src, (f16*)dst, dst_ld, B, C, H, W);
-  else if (src_dtype == CVMI_F16 && dst_dtype == CVMI_F32) hipLaunchKernelGGL((nchw_to_nhwc_kernel<f16, float>), g, b, 0, stream, (const f16*)src, (float*)dst, dst_ld, B, C, H, W);
+  else if (src_dtype == CVMI_T16 && dst_dtype == CVMI_T16) hipLaunchKernelGGL((nchw_to_nhwc_kernel<f16, f16>), g, b, 0, stream, (const f16*)src, (f16*)dst, dst_ld, B, C, H, W);
+  else if (src_dtype == CVMI_T16 && dst_dtype == CVMI_F32) hipLaunchKernelGGL((nchw_to_nhwc_kernel<f16, float>), g, b, 0, stream, (const f16*)src, (float*)dst, dst_ld, B, C, H, W);
   else CVMI_FAIL("nchw_to_nhwc: bad dtypes %d -> %d", src_dtype, dst_dtype);
   CVMI_LAUNCH_CHECK();
   return 0;
 }
 
+#ifndef CVMI_OPERAND_BF16
 extern "C" int cvmi_nhwc_to_nchw_f32(const void* src, int src_dtype, int src_ld, float* dst, int B, int C, int H, int W, cvmi_stream_t stream_) {
   CVMI_CHECK(src && dst && B > 0 && C > 0 && H > 0 && W > 0 && src_ld >= C, "nhwc_to_nchw: bad arguments");
   hipStream_t stream = (hipStream_t)stream_;
@@ -512,3 +531,5 @@ extern "C" int cvmi_nhwc_to_nchw_f32(const void* src, int src_dtype, int src_ld,
   CVMI_LAUNCH_CHECK();
   return 0;
 }
+#endif
+

@@ -10,10 +10,16 @@ import threading
 import torch
 
 from . import _lib
-from ._lib import F16, F32, AttnDesc, C3k2Desc, ConvDesc
+from ._lib import BF16, F16, F32, AttnDesc, C3k2Desc, ConvDesc
 
-TORCH_DTYPE = {F16: torch.float16, F32: torch.float32}
-ESIZE = {F16: 2, F32: 4}
+TORCH_DTYPE = {F16: torch.float16, F32: torch.float32, BF16: torch.bfloat16}
+ESIZE = {F16: 2, F32: 4, BF16: 2}
+DTYPE_OF = {torch.float16: F16, torch.float32: F32, torch.bfloat16: BF16}
+
+
+def is16(dtype):
+    """16-bit operand storage (fp16 or bf16): fp32 accumulation, f32 residual streams beside it."""
+    return dtype in (F16, BF16)
 
 
 def require_gpu():
@@ -233,7 +239,7 @@ def op_conv(plan, label, pc, srcs, dst, stride=1, pad=None, act=_lib.ACT_NONE, r
     if res_rep > 1:
         assert res is not None and res.B * res_rep == v0.B, (label, "res_rep needs a per-image residual")
         assert shuffle_cout or res_mod == dst.H * dst.W, (label, "res_rep: ConvTranspose scatter or res_mod = rows per image")
-    out_f32 = 1 if (dst.dtype == F32 and pc.dtype == F16) else 0
+    out_f32 = 1 if (dst.dtype == F32 and is16(pc.dtype)) else 0
     d = ConvDesc(
         x0=v0.ptr, x1=(v1.ptr if v1 is not None else None), w=pc.w.data_ptr(), bias=pc.bias.data_ptr(),
         res=(res.ptr if res is not None else None), y=dst.ptr,
@@ -391,7 +397,7 @@ class Rows:
         self.t, self.rows, self.C = t, rows, C
         self.ld = ld if ld is not None else C
         self.offset = offset
-        self.dtype = dtype if dtype is not None else (F16 if t.dtype == torch.float16 else F32)
+        self.dtype = dtype if dtype is not None else DTYPE_OF[t.dtype]
 
     @property
     def ptr(self):
@@ -406,9 +412,9 @@ def op_layernorm(plan, label, src, gamma, beta, dst, eps=1e-6, act=_lib.ACT_NONE
     assert src.C == dst.C == gamma.numel()
     if dst2 is not None:
         dst2 = _as_rows(dst2)
-        assert pad is None and act == _lib.ACT_NONE and src.dtype == dst.dtype == _lib.F32 and dst2.dtype == _lib.F16
+        assert pad is None and act == _lib.ACT_NONE and src.dtype == dst.dtype == _lib.F32 and is16(dst2.dtype)
         assert dst2.rows == src.rows and dst2.C == src.C
-        args2 = (src.ptr, src.ld, gamma.data_ptr(), beta.data_ptr(), dst.ptr, dst.ld, dst2.ptr, dst2.ld, src.rows, src.C, float(eps))
+        args2 = (src.ptr, src.ld, gamma.data_ptr(), beta.data_ptr(), dst.ptr, dst.ld, dst2.ptr, dst2.ld, dst2.dtype, src.rows, src.C, float(eps))
         plan.keep.append((src, dst, dst2, gamma, beta))
         sp1, fn2 = plan.sptr, lib.cvmi_layernorm_dual
 
@@ -485,19 +491,20 @@ def op_call(plan, label, kind, fn, args, keep=(), bytes_=0, flops=0):
 
 # ---- fused Hiera MLP (hiera_mlp.hip) ---------------------------------------------------------------------------------------
 def hiera_mlp_supported(C_, dtype):
-    return dtype == F16 and bool(_lib.load().cvmi_hiera_mlp_supported(C_))
+    return is16(dtype) and bool(_lib.load().cvmi_hiera_mlp_supported(C_))
 
 
 class PackedHieraMlp:
     """fc1 / fc2 of one Hiera block in the MFMA-fragment order cvmi_hiera_mlp streams (include/cvmi355.h)."""
 
-    def __init__(self, w1, b1, w2, b2, device="cuda"):
-        # w1 [4C, C], b1 [4C], w2 [C, 4C], b2 [C]  (float32, LoRA already merged)
+    def __init__(self, w1, b1, w2, b2, device="cuda", dtype=F16):
+        # w1 [4C, C], b1 [4C], w2 [C, 4C], b2 [C]  (float32, LoRA already merged); dtype: F16 or BF16 operands
+        td = TORCH_DTYPE[dtype]
         Hd, C_ = w1.shape
         assert Hd == 4 * C_ and tuple(w2.shape) == (C_, Hd) and C_ % 16 == 0
         ks1, nt, nch = C_ // 16 + 1, (C_ + 31) // 32, Hd // 32
-        b_hi = b1.to(torch.float16).float()
-        b_lo = (b1 - b_hi).to(torch.float16).float()
+        b_hi = b1.to(td).float()
+        b_lo = (b1 - b_hi).to(td).float()
         w1x = torch.cat((w1, b_hi[:, None], b_lo[:, None], torch.zeros(Hd, 14)), 1)              # [4C, C + 16]
         f1 = w1x.view(nch, 32, ks1, 2, 8).permute(0, 2, 3, 1, 4)                                   # (j, s, h, r, e)
         w2p = torch.zeros(nt * 32, Hd)
@@ -505,9 +512,9 @@ class PackedHieraMlp:
         f2 = w2p.view(nt, 32, nch, 2, 2, 2, 4).permute(2, 0, 3, 5, 1, 4, 6)                        # (j, t, s2, h, r, e_hi, e_lo)
         packed = torch.cat((f1.reshape(nch, -1), f2.reshape(nch, -1)), 1).contiguous()
         assert packed.numel() * 2 == _lib.load().cvmi_hiera_mlp_packed_bytes(C_)
-        self.w = packed.to(torch.float16).to(device)
+        self.w = packed.to(td).to(device)
         self.bias = b2.float().contiguous().to(device)          # (.w / .bias: what distributed.packed_tensors broadcasts)
-        self.C = C_
+        self.C, self.dtype = C_, dtype
         self.param_bytes = 2 * Hd * C_ * 2
 
 
@@ -516,7 +523,7 @@ def op_hiera_mlp(plan, label, pm, x, gamma, beta, eps=1e-6):
     lib = _lib.load()
     assert x.dtype == F32 and x.c == pm.C and x.c0 == 0
     rows = x.B * x.H * x.W
-    args = (x.ptr, x.ld, gamma.data_ptr(), beta.data_ptr(), float(eps), pm.w.data_ptr(), pm.bias.data_ptr(), rows, pm.C)
+    args = (x.ptr, x.ld, gamma.data_ptr(), beta.data_ptr(), float(eps), pm.w.data_ptr(), pm.bias.data_ptr(), rows, pm.C, pm.dtype)
     plan.keep.append((pm, x, gamma, beta))
     sp0, fn = plan.sptr, lib.cvmi_hiera_mlp
 
@@ -529,26 +536,27 @@ def op_hiera_mlp(plan, label, pm, x, gamma, beta, eps=1e-6):
 
 # ---- token-stationary linear layer (tok_linear.hip) ------------------------------------------------------------------------
 def tok_linear_supported(K, dtype, rows):
-    return dtype == F16 and rows % 256 == 0 and bool(_lib.load().cvmi_tok_linear_supported(K))
+    return is16(dtype) and rows % 256 == 0 and bool(_lib.load().cvmi_tok_linear_supported(K))
 
 
 class PackedTokLinear:
     """One linear layer in the MFMA-fragment order cvmi_tok_linear streams (include/cvmi355.h); the bias rides in the weights."""
 
-    def __init__(self, w, b, device="cuda"):
-        N, K = w.shape                                       # float32, LoRA already merged
+    def __init__(self, w, b, device="cuda", dtype=F16):
+        N, K = w.shape                                       # float32, LoRA already merged; dtype: F16 or BF16 operands
+        td = TORCH_DTYPE[dtype]
         assert K % 16 == 0
         ks1, nch = K // 16 + 1, ((N + 31) // 32 + 1) // 2 * 2       # chunk count padded to even (the kernel may take two per barrier)
         b = b if b is not None else torch.zeros(N)
-        b_hi = b.to(torch.float16).float()
-        b_lo = (b - b_hi).to(torch.float16).float()
+        b_hi = b.to(td).float()
+        b_lo = (b - b_hi).to(td).float()
         wx = torch.zeros(nch * 32, K + 16)
         wx[:N, :K], wx[:N, K], wx[:N, K + 1] = w, b_hi, b_lo
         packed = wx.view(nch, 32, ks1, 2, 8).permute(0, 2, 3, 1, 4).contiguous()                  # (j, s, h, r, e)
         assert packed.numel() * 2 == _lib.load().cvmi_tok_linear_packed_bytes(K, N)
-        self.w = packed.to(torch.float16).to(device)
+        self.w = packed.to(td).to(device)
         self.bias = torch.zeros(4, device=device)             # (placeholder: distributed.packed_tensors expects .w / .bias)
-        self.N, self.K = N, K
+        self.N, self.K, self.dtype = N, K, dtype
         self.param_bytes = N * K * 2
 
 
@@ -558,9 +566,10 @@ def op_tok_linear(plan, label, pt, src, dst, ln=None, act=_lib.ACT_NONE, residua
     src, dst = _as_rows(src), _as_rows(dst)
     assert src.C == pt.K and dst.C == pt.N and src.rows == dst.rows and src.rows % 256 == 0, label
     assert (src.dtype == F32) == (ln is not None) and (dst.dtype == F32) == bool(residual), label
+    assert (ln is not None or src.dtype == pt.dtype) and (residual or dst.dtype == pt.dtype), label
     gam, bet, eps = ln if ln is not None else (None, None, 0.0)
     args = (src.ptr, src.ld, 1 if ln is not None else 0, gam.data_ptr() if ln is not None else None, bet.data_ptr() if ln is not None else None,
-            float(eps), pt.w.data_ptr(), dst.ptr, dst.ld, 1 if residual else 0, src.rows, pt.K, pt.N, act)
+            float(eps), pt.w.data_ptr(), dst.ptr, dst.ld, 1 if residual else 0, src.rows, pt.K, pt.N, act, pt.dtype)
     plan.keep.append((pt, src, dst, gam, bet))
     sp0, fn = plan.sptr, lib.cvmi_tok_linear
 

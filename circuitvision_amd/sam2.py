@@ -28,8 +28,8 @@ import torch
 import torch.nn.functional as TF
 
 from . import _lib
-from ._lib import ACT_GELU, ACT_NONE, ACT_RELU, ACT_SIGMOID, F16, F32
-from .engine import (ESIZE, TORCH_DTYPE, Buf, PackedConv, PackedHieraMlp, PackedTokLinear, Plan, Rows, hiera_mlp_supported, make_attn_desc, op_attention,
+from ._lib import ACT_GELU, ACT_NONE, ACT_RELU, ACT_SIGMOID, BF16, F16, F32
+from .engine import (ESIZE, TORCH_DTYPE, is16, Buf, PackedConv, PackedHieraMlp, PackedTokLinear, Plan, Rows, hiera_mlp_supported, make_attn_desc, op_attention,
                      op_call, op_cast, op_conv, op_hiera_mlp, op_layernorm, op_maxpool2, op_tok_linear, require_gpu, tok_linear_supported)
 
 HIERA_L = dict(embed_dim=144, num_heads=2, stages=(2, 6, 36, 4), global_att_blocks=(23, 33, 43), window_spec=(8, 4, 16, 8))
@@ -185,10 +185,10 @@ class Sam2Weights:
 
     def _linear(self, key, mod, cout, cin, tok=False):
         w, b = self.p.weight(mod, (cout, cin)), self.p.bias(mod, cout)
-        if tok and self.use_tok and self.dtype == F16 and tok_linear_supported(cin, self.dtype, 256):
+        if tok and self.use_tok and is16(self.dtype) and tok_linear_supported(cin, self.dtype, 256):
             # short-K Hiera linears also in the token-stationary kernel's fragment order (tok_linear.hip); the plan picks it
             # whenever its row count is a multiple of 256
-            self.tl[key] = PackedTokLinear(w, b, self.device)
+            self.tl[key] = PackedTokLinear(w, b, self.device, self.dtype)
         return self._pack(key, _lin(w), b)
 
     def _norm(self, key, mod, c):
@@ -233,7 +233,7 @@ class Sam2Weights:
                 # stages 1 / 2: norm2 + fc1 + GELU + fc2 + residual as ONE launch (hiera_mlp.hip); weights in fragment order
                 self.mlp[f"b{i}"] = PackedHieraMlp(self.p.weight(f"{b}.mlp.layers.0", (4 * dim_out, dim_out)), self.p.bias(f"{b}.mlp.layers.0", 4 * dim_out),
                                                    self.p.weight(f"{b}.mlp.layers.1", (dim_out, 4 * dim_out)), self.p.bias(f"{b}.mlp.layers.1", dim_out),
-                                                   self.device)
+                                                   self.device, self.dtype)
                 self.param_bytes += self.mlp[f"b{i}"].param_bytes
             else:
                 self._linear(f"b{i}.fc1", f"{b}.mlp.layers.0", 4 * dim_out, dim_out, tok=True)
@@ -565,7 +565,7 @@ class Sam2Plan:
             # embedding: in fp16 mode layer 0 reads the B shared copies (k / v and q projections on B images instead of B * P,
             # attention kernels index the shared batch entry, the first residual add broadcasts) and the repeat pass disappears.
             # f32 parity mode keeps the literal repeat_image formulation (upstream MaskDecoder.predict_masks) as the cross-check.
-            self.share_l0 = dt == F16 and os.environ.get("CVMI_SAM_SHARE_L0", "1") != "0"
+            self.share_l0 = is16(dt) and os.environ.get("CVMI_SAM_SHARE_L0", "1") != "0"
             if not self.share_l0:
                 op_call(self.plan, "repeat_embed", "decoder", lib.cvmi_repeat_images, (emb.t.data_ptr(), keys.t.data_ptr(), P * 256 * 4, B, NP),
                         keep=(emb, keys), bytes_=(B + NB) * P * 256 * 4)
@@ -599,7 +599,7 @@ class Sam2Plan:
             op_attention(self.plan, label, desc, (qb, kb, vb, ob), flops=4 * NB * 8 * Nq * Nk * hd)
             self.plan.ops[-1] = (self.plan.ops[-1][0], "decoder") + self.plan.ops[-1][2:]
 
-        dual = dt == F16                         # norm4 writes the fp16 operand copy of the image stream itself (no cast pass)
+        dual = is16(dt)                          # norm4 writes the 16-bit operand copy of the image stream itself (no cast pass)
         qn = bufd(1, T, 256, tag="qn")           # compute-dtype copies of the f32 streams
         kn = bufd(fs, fs, 256, tag="kn")
         G = lambda *a, **k: self.gemm(*a, kind="decoder", **k)

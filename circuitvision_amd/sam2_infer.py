@@ -10,7 +10,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import F16, F32
+from ._lib import BF16, F16, F32
 from .engine import TORCH_DTYPE, require_gpu
 from .sam2 import HIERA_L, Sam2Plan, Sam2Weights, SamBaseCheckpointParams, SamStateDictParams, SamSyntheticParams
 
@@ -38,7 +38,7 @@ class SAM2Model:
                  embedding_r=4, lora_rank=4, lora_alpha=16, dynamic_multimask_via_stability=True):
         require_gpu()
         self.hiera, self.image_size = hiera, image_size
-        self.dtype = {"f16": F16, "fp16": F16, "f32": F32, "fp32": F32}[dtype] if isinstance(dtype, str) else dtype
+        self.dtype = {"f16": F16, "fp16": F16, "f32": F32, "fp32": F32, "bf16": BF16}[dtype] if isinstance(dtype, str) else dtype
         self.dev = dev
         self.cfg = dict(use_refinement=use_refinement, refinement_kernels=tuple(refinement_kernels), embedding_r=embedding_r)
         self.lora = (lora_rank, lora_alpha)
@@ -86,9 +86,9 @@ class SAM2Model:
         lib = _lib.load()
         B = images.shape[0]
         x = images.to(self.dev)
-        if x.dtype not in (torch.float32, torch.float16):
-            x = x.float()
-        src_dt = F32 if x.dtype == torch.float32 else F16
+        if x.dtype not in (torch.float32, torch.float16, torch.bfloat16) or (x.dtype == torch.float16) != (self.dtype == F16) and x.dtype != torch.float32:
+            x = x.float()                                     # (a 16-bit input of the OTHER 16-bit type goes through f32)
+        src_dt = {torch.float32: F32, torch.float16: F16, torch.bfloat16: BF16}[x.dtype]
         torch.cuda.current_stream().synchronize()
         sp = self.stream.cuda_stream
         if x.permute(0, 2, 3, 1).is_contiguous():            # already channels-last memory (SAM2Transforms output)

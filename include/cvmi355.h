@@ -17,7 +17,9 @@
  *   - activations are NHWC ("pixels x channels", channel contiguous); a tensor view is
  *     (ptr, ld) where ld = elements between consecutive pixels, so channel slices of a wider
  *     buffer (zero-copy concat / split) are first-class.
- *   - dtype: CVMI_F16 (fp16 storage, fp32 accumulate) or CVMI_F32 (exact-f32 MFMA, parity mode).
+ *   - dtype: CVMI_F16 (fp16 storage, fp32 accumulate), CVMI_F32 (exact-f32 MFMA, parity mode) or -- on the SAM 2 path's entry points
+ *     (conv2d, attention, layernorm, cast, maxpool2x2, space_to_depth4, nchw_to_nhwc, prompt_tokens, hyper_masks, sam2_transform,
+ *     hiera_mlp, tok_linear) -- CVMI_BF16 (bf16 storage / MFMA operands, fp32 accumulate; BASELINE configs[4]).
  */
 #ifndef CVMI355_H
 #define CVMI355_H
@@ -29,11 +31,11 @@
 extern "C" {
 #endif
 
-#define CVMI_VERSION 108
+#define CVMI_VERSION 109
 
 typedef void* cvmi_stream_t; /* hipStream_t */
 
-enum { CVMI_F16 = 0, CVMI_F32 = 1 };
+enum { CVMI_F16 = 0, CVMI_F32 = 1, CVMI_BF16 = 2 };   /* BF16: bf16 storage / operands, fp32 accumulate (SAM 2 path entry points) */
 enum { CVMI_ACT_NONE = 0, CVMI_ACT_SILU = 1, CVMI_ACT_RELU = 2, CVMI_ACT_GELU = 3, CVMI_ACT_SIGMOID = 4 };
 
 /* ---- library -------------------------------------------------------------------------------- */
@@ -214,10 +216,10 @@ int cvmi_nhwc_to_nchw_f32(const void* src, int src_dtype, int src_ld, float* dst
 int cvmi_layernorm(const void* x, int x_ld, int x_dtype, const float* gamma, const float* beta,
                    void* y, int y_ld, int y_dtype, long long rows, int C, float eps, int act,
                    int pad_h, int pad_w, int pad_hp, int pad_wp, cvmi_stream_t stream);
-/* Same over an f32 stream, writing the f32 result to y AND an fp16 copy to y2 (the GEMM-operand copy the next layer
+/* Same over an f32 stream, writing the f32 result to y AND a 16-bit (y2_dtype) copy to y2 (the GEMM-operand copy the next layer
  * reads: saves a cast pass over the stream; SAM 2 two-way transformer norm4, sam2_infer.py:252). */
 int cvmi_layernorm_dual(const void* x, int x_ld, const float* gamma, const float* beta, void* y, int y_ld, void* y2, int y2_ld,
-                        long long rows, int C, float eps, cvmi_stream_t stream);
+                        int y2_dtype /* CVMI_F16 | CVMI_BF16 */, long long rows, int C, float eps, cvmi_stream_t stream);
 
 /* Fused MLP half of a Hiera block, in place on the f32 residual stream (sam2 hieradet MultiScaleBlock: `x = x + mlp(norm2(x))`,
  * behind sam2_infer.py:226):   x[r, :] += fc2( GELU( fc1( LayerNorm(x[r, :]; gamma, beta, eps) ) ) )   for r < rows, hidden = 4 C,
@@ -234,7 +236,7 @@ int cvmi_layernorm_dual(const void* x, int x_ld, const float* gamma, const float
 int cvmi_hiera_mlp_supported(int C);
 size_t cvmi_hiera_mlp_packed_bytes(int C);
 int cvmi_hiera_mlp(void* x, int x_ld, const float* gamma, const float* beta, float eps, const void* w_packed,
-                   const float* b2, long long rows, int C, cvmi_stream_t stream);
+                   const float* b2, long long rows, int C, int dtype /* CVMI_F16 | CVMI_BF16: type of w_packed */, cvmi_stream_t stream);
 
 /* Token-stationary linear layer for Hiera's short-K GEMMs (sam2 hieradet MultiScaleBlock: qkv(norm1(x)), x = shortcut + proj(attn),
  * mlp.layers[0](norm2(x)) + GELU; behind sam2_infer.py:226):
@@ -250,7 +252,7 @@ int cvmi_tok_linear_supported(int K);
 size_t cvmi_tok_linear_packed_bytes(int K, int N);
 int cvmi_tok_linear(const void* in, int in_ld, int in_f32_layernorm, const float* gamma, const float* beta, float eps,
                     const void* w_packed, void* out, int out_ld, int out_f32_residual, long long rows, int K, int N, int act,
-                    cvmi_stream_t stream);
+                    int dtype /* CVMI_F16 | CVMI_BF16: type of w_packed and of the 16-bit input / output */, cvmi_stream_t stream);
 
 /* 2x2 / stride 2 max-pool, NHWC (Hiera shortcut path of the q-pooling blocks: do_pool(proj(x))). */
 int cvmi_maxpool2x2(const void* x, int x_ld, void* y, int y_ld, int B, int H, int W, int C, int dtype,

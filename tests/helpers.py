@@ -2,10 +2,10 @@
 import torch
 
 from circuitvision_amd import _lib
-from circuitvision_amd._lib import F16, F32
+from circuitvision_amd._lib import BF16, F16, F32
 from circuitvision_amd.engine import Buf, Plan, TORCH_DTYPE
 
-TOL = {F16: dict(rtol=2e-2, atol=2e-2), F32: dict(rtol=1e-4, atol=1e-4)}
+TOL = {F16: dict(rtol=2e-2, atol=2e-2), F32: dict(rtol=1e-4, atol=1e-4), BF16: dict(rtol=1.2e-1, atol=1.2e-1)}
 
 
 def stream():

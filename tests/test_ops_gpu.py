@@ -12,7 +12,7 @@ import torch
 import torch.nn.functional as F
 
 from circuitvision_amd import _lib
-from circuitvision_amd._lib import ACT_GELU, ACT_NONE, ACT_RELU, ACT_SILU, F16, F32
+from circuitvision_amd._lib import ACT_GELU, ACT_NONE, ACT_RELU, ACT_SILU, BF16, F16, F32
 from circuitvision_amd.engine import (Buf, PackedConv, PackedDW, Plan, make_attn_desc, op_attention, op_conv, op_dwconv,
                                       op_sppf_pool)
 from helpers import TOL, from_view, quant, run, stream, to_buf
@@ -419,8 +419,9 @@ def test_gemm_256_tile_counted_dma_pipeline(M, N, K, out_f32, act):
         assert torch.equal(yb.t, first)
 
 
+@pytest.mark.parametrize("dt", [F16, BF16])
 @pytest.mark.parametrize("C_,rows", [(144, 1000), (288, 777), (144, 256 * 37 + 5)])
-def test_hiera_mlp_fused_vs_torch(C_, rows):
+def test_hiera_mlp_fused_vs_torch(C_, rows, dt):
     """x + fc2(GELU(fc1(LayerNorm(x)))) in one launch (hiera_mlp.hip) vs fp32 torch on the same fp16-rounded weights:
     the pre-activations are computed from fp16 operands and the hidden activation is rounded to fp16, as in the unfused chain.
     Ragged row counts exercise the clamped last tile; rows beyond `rows` must stay untouched."""
@@ -429,14 +430,14 @@ def test_hiera_mlp_fused_vs_torch(C_, rows):
     g = torch.Generator().manual_seed(C_ + rows)
     x = torch.randn(rows + 3, C_, generator=g) * 1.5 + 0.3
     gam, bet = torch.rand(C_, generator=g) + 0.5, torch.randn(C_, generator=g) * 0.2
-    w1 = quant(torch.randn(4 * C_, C_, generator=g) / C_ ** 0.5, F16)
+    w1 = quant(torch.randn(4 * C_, C_, generator=g) / C_ ** 0.5, dt)
     b1 = torch.randn(4 * C_, generator=g) * 0.3
-    w2 = quant(torch.randn(C_, 4 * C_, generator=g) / (4 * C_) ** 0.5, F16)
+    w2 = quant(torch.randn(C_, 4 * C_, generator=g) / (4 * C_) ** 0.5, dt)
     b2 = torch.randn(C_, generator=g) * 0.3
-    xn = quant(TF.layer_norm(x[:rows], (C_,), gam, bet, 1e-6), F16)
-    hid = quant(TF.gelu(xn @ w1.t() + b1), F16)
+    xn = quant(TF.layer_norm(x[:rows], (C_,), gam, bet, 1e-6), dt)
+    hid = quant(TF.gelu(xn @ w1.t() + b1), dt)
     ref = x[:rows] + hid @ w2.t() + b2
-    pm = PackedHieraMlp(w1, b1, w2, b2)
+    pm = PackedHieraMlp(w1, b1, w2, b2, dtype=dt)
     xb = Buf(1, 1, rows + 3, C_, F32)
     xb.t.copy_(x.view(1, 1, rows + 3, C_))
     view = xb.images(0, 1).view()
@@ -447,7 +448,8 @@ def test_hiera_mlp_fused_vs_torch(C_, rows):
     got = xb.t.view(rows + 3, C_).cpu()
     assert torch.equal(got[rows:], x[rows:])
     err = (got[:rows] - ref).abs().max().item()
-    torch.testing.assert_close(got[:rows], ref, rtol=3e-3, atol=3e-3), err
+    tol = 3e-3 if dt == F16 else 2.4e-2                       # bf16: 8 mantissa bits against 11
+    torch.testing.assert_close(got[:rows], ref, rtol=tol, atol=tol), err
     # bit-identical reruns (a second pass on the SAME input)
     xb.t.copy_(x.view(1, 1, rows + 3, C_))
     run(plan)
@@ -457,44 +459,48 @@ def test_hiera_mlp_fused_vs_torch(C_, rows):
 @pytest.mark.parametrize("K,N,ln,res,act", [(144, 432, True, False, ACT_NONE), (288, 864, True, False, ACT_NONE), (576, 1728, True, False, ACT_NONE),
                                             (576, 2304, True, False, ACT_GELU), (576, 576, False, True, ACT_NONE), (144, 144, False, True, ACT_NONE),
                                             (288, 104, False, False, ACT_GELU), (576, 40, True, True, ACT_NONE), (144, 432, True, False, ACT_GELU), (288, 288, True, True, ACT_NONE)])
-def test_tok_linear_vs_torch(K, N, ln, res, act):
-    """Token-stationary linear layer (tok_linear.hip): optional fused LayerNorm of the f32 stream on the way in, fp16 output with
-    optional GELU or in-place f32 residual update, N not a multiple of 32 (masked last chunk), vs fp32 torch on fp16-rounded weights."""
+@pytest.mark.parametrize("dt", [F16, BF16])
+def test_tok_linear_vs_torch(K, N, ln, res, act, dt):
+    """Token-stationary linear layer (tok_linear.hip): optional fused LayerNorm of the f32 stream on the way in, 16-bit output with
+    optional GELU or in-place f32 residual update, N not a multiple of 32 (masked last chunk), vs fp32 torch on weights rounded to the
+    operand type (fp16, or bf16: the -DCVMI_OPERAND_BF16 build of the same kernel)."""
     import torch.nn.functional as TF
     from circuitvision_amd.engine import PackedTokLinear, Rows, op_tok_linear
+    td = TORCH_DTYPE[dt]
+    tol = 1.0 if dt == F16 else 8.0                            # bf16 carries 8 mantissa bits against fp16's 11
     rows = 512
     g = torch.Generator().manual_seed(K + N)
-    w = quant(torch.randn(N, K, generator=g) / K ** 0.5, F16)
+    w = quant(torch.randn(N, K, generator=g) / K ** 0.5, dt)
     b = torch.randn(N, generator=g) * 0.3
     gam, bet = torch.rand(K, generator=g) + 0.5, torch.randn(K, generator=g) * 0.2
     if ln:
         x = torch.randn(rows, K, generator=g) * 1.5 + 0.7
-        x[:, 3] += 40.0                                     # an outlier channel: the shifted single-pass variance must cope
-        xin = quant(TF.layer_norm(x, (K,), gam, bet, 1e-6), F16)
+        x[:, 3] += 40.0                                     # an outlier channel: the variance pass must cope
+        xin = quant(TF.layer_norm(x, (K,), gam, bet, 1e-6), dt)
         src_t = x.cuda()
     else:
-        x = quant(torch.randn(rows, K, generator=g), F16)
+        x = quant(torch.randn(rows, K, generator=g), dt)
         xin = x
-        src_t = x.half().cuda()
+        src_t = x.to(td).cuda()
     y = xin @ w.t() + b
     if act == ACT_GELU:
         y = TF.gelu(y)
-    Np = (N + 3) // 4 * 4
+    Np = (N + 7) // 8 * 8
     if res:
         r0 = torch.randn(rows, Np, generator=g)
         ref = r0.clone(); ref[:, :N] += y
         dst_t = r0.cuda()
     else:
         ref = None
-        dst_t = torch.full((rows, Np), 7.0, dtype=torch.float16, device="cuda")
-    pt = PackedTokLinear(w, b)
+        dst_t = torch.full((rows, Np), 7.0, dtype=td, device="cuda")
+    pt = PackedTokLinear(w, b, dtype=dt)
     plan = Plan(stream())
     op_tok_linear(plan, "tl", pt, Rows(src_t, rows, K), Rows(dst_t, rows, N, ld=Np), ln=(gam.cuda(), bet.cuda(), 1e-6) if ln else None,
                   act=act, residual=res)
     run(plan)
     got = dst_t.float().cpu()
     if res:
-        torch.testing.assert_close(got, ref, rtol=3e-3, atol=3e-3)
+        torch.testing.assert_close(got, ref, rtol=3e-3 * tol, atol=3e-3 * tol)
     else:
-        torch.testing.assert_close(got[:, :N], y, rtol=4e-3, atol=4e-3)
+        torch.testing.assert_close(got[:, :N], y, rtol=4e-3 * tol, atol=4e-3 * tol)
         assert bool((got[:, N:] == 7.0).all())               # columns beyond N untouched
