@@ -59,7 +59,7 @@ def parse():
     ap.add_argument("--prompts", type=int, default=32, help="box prompts per image (sam2l_box)")
     ap.add_argument("--batch", type=int, default=None, help="images per GPU per stage launch (default 32 YOLO / 16 SAM)")
     ap.add_argument("--total-images", type=int, default=64, help="pipeline workload: images in the whole job")
-    ap.add_argument("--dtype", default="f16")
+    ap.add_argument("--dtype", default="f16", choices=["f16", "f32", "bf16"], help="operand storage type (bf16: SAM 2 workloads, BASELINE configs[4])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile-pass", action="store_true")
     a = ap.parse_args()
@@ -192,6 +192,8 @@ class YoloStage:
         from circuitvision_amd.yolo11 import SyntheticParams, Yolo11Plan, Yolo11Weights
         from synth import circuit_image
         self.scale, self.B, self.nc = scale, B, 62
+        if a.dtype == "bf16":
+            raise SystemExit("--dtype bf16 is built for the SAM 2 path (workloads sam2l / sam2l_box); the detector runs fp16 / f32")
         self.dtype = {"f16": _lib.F16, "f32": _lib.F32}[a.dtype]
         self.params = SyntheticParams(seed=0, nc=self.nc)
         self.wt = Yolo11Weights(scale, self.nc, self.params, self.dtype, device=f"cuda:{local_rank}")
@@ -281,7 +283,7 @@ class SamStage:
         from circuitvision_amd.sam2 import HIERA_L, LORA_TARGETS_REFERENCE, Sam2Plan, Sam2Weights, SamSyntheticParams
         from synth import circuit_image
         self.B, self.P = B, prompts
-        self.dtype = {"f16": _lib.F16, "f32": _lib.F32}[a.dtype]
+        self.dtype = {"f16": _lib.F16, "f32": _lib.F32, "bf16": _lib.BF16}[a.dtype]
         key = (a.dtype, local_rank)
         if key not in SamStage._weights:                         # two SAM stages of one step share the weights
             params = SamSyntheticParams(seed=0, lora_targets=LORA_TARGETS_REFERENCE)

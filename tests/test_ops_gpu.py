@@ -465,7 +465,7 @@ def test_tok_linear_vs_torch(K, N, ln, res, act, dt):
     optional GELU or in-place f32 residual update, N not a multiple of 32 (masked last chunk), vs fp32 torch on weights rounded to the
     operand type (fp16, or bf16: the -DCVMI_OPERAND_BF16 build of the same kernel)."""
     import torch.nn.functional as TF
-    from circuitvision_amd.engine import PackedTokLinear, Rows, op_tok_linear
+    from circuitvision_amd.engine import TORCH_DTYPE, PackedTokLinear, Rows, op_tok_linear
     td = TORCH_DTYPE[dt]
     tol = 1.0 if dt == F16 else 8.0                            # bf16 carries 8 mantissa bits against fp16's 11
     rows = 512
