@@ -13,6 +13,7 @@
 // lane = row, registers = 4 consecutive channels per group -> 8-byte fp16 / 16-byte f32 stores.
 // 8 waves per workgroup (two per SIMD: one wave's epilogue VALU and stores overlap the other's MFMAs), 256 rows per workgroup.
 #include "common.hpp"
+#include <stdlib.h>
 
 namespace {
 
@@ -22,12 +23,13 @@ template <int K> struct TlCfg {
   static constexpr int KS = K / 16, KS1 = KS + 1;
   static constexpr int CHB = KS1 * 1024;                       // bytes per 32-channel weight chunk
   static constexpr int SLOTS = K <= 288 ? 4 : 3;                // ring depth
-  static constexpr int LDS = SLOTS * CHB;
+  static constexpr int STG = 32 * 144;                          // per-wave transposition stage of the epilogue: 32 rows x (128 + 16) bytes
+  static constexpr int LDS = SLOTS * CHB + TL_NW * STG;
 };
 
 // LN = true: `in` is the f32 stream (ld in_ld), normalised with gamma / beta / eps.  LN = false: `in` is fp16 [rows, in_ld].
 // RES = true: out is f32 (ld out_ld), out[r, n] += y.  RES = false: out is fp16.
-template <int K, bool LN, bool RES, bool GELU>
+template <int K, bool LN, bool RES, bool GELU, bool TSTORE>
 __global__ __launch_bounds__(TL_NW * 64, 2) void tok_linear_kernel(const void* __restrict__ in, int in_ld, const float* __restrict__ gamma,
                                                                    const float* __restrict__ beta, float eps, const char* __restrict__ wp,
                                                                    void* __restrict__ out, int out_ld, long long rows, int N) {
@@ -122,6 +124,11 @@ __global__ __launch_bounds__(TL_NW * 64, 2) void tok_linear_kernel(const void* _
       r4[g] = 32 * j + 8 * g + 4 * lh < N ? *reinterpret_cast<const f32x4*>(o + 8 * g) : z;
     }
   };
+  // The accumulator has the row on the lane: written out directly, every lane of a store touches a different cache line (8-byte / 16-byte
+  // pieces, 64 lines per instruction).  TSTORE: the chunk goes through a wave-private LDS stage and leaves as whole 64-byte (16-bit) /
+  // 128-byte (f32) row pieces -- 4 / 8 lanes per row, 16 / 8 rows per instruction.
+  char* const stage = smem + SLOTS * CHB + wv * Cfg::STG;
+  const long long wrow0 = ((long long)blockIdx.x * TL_NW + wv) * 32;
   auto epilogue = [&](const f32x16& acc, int j) {
     if constexpr (RES) {
       float* o = reinterpret_cast<float*>(out) + row * (long long)out_ld + 32 * j + 4 * lh;
@@ -133,6 +140,21 @@ __global__ __launch_bounds__(TL_NW * 64, 2) void tok_linear_kernel(const void* _
           for (int e = 0; e < 4; ++e) v[e] += acc[4 * g + e];
           *reinterpret_cast<f32x4*>(o + 8 * g) = v;
         }
+      }
+    } else if constexpr (TSTORE) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        f16x4 h4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) h4[e] = (f16)(GELU ? gelu_fast(acc[4 * g + e]) : acc[4 * g + e]);
+        *reinterpret_cast<f16x4*>(stage + lr * 80 + (8 * g + 4 * lh) * 2) = h4;
+      }
+      const int sr = lane >> 2, pc = lane & 3;
+      const int c0 = 32 * j + pc * 8;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const u32x4 v = *reinterpret_cast<const u32x4*>(stage + (16 * i + sr) * 80 + pc * 16);
+        if (c0 < N) *reinterpret_cast<u32x4*>(reinterpret_cast<f16*>(out) + (wrow0 + 16 * i + sr) * (long long)out_ld + c0) = v;
       }
     } else {
       f16* o = reinterpret_cast<f16*>(out) + row * (long long)out_ld + 32 * j + 4 * lh;
@@ -158,6 +180,7 @@ __global__ __launch_bounds__(TL_NW * 64, 2) void tok_linear_kernel(const void* _
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if constexpr (RES) { if (j > 0) res_load(j - 1); }
+    if constexpr (!RES && TSTORE) { if (j > 0) epilogue(prev, j - 1); }      // (its LDS round trip ends before the ring's counted waits begin)
     if (j + SLOTS - 1 < nch) issue_chunk(j + SLOTS - 1);
     const char* const buf = smem + (j % SLOTS) * CHB + lane * 16;
     // A-fragment ring: PF ds_read_b128 stay in flight ahead of the MFMA that consumes them.  The reads and their COUNTED waits are
@@ -169,7 +192,7 @@ __global__ __launch_bounds__(TL_NW * 64, 2) void tok_linear_kernel(const void* _
     const unsigned lbase = (unsigned)(size_t)((const __attribute__((address_space(3))) char*)buf);
 #pragma unroll
     for (int f = 0; f < PF; ++f) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(ring[f]) : "v"(lbase), "i"(f * 1024));
-    if constexpr (!RES) { if (j > 0) epilogue(prev, j - 1); }
+    if constexpr (!RES && !TSTORE) { if (j > 0) epilogue(prev, j - 1); }
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -198,16 +221,26 @@ __global__ __launch_bounds__(TL_NW * 64, 2) void tok_linear_kernel(const void* _
   epilogue(prev, nch - 1);
 }
 
-template <int K, bool LN, bool RES, bool GELU>
-int launch_tl(const void* in, int in_ld, const float* gamma, const float* beta, float eps, const void* wp, void* out, int out_ld, long long rows,
+template <int K, bool LN, bool RES, bool GELU, bool TSTORE>
+int launch_tl1(const void* in, int in_ld, const float* gamma, const float* beta, float eps, const void* wp, void* out, int out_ld, long long rows,
               int N, hipStream_t s) {
   using Cfg = TlCfg<K>;
-  static hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&tok_linear_kernel<K, LN, RES, GELU>), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
+  static hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&tok_linear_kernel<K, LN, RES, GELU, TSTORE>), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
   CVMI_HIP(attr);
-  hipLaunchKernelGGL((tok_linear_kernel<K, LN, RES, GELU>), dim3((unsigned)(rows / 256)), dim3(TL_NW * 64), Cfg::LDS, s, in, in_ld, gamma, beta, eps,
+  hipLaunchKernelGGL((tok_linear_kernel<K, LN, RES, GELU, TSTORE>), dim3((unsigned)(rows / 256)), dim3(TL_NW * 64), Cfg::LDS, s, in, in_ld, gamma, beta, eps,
                      (const char*)wp, out, out_ld, rows, N);
   CVMI_LAUNCH_CHECK();
   return 0;
+}
+
+template <int K, bool LN, bool RES, bool GELU>
+int launch_tl(const void* in, int in_ld, const float* gamma, const float* beta, float eps, const void* wp, void* out, int out_ld, long long rows,
+              int N, hipStream_t s) {
+  if constexpr (!RES) {
+    static const int ts = getenv("CVMI_TOKLIN_TSTORE") ? atoi(getenv("CVMI_TOKLIN_TSTORE")) : 0;       // measurements: 1 = transposed stores
+    if (ts && N % 8 == 0 && out_ld % 8 == 0) return launch_tl1<K, LN, RES, GELU, true>(in, in_ld, gamma, beta, eps, wp, out, out_ld, rows, N, s);
+  }
+  return launch_tl1<K, LN, RES, GELU, false>(in, in_ld, gamma, beta, eps, wp, out, out_ld, rows, N, s);
 }
 
 template <int K>

@@ -256,15 +256,15 @@ def test_sam2_wrapper_hiera_l_f16_matches_oracle():
 
 def test_sam2_hiera_l_bf16_matches_oracle():
     """BASELINE configs[4] operand type at the configs[2] shape, B = 1: SAM 2.1 Hiera-L in bf16 (bf16 MFMA operands incl. attention,
-    f32 residual streams / statistics / softmax).  Tolerance: 8x the fp16 bound (3 fewer mantissa bits): low-res mask logits within
-    2.0 std (max) / 0.3 std (rms) of the fp32 oracle -- reported -- and binary-mask IoU >= 0.95."""
+    f32 residual streams / statistics / softmax).  Tolerance (measured r02: 5.9e-2 / 1.2e-2 of the logits' std, mask IoU 0.9987): low-res
+    mask logits within 0.25 std (max) / 0.05 std (rms) of the fp32 oracle, binary-mask IoU >= 0.99."""
     from circuitvision_amd.sam2 import HIERA_L, LORA_TARGETS_REFERENCE
     sp, (hi, lo, iou, inter) = _run_wrapper(HIERA_L, LORA_TARGETS_REFERENCE, _hiera_l_oracle, 1024, BF16, B=1)
-    _assert_logits("Hiera-L bf16 low-res logits", sp.low_res.cpu(), lo, 2.0, 0.3)
+    _assert_logits("Hiera-L bf16 low-res logits", sp.low_res.cpu(), lo, 0.25, 0.05)
     a, b = sp.high_res.cpu() > 0, hi > 0
     iou_m = (a & b).sum().item() / max(1, (a | b).sum().item())
     print(f"Hiera-L bf16: binary-mask IoU vs the fp32 oracle {iou_m:.4f}")
-    assert iou_m >= 0.95
+    assert iou_m >= 0.99
 
 
 def test_boundary_get_modified_sam2_and_transforms():
