@@ -319,7 +319,12 @@ class SamStage:
                 k[0] += ms / reps; k[1] += 1; k[2] += b / reps; k[3] += f / reps
         total_ms = sum(v[0] for v in acc.values())
         roofs = {}
-        for name, kind, what in (("sam2l_linear_gemm", "gemm", "Hiera linear layers (qkv / proj / fc1 / fc2 / dim-proj GEMMs: gemm256* / igemm / gemm_glds kernels)"),
+        if "mlp_fused" in acc:                                    # the fused stage-1 / 2 MLP launches are linear-layer flops too
+            g, m = acc.setdefault("gemm", [0.0, 0, 0, 0]), acc["mlp_fused"]
+            acc["linear"] = [g[0] + m[0], g[1] + m[1], g[2] + m[2], g[3] + m[3]]
+        else:
+            acc["linear"] = list(acc["gemm"])
+        for name, kind, what in (("sam2l_linear_gemm", "linear", "Hiera / neck / decoder linear layers (tok_linear, hiera_mlp, gemm256*, igemm, gemm_glds kernels; LayerNorm and GELU fused where noted in DESIGN.md)"),
                                  ("sam2l_attention_global", "attn_global", "Hiera global attention, 3 blocks x 4096 x 4096 keys per head (attn_dma72_kernel)"),
                                  ("sam2l_attention_window", "attn_window", "Hiera windowed attention (attn_res256 / attn_res64 / attn_win16 kernels)")):
             if kind not in acc:
@@ -330,6 +335,7 @@ class SamStage:
                            "traffic": None, "kernel": f"{what}: aggregate of {n // reps} launches per B={self.B} pass",
                            "kernel_ms_per_step": round(ms, 3), "algorithmic_flops_per_step": int(fl)}
         roofs["sam2l_linear_gemm"]["whole_pass_tflops"] = round(self.B * SAM_FLOP_PER_IMAGE / (total_ms * 1e-3) / 1e12, 1)
+        acc.pop("linear")
         breakdown = {k: {"ms": round(v[0], 3), "launches": v[1] // reps, "gflop": round(v[3] / 1e9, 1),
                          "tflops": round(v[3] / max(v[0], 1e-9) / 1e9, 1)} for k, v in acc.items()}
         return roofs, breakdown

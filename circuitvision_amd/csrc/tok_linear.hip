@@ -29,7 +29,11 @@ template <int K> struct TlCfg {
 
 // LN = true: `in` is the f32 stream (ld in_ld), normalised with gamma / beta / eps.  LN = false: `in` is fp16 [rows, in_ld].
 // RES = true: out is f32 (ld out_ld), out[r, n] += y.  RES = false: out is fp16.
-template <int K, bool LN, bool RES, bool GELU, bool TSTORE>
+// STAMP: diagnostic build (CVMI_TOKLIN_STAMP=1): wave 0 of workgroup 0 accumulates s_memtime differences of the loop's segments into
+// g_tl_stamp (read by cvmi_debug_stamps).  Never used for timing runs: the stamps serialise what the real kernel overlaps.
+__device__ unsigned long long g_tl_stamp[8];
+
+template <int K, bool LN, bool RES, bool GELU, bool TSTORE, bool STAMP = false>
 __global__ __launch_bounds__(TL_NW * 64, 2) void tok_linear_kernel(const void* __restrict__ in, int in_ld, const float* __restrict__ gamma,
                                                                    const float* __restrict__ beta, float eps, const char* __restrict__ wp,
                                                                    void* __restrict__ out, int out_ld, long long rows, int N) {
@@ -172,13 +176,24 @@ __global__ __launch_bounds__(TL_NW * 64, 2) void tok_linear_kernel(const void* _
   f32x16 prev;
 #pragma unroll
   for (int r = 0; r < 16; ++r) prev[r] = 0.f;
+  unsigned long long seg[6] = {0, 0, 0, 0, 0, 0};
+  auto stamp = [&]() -> unsigned long long {
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+    return t;
+  };
+  const unsigned long long t_begin = STAMP ? stamp() : 0ull;
 #pragma unroll 1
   for (int j = 0; j < nch; ++j) {
+    unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+    if constexpr (STAMP) t0 = stamp();
     // Every wave waits for its OWN DMA pieces (explicitly: hipcc puts no vmcnt wait in front of a barrier for LDS-DMA writes),
     // then the barrier publishes chunk j and frees slot (j - 1) % SLOTS.  vmcnt(0) also covers the wave's own stores, which is
     // why the epilogue of chunk j - 1 is issued AFTER this barrier: its stores then have a whole chunk of MFMAs to complete in.
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (STAMP) t1 = stamp();
     __syncthreads();
+    if constexpr (STAMP) t2 = stamp();
     if constexpr (RES) { if (j > 0) res_load(j - 1); }
     if constexpr (!RES && TSTORE) { if (j > 0) epilogue(prev, j - 1); }      // (its LDS round trip ends before the ring's counted waits begin)
     if (j + SLOTS - 1 < nch) issue_chunk(j + SLOTS - 1);
@@ -190,6 +205,7 @@ __global__ __launch_bounds__(TL_NW * 64, 2) void tok_linear_kernel(const void* _
     // lgkm traffic inside the loop.
     u32x4 ring[PF];
     const unsigned lbase = (unsigned)(size_t)((const __attribute__((address_space(3))) char*)buf);
+    if constexpr (STAMP) t3 = stamp();
 #pragma unroll
     for (int f = 0; f < PF; ++f) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(ring[f]) : "v"(lbase), "i"(f * 1024));
     if constexpr (!RES && !TSTORE) { if (j > 0) epilogue(prev, j - 1); }
@@ -216,18 +232,30 @@ __global__ __launch_bounds__(TL_NW * 64, 2) void tok_linear_kernel(const void* _
       if constexpr (RES) { if (f == KS1 / 2 && j > 0) epilogue(prev, j - 1); }
     }
     prev = acc;
+    if constexpr (STAMP) {
+      asm volatile("" : "+v"(prev));
+      const unsigned long long t4 = stamp();
+      seg[0] += t1 - t0; seg[1] += t2 - t1; seg[2] += t3 - t2; seg[3] += t4 - t3;
+    }
+  }
+  if constexpr (STAMP) {
+    const unsigned long long t_end = stamp();
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      g_tl_stamp[0] += seg[0]; g_tl_stamp[1] += seg[1]; g_tl_stamp[2] += seg[2]; g_tl_stamp[3] += seg[3];
+      g_tl_stamp[4] += t_end - t_begin; g_tl_stamp[5] += (unsigned long long)nch; g_tl_stamp[6] += 1;
+    }
   }
   if constexpr (RES) res_load(nch - 1);
   epilogue(prev, nch - 1);
 }
 
-template <int K, bool LN, bool RES, bool GELU, bool TSTORE>
+template <int K, bool LN, bool RES, bool GELU, bool TSTORE, bool STAMP = false>
 int launch_tl1(const void* in, int in_ld, const float* gamma, const float* beta, float eps, const void* wp, void* out, int out_ld, long long rows,
               int N, hipStream_t s) {
   using Cfg = TlCfg<K>;
-  static hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&tok_linear_kernel<K, LN, RES, GELU, TSTORE>), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
+  static hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&tok_linear_kernel<K, LN, RES, GELU, TSTORE, STAMP>), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
   CVMI_HIP(attr);
-  hipLaunchKernelGGL((tok_linear_kernel<K, LN, RES, GELU, TSTORE>), dim3((unsigned)(rows / 256)), dim3(TL_NW * 64), Cfg::LDS, s, in, in_ld, gamma, beta, eps,
+  hipLaunchKernelGGL((tok_linear_kernel<K, LN, RES, GELU, TSTORE, STAMP>), dim3((unsigned)(rows / 256)), dim3(TL_NW * 64), Cfg::LDS, s, in, in_ld, gamma, beta, eps,
                      (const char*)wp, out, out_ld, rows, N);
   CVMI_LAUNCH_CHECK();
   return 0;
@@ -237,7 +265,13 @@ template <int K, bool LN, bool RES, bool GELU>
 int launch_tl(const void* in, int in_ld, const float* gamma, const float* beta, float eps, const void* wp, void* out, int out_ld, long long rows,
               int N, hipStream_t s) {
   if constexpr (!RES) {
-    static const int ts = getenv("CVMI_TOKLIN_TSTORE") ? atoi(getenv("CVMI_TOKLIN_TSTORE")) : 0;       // measurements: 1 = transposed stores
+    static const int ts = getenv("CVMI_TOKLIN_TSTORE") ? atoi(getenv("CVMI_TOKLIN_TSTORE")) : 1;       // 0 = direct stores (A/B measurements)
+#ifndef CVMI_OPERAND_BF16
+    static const int st = getenv("CVMI_TOKLIN_STAMP") ? atoi(getenv("CVMI_TOKLIN_STAMP")) : 0;         // diagnostic build, never for timing
+    if constexpr (K == 576 && LN) {
+      if (st && N % 8 == 0) return launch_tl1<K, LN, RES, GELU, true, true>(in, in_ld, gamma, beta, eps, wp, out, out_ld, rows, N, s);
+    }
+#endif
     if (ts && N % 8 == 0 && out_ld % 8 == 0) return launch_tl1<K, LN, RES, GELU, true>(in, in_ld, gamma, beta, eps, wp, out, out_ld, rows, N, s);
   }
   return launch_tl1<K, LN, RES, GELU, false>(in, in_ld, gamma, beta, eps, wp, out, out_ld, rows, N, s);
@@ -262,6 +296,14 @@ int dispatch_tl(bool ln, bool res, int act, const void* in, int in_ld, const flo
 }  // namespace
 
 #ifndef CVMI_OPERAND_BF16
+// diagnostic: read and clear the segment sums of the CVMI_TOKLIN_STAMP build: {wait, barrier, issue, mfma, total, chunks, launches, -}
+extern "C" int cvmi_debug_stamps(unsigned long long* out8) {
+  CVMI_HIP(hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_tl_stamp), 8 * sizeof(unsigned long long)));
+  unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  CVMI_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_tl_stamp), z, sizeof(z)));
+  return 0;
+}
+
 extern "C" int cvmi_tok_linear_supported(int K) { return K == 144 || K == 288 || K == 576; }
 
 extern "C" size_t cvmi_tok_linear_packed_bytes(int K, int N) {

@@ -254,6 +254,11 @@ int cvmi_tok_linear(const void* in, int in_ld, int in_f32_layernorm, const float
                     const void* w_packed, void* out, int out_ld, int out_f32_residual, long long rows, int K, int N, int act,
                     int dtype /* CVMI_F16 | CVMI_BF16: type of w_packed and of the 16-bit input / output */, cvmi_stream_t stream);
 
+/* Diagnostic only (CVMI_TOKLIN_STAMP=1 selects a stamped build of the K = 576 LayerNorm form of cvmi_tok_linear, never for timing
+ * runs): reads and clears the s_memtime sums of workgroup 0 / wave 0: {DMA wait, barrier, issue (epilogue + prefetch), MFMA sequence,
+ * whole kernel, chunks, launches, 0} in shader cycles. */
+int cvmi_debug_stamps(unsigned long long* out8);
+
 /* 2x2 / stride 2 max-pool, NHWC (Hiera shortcut path of the q-pooling blocks: do_pool(proj(x))). */
 int cvmi_maxpool2x2(const void* x, int x_ld, void* y, int y_ld, int B, int H, int W, int C, int dtype,
                     cvmi_stream_t stream);
