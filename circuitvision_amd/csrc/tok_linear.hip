@@ -13,6 +13,7 @@
 // lane = row, registers = 4 consecutive channels per group -> 8-byte fp16 / 16-byte f32 stores.
 // 8 waves per workgroup (two per SIMD: one wave's epilogue VALU and stores overlap the other's MFMAs), 256 rows per workgroup.
 #include "common.hpp"
+#include <type_traits>
 #include <stdlib.h>
 
 namespace {
@@ -33,7 +34,7 @@ template <int K> struct TlCfg {
 // g_tl_stamp (read by cvmi_debug_stamps).  Never used for timing runs: the stamps serialise what the real kernel overlaps.
 __device__ unsigned long long g_tl_stamp[8];
 
-template <int K, bool LN, bool RES, bool GELU, bool TSTORE, bool STAMP = false>
+template <int K, bool LN, bool RES, bool GELU, bool TSTORE, bool STAMP = false, bool INTER = false>
 __global__ __launch_bounds__(TL_NW * 64, 2) void tok_linear_kernel(const void* __restrict__ in, int in_ld, const float* __restrict__ gamma,
                                                                    const float* __restrict__ beta, float eps, const char* __restrict__ wp,
                                                                    void* __restrict__ out, int out_ld, long long rows, int N) {
@@ -172,6 +173,22 @@ __global__ __launch_bounds__(TL_NW * 64, 2) void tok_linear_kernel(const void* _
     }
   };
 
+  // The same epilogue cut into 16 single-value steps (+ one store per 4 values) that the MFMA loop issues BETWEEN its MFMAs: a stamped
+  // build showed a chunk spending 1325 cycles in its 37 MFMAs, 1254 in the epilogue in front of them and 1827 at the barrier waiting for
+  // the SIMD partner's MFMAs -- the epilogue of chunk j - 1 is independent of the MFMAs of chunk j and fits into their issue gaps.
+  f16x4 eh4;
+  auto epilogue_step = [&](const f32x16& acc, int j, int r) {              // r = 0 .. 15, compile-time
+    const int g = r >> 2, e = r & 3;
+    if constexpr (RES) {
+      r4[g][e] += acc[r];                                       // (N % 32 == 0 in this form: no channel mask, no branch)
+      if (e == 3) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(out) + row * (long long)out_ld + 32 * j + 4 * lh + 8 * g) = r4[g];
+    } else {
+      eh4[e] = (f16)(GELU ? gelu_fast(acc[r]) : acc[r]);
+      if (e == 3) *reinterpret_cast<f16x4*>(reinterpret_cast<f16*>(out) + row * (long long)out_ld + 32 * j + 4 * lh + 8 * g) = eh4;
+    }
+  };
+  constexpr int ESTEP = KS1 >= 33 ? 2 : 1;                       // MFMAs per epilogue step (K = 144: 10 MFMAs carry 16 steps -> 2 per MFMA below)
+
   constexpr int PF = K >= 576 ? 6 : 8;          // ring depth (K = 576: the 148 Xn registers leave less room)
   f32x16 prev;
 #pragma unroll
@@ -183,8 +200,11 @@ __global__ __launch_bounds__(TL_NW * 64, 2) void tok_linear_kernel(const void* _
     return t;
   };
   const unsigned long long t_begin = STAMP ? stamp() : 0ull;
-#pragma unroll 1
-  for (int j = 0; j < nch; ++j) {
+  // One chunk interval.  FIRST (compile-time) = chunk 0: no previous chunk to finish.  The interleaved form must not contain a RUN-TIME
+  // branch between a ring read and its counted wait: every branch splits the unrolled sequence into basic blocks, and hipcc is free to copy
+  // values that are live across a block boundary -- including ring registers whose LDS data is still in flight.
+  auto interval = [&](auto first_tag, int j) {
+    constexpr bool FIRST = decltype(first_tag)::value;
     unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0;
     if constexpr (STAMP) t0 = stamp();
     // Every wave waits for its OWN DMA pieces (explicitly: hipcc puts no vmcnt wait in front of a barrier for LDS-DMA writes),
@@ -194,8 +214,8 @@ __global__ __launch_bounds__(TL_NW * 64, 2) void tok_linear_kernel(const void* _
     if constexpr (STAMP) t1 = stamp();
     __syncthreads();
     if constexpr (STAMP) t2 = stamp();
-    if constexpr (RES) { if (j > 0) res_load(j - 1); }
-    if constexpr (!RES && TSTORE) { if (j > 0) epilogue(prev, j - 1); }      // (its LDS round trip ends before the ring's counted waits begin)
+    if constexpr (RES) { if (INTER ? !FIRST : j > 0) res_load(j - 1); }
+    if constexpr (!RES && TSTORE && !INTER) { if (j > 0) epilogue(prev, j - 1); }      // (its LDS round trip ends before the ring's counted waits begin)
     if (j + SLOTS - 1 < nch) issue_chunk(j + SLOTS - 1);
     const char* const buf = smem + (j % SLOTS) * CHB + lane * 16;
     // A-fragment ring: PF ds_read_b128 stay in flight ahead of the MFMA that consumes them.  The reads and their COUNTED waits are
@@ -208,7 +228,7 @@ __global__ __launch_bounds__(TL_NW * 64, 2) void tok_linear_kernel(const void* _
     if constexpr (STAMP) t3 = stamp();
 #pragma unroll
     for (int f = 0; f < PF; ++f) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(ring[f]) : "v"(lbase), "i"(f * 1024));
-    if constexpr (!RES && !TSTORE) { if (j > 0) epilogue(prev, j - 1); }
+    if constexpr (!RES && !TSTORE && !INTER) { if (j > 0) epilogue(prev, j - 1); }
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -229,7 +249,17 @@ __global__ __launch_bounds__(TL_NW * 64, 2) void tok_linear_kernel(const void* _
       const f16x8 a = __builtin_bit_cast(f16x8, ring[f % PF]);
       acc = CVMI_MFMA_32X32X16(a, __builtin_bit_cast(f16x8, xn[f]), acc, 0, 0, 0);
       if (f + PF < KS1) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(ring[f % PF]) : "v"(lbase), "i"((f + PF) * 1024));
-      if constexpr (RES) { if (f == KS1 / 2 && j > 0) epilogue(prev, j - 1); }
+      if constexpr (RES && !INTER) { if (f == KS1 / 2 && j > 0) epilogue(prev, j - 1); }
+      if constexpr (INTER) {
+        if constexpr (!FIRST) {                                // 16 steps spread over the first MFMAs (RES: from MFMA 2 on, after the loads had time)
+          constexpr int F0 = RES ? 2 : 0;
+          if constexpr (KS1 >= 16 + F0) {
+            if (f >= F0 && (f - F0) % ESTEP == 0 && (f - F0) / ESTEP < 16) epilogue_step(prev, j - 1, (f - F0) / ESTEP);
+          } else {                                             // few MFMAs per chunk (K = 144): two steps per MFMA
+            if (f < 8) { epilogue_step(prev, j - 1, 2 * f); epilogue_step(prev, j - 1, 2 * f + 1); }
+          }
+        }
+      }
     }
     prev = acc;
     if constexpr (STAMP) {
@@ -237,6 +267,14 @@ __global__ __launch_bounds__(TL_NW * 64, 2) void tok_linear_kernel(const void* _
       const unsigned long long t4 = stamp();
       seg[0] += t1 - t0; seg[1] += t2 - t1; seg[2] += t3 - t2; seg[3] += t4 - t3;
     }
+  };
+  if constexpr (INTER) {
+    interval(std::true_type{}, 0);
+#pragma unroll 1
+    for (int j = 1; j < nch; ++j) interval(std::false_type{}, j);
+  } else {
+#pragma unroll 1
+    for (int j = 0; j < nch; ++j) interval(std::false_type{}, j);
   }
   if constexpr (STAMP) {
     const unsigned long long t_end = stamp();
@@ -249,13 +287,13 @@ __global__ __launch_bounds__(TL_NW * 64, 2) void tok_linear_kernel(const void* _
   epilogue(prev, nch - 1);
 }
 
-template <int K, bool LN, bool RES, bool GELU, bool TSTORE, bool STAMP = false>
+template <int K, bool LN, bool RES, bool GELU, bool TSTORE, bool STAMP = false, bool INTER = false>
 int launch_tl1(const void* in, int in_ld, const float* gamma, const float* beta, float eps, const void* wp, void* out, int out_ld, long long rows,
               int N, hipStream_t s) {
   using Cfg = TlCfg<K>;
-  static hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&tok_linear_kernel<K, LN, RES, GELU, TSTORE, STAMP>), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
+  static hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&tok_linear_kernel<K, LN, RES, GELU, TSTORE, STAMP, INTER>), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
   CVMI_HIP(attr);
-  hipLaunchKernelGGL((tok_linear_kernel<K, LN, RES, GELU, TSTORE, STAMP>), dim3((unsigned)(rows / 256)), dim3(TL_NW * 64), Cfg::LDS, s, in, in_ld, gamma, beta, eps,
+  hipLaunchKernelGGL((tok_linear_kernel<K, LN, RES, GELU, TSTORE, STAMP, INTER>), dim3((unsigned)(rows / 256)), dim3(TL_NW * 64), Cfg::LDS, s, in, in_ld, gamma, beta, eps,
                      (const char*)wp, out, out_ld, rows, N);
   CVMI_LAUNCH_CHECK();
   return 0;
@@ -264,6 +302,8 @@ int launch_tl1(const void* in, int in_ld, const float* gamma, const float* beta,
 template <int K, bool LN, bool RES, bool GELU>
 int launch_tl(const void* in, int in_ld, const float* gamma, const float* beta, float eps, const void* wp, void* out, int out_ld, long long rows,
               int N, hipStream_t s) {
+  static const int inter = getenv("CVMI_TOKLIN_INTER") ? atoi(getenv("CVMI_TOKLIN_INTER")) : 1;        // 0 = block epilogue (A/B measurements)
+  if (inter && N % 32 == 0) return launch_tl1<K, LN, RES, GELU, false, false, true>(in, in_ld, gamma, beta, eps, wp, out, out_ld, rows, N, s);
   if constexpr (!RES) {
     static const int ts = getenv("CVMI_TOKLIN_TSTORE") ? atoi(getenv("CVMI_TOKLIN_TSTORE")) : 1;       // 0 = direct stores (A/B measurements)
 #ifndef CVMI_OPERAND_BF16
