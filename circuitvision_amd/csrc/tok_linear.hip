@@ -11,7 +11,8 @@
 // L2 -> LDS by global_load_lds into a ring and read lane-linearly (conflict-free ds_read_b128, kept PF deep in flight).  Only
 // the A operand comes from LDS -- half the LDS traffic of a tiled GEMM -- and the accumulator of a chunk is its epilogue:
 // lane = row, registers = 4 consecutive channels per group -> 8-byte fp16 / 16-byte f32 stores.
-// 8 waves per workgroup (two per SIMD: one wave's epilogue VALU and stores overlap the other's MFMAs), 256 rows per workgroup.
+// 8 waves per workgroup, 256 rows; the two waves of a SIMD run half a chunk interval apart (ping-pong schedule, below): one in its
+// MFMAs beside the other in its epilogue VALU, stores and weight prefetch.
 #include "common.hpp"
 #include <type_traits>
 #include <stdlib.h>
@@ -32,9 +33,9 @@ template <int K> struct TlCfg {
 // RES = true: out is f32 (ld out_ld), out[r, n] += y.  RES = false: out is fp16.
 // STAMP: diagnostic build (CVMI_TOKLIN_STAMP=1): wave 0 of workgroup 0 accumulates s_memtime differences of the loop's segments into
 // g_tl_stamp (read by cvmi_debug_stamps).  Never used for timing runs: the stamps serialise what the real kernel overlaps.
-__device__ unsigned long long g_tl_stamp[8];
+__device__ unsigned long long g_tl_stamp[24];
 
-template <int K, bool LN, bool RES, bool GELU, bool TSTORE, bool STAMP = false, bool INTER = false>
+template <int K, bool LN, bool RES, bool GELU, bool TSTORE, bool STAMP = false, int PP = 0>
 __global__ __launch_bounds__(TL_NW * 64, 2) void tok_linear_kernel(const void* __restrict__ in, int in_ld, const float* __restrict__ gamma,
                                                                    const float* __restrict__ beta, float eps, const char* __restrict__ wp,
                                                                    void* __restrict__ out, int out_ld, long long rows, int N) {
@@ -173,68 +174,25 @@ __global__ __launch_bounds__(TL_NW * 64, 2) void tok_linear_kernel(const void* _
     }
   };
 
-  // The same epilogue cut into 16 single-value steps (+ one store per 4 values) that the MFMA loop issues BETWEEN its MFMAs: a stamped
-  // build showed a chunk spending 1325 cycles in its 37 MFMAs, 1254 in the epilogue in front of them and 1827 at the barrier waiting for
-  // the SIMD partner's MFMAs -- the epilogue of chunk j - 1 is independent of the MFMAs of chunk j and fits into their issue gaps.
-  f16x4 eh4;
-  auto epilogue_step = [&](const f32x16& acc, int j, int r) {              // r = 0 .. 15, compile-time
-    const int g = r >> 2, e = r & 3;
-    if constexpr (RES) {
-      r4[g][e] += acc[r];                                       // (N % 32 == 0 in this form: no channel mask, no branch)
-      if (e == 3) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(out) + row * (long long)out_ld + 32 * j + 4 * lh + 8 * g) = r4[g];
-    } else {
-      eh4[e] = (f16)(GELU ? gelu_fast(acc[r]) : acc[r]);
-      if (e == 3) *reinterpret_cast<f16x4*>(reinterpret_cast<f16*>(out) + row * (long long)out_ld + 32 * j + 4 * lh + 8 * g) = eh4;
-    }
-  };
-  constexpr int ESTEP = KS1 >= 33 ? 2 : 1;                       // MFMAs per epilogue step (K = 144: 10 MFMAs carry 16 steps -> 2 per MFMA below)
-
   constexpr int PF = K >= 576 ? 6 : 8;          // ring depth (K = 576: the 148 Xn registers leave less room)
-  f32x16 prev;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) prev[r] = 0.f;
-  unsigned long long seg[6] = {0, 0, 0, 0, 0, 0};
-  auto stamp = [&]() -> unsigned long long {
-    unsigned long long t;
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
-    return t;
-  };
-  const unsigned long long t_begin = STAMP ? stamp() : 0ull;
-  // One chunk interval.  FIRST (compile-time) = chunk 0: no previous chunk to finish.  The interleaved form must not contain a RUN-TIME
-  // branch between a ring read and its counted wait: every branch splits the unrolled sequence into basic blocks, and hipcc is free to copy
-  // values that are live across a block boundary -- including ring registers whose LDS data is still in flight.
-  auto interval = [&](auto first_tag, int j) {
-    constexpr bool FIRST = decltype(first_tag)::value;
-    unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0;
-    if constexpr (STAMP) t0 = stamp();
-    // Every wave waits for its OWN DMA pieces (explicitly: hipcc puts no vmcnt wait in front of a barrier for LDS-DMA writes),
-    // then the barrier publishes chunk j and frees slot (j - 1) % SLOTS.  vmcnt(0) also covers the wave's own stores, which is
-    // why the epilogue of chunk j - 1 is issued AFTER this barrier: its stores then have a whole chunk of MFMAs to complete in.
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if constexpr (STAMP) t1 = stamp();
-    __syncthreads();
-    if constexpr (STAMP) t2 = stamp();
-    if constexpr (RES) { if (INTER ? !FIRST : j > 0) res_load(j - 1); }
-    if constexpr (!RES && TSTORE && !INTER) { if (j > 0) epilogue(prev, j - 1); }      // (its LDS round trip ends before the ring's counted waits begin)
-    if (j + SLOTS - 1 < nch) issue_chunk(j + SLOTS - 1);
+  // The K/16 + 1 MFMAs of chunk j.  A-fragment ring: PF ds_read_b128 stay in flight ahead of the MFMA that consumes them.  The reads and
+  // their COUNTED waits are inline asm: left to hipcc the same source becomes read -> lgkmcnt(0) -> MFMA (every MFMA then waits a full LDS
+  // round trip, and the matrix pipe idles two thirds of the time).  LDS returns data in issue order, so before MFMA f at most
+  // min(PF - 1, KS1 - 1 - f) younger reads may still be outstanding; nothing else of the wave may touch LDS inside the sequence, and no
+  // run-time branch may sit between a read and its wait (hipcc may copy values that live across a block boundary, in-flight or not).
+  // `head()` runs after the ring's first reads are issued, `mid()` after MFMA KS1 / 2.
+  auto mfma_seq = [&](int j, auto&& head, auto&& mid) -> f32x16 {
     const char* const buf = smem + (j % SLOTS) * CHB + lane * 16;
-    // A-fragment ring: PF ds_read_b128 stay in flight ahead of the MFMA that consumes them.  The reads and their COUNTED waits are
-    // inline asm: left to hipcc the same source becomes read -> lgkmcnt(0) -> MFMA (every MFMA then waits a full LDS round trip, and the
-    // matrix pipe idles two thirds of the time).  LDS returns data in issue order, so before MFMA f at most min(PF - 1, KS1 - 1 - f)
-    // younger reads may still be outstanding.  The epilogue of the previous chunk touches no LDS, so these reads are the wave's only
-    // lgkm traffic inside the loop.
     u32x4 ring[PF];
     const unsigned lbase = (unsigned)(size_t)((const __attribute__((address_space(3))) char*)buf);
-    if constexpr (STAMP) t3 = stamp();
 #pragma unroll
     for (int f = 0; f < PF; ++f) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(ring[f]) : "v"(lbase), "i"(f * 1024));
-    if constexpr (!RES && !TSTORE && !INTER) { if (j > 0) epilogue(prev, j - 1); }
+    head();
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
     for (int f = 0; f < KS1; ++f) {
-      constexpr int dummy = 0; (void)dummy;
       const int young = (KS1 - 1 - f) < (PF - 1) ? (KS1 - 1 - f) : (PF - 1);
       switch (young) {                                         // (f is a compile-time constant after unrolling)
         case 0: asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ring[f % PF])); break;
@@ -249,32 +207,119 @@ __global__ __launch_bounds__(TL_NW * 64, 2) void tok_linear_kernel(const void* _
       const f16x8 a = __builtin_bit_cast(f16x8, ring[f % PF]);
       acc = CVMI_MFMA_32X32X16(a, __builtin_bit_cast(f16x8, xn[f]), acc, 0, 0, 0);
       if (f + PF < KS1) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(ring[f % PF]) : "v"(lbase), "i"((f + PF) * 1024));
-      if constexpr (RES && !INTER) { if (f == KS1 / 2 && j > 0) epilogue(prev, j - 1); }
-      if constexpr (INTER) {
-        if constexpr (!FIRST) {                                // 16 steps spread over the first MFMAs (RES: from MFMA 2 on, after the loads had time)
-          constexpr int F0 = RES ? 2 : 0;
-          if constexpr (KS1 >= 16 + F0) {
-            if (f >= F0 && (f - F0) % ESTEP == 0 && (f - F0) / ESTEP < 16) epilogue_step(prev, j - 1, (f - F0) / ESTEP);
-          } else {                                             // few MFMAs per chunk (K = 144): two steps per MFMA
-            if (f < 8) { epilogue_step(prev, j - 1, 2 * f); epilogue_step(prev, j - 1, 2 * f + 1); }
-          }
-        }
+      if (f == KS1 / 2) mid();
+    }
+    return acc;
+  };
+  auto nothing = [] {};
+  unsigned long long seg[6] = {0, 0, 0, 0, 0, 0};
+  auto stamp = [&]() -> unsigned long long {
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+    return t;
+  };
+  const unsigned long long t_begin = STAMP ? stamp() : 0ull;
+
+  if constexpr (PP) {
+    // ---- ping-pong schedule ------------------------------------------------------------------------------------------------------
+    // The two waves of a SIMD (w and w + 4) share its matrix pipe and its VALU issue.  Under one barrier per chunk both run the same
+    // program in phase -- epilogue beside epilogue, MFMAs beside MFMAs -- and a stamped build showed what that costs: per chunk 1325
+    // cycles in the 37 MFMAs, 1254 in epilogue + prefetch issue, and 1827 + 655 waiting (the partner's MFMAs): 5061 cycles for 2 x 1184
+    // cycles of matrix work per SIMD.  Here every chunk interval has TWO barriers and the halves run half an interval apart:
+    //     waves 0-3:  b1 | MFMAs(j)                | b2 | prefetch, epilogue(j)     |
+    //     waves 4-7:  b1 | prefetch, epilogue(j-1) | b2 | MFMAs(j)                  |
+    // so a SIMD always holds one wave in its matrix phase beside one in its VALU / memory phase, and the accumulator of a chunk is
+    // consumed by the phase right after it (no copy).  Ring invariants: chunk c is written to slot c % SLOTS after b1 of interval
+    // c - SLOTS + 1 -- the last reads of chunk c - SLOTS (trailing half, second phase of interval c - SLOTS) ended before that barrier
+    // -- and every wave waits for its own pieces (vmcnt(0), explicit: hipcc puts no wait in front of a barrier for LDS-DMA writes) at
+    // the end of its NEXT matrix phase, at least one barrier before b1 of interval c.  That wait also covers the wave's epilogue stores
+    // and residual loads, all issued a full phase earlier.
+    auto bar = [] {
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+    };
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // chunks 0 .. SLOTS - 2
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    // STAMP: segment sums of wave 0 (leading half) -> g_tl_stamp[0 .. 11], of wave 4 (trailing half) -> [12 .. 23]
+    auto tick = [&](int k, unsigned long long& t) {
+      if constexpr (STAMP) { const unsigned long long n = stamp(); seg[k] += n - t; t = n; }
+    };
+    unsigned long long t = t_begin;
+    if (wv < TL_NW / 2) {
+#pragma unroll 1
+      for (int j = 0; j < nch; ++j) {
+        bar();
+        tick(0, t);
+        if constexpr (RES) res_load(j);
+        acc = mfma_seq(j, [&] { if constexpr (PP == 2) { if (j + SLOTS - 1 < nch) issue_chunk(j + SLOTS - 1); } }, nothing);
+        if constexpr (STAMP) { asm volatile("" : "+v"(acc)); tick(1, t); }
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(acc) :: "memory");
+        tick(2, t);
+        bar();
+        tick(3, t);
+        if constexpr (PP == 1) { if (j + SLOTS - 1 < nch) issue_chunk(j + SLOTS - 1); }
+        tick(5, t);
+        epilogue(acc, j);
+        tick(4, t);
+      }
+    } else {
+#pragma unroll 1
+      for (int j = 0; j < nch; ++j) {
+        bar();
+        tick(0, t);
+        if constexpr (PP == 1) { if (j + SLOTS - 1 < nch) issue_chunk(j + SLOTS - 1); }
+        tick(5, t);
+        if (j > 0) epilogue(acc, j - 1);
+        if constexpr (RES) res_load(j);
+        tick(1, t);
+        bar();
+        tick(2, t);
+        acc = mfma_seq(j, [&] { if constexpr (PP == 2) { if (j + SLOTS - 1 < nch) issue_chunk(j + SLOTS - 1); } }, nothing);
+        if constexpr (STAMP) { asm volatile("" : "+v"(acc)); tick(3, t); }
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(acc) :: "memory");
+        tick(4, t);
+      }
+      epilogue(acc, nch - 1);
+    }
+    if constexpr (STAMP) {
+      if (blockIdx.x == 0 && (tid == 0 || tid == 256)) {
+        unsigned long long* g = g_tl_stamp + (tid ? 12 : 0);
+        for (int k = 0; k < 6; ++k) g[k] += seg[k];
+        g[6] += stamp() - t_begin; g[7] += (unsigned long long)nch; g[8] += 1;
       }
     }
-    prev = acc;
+    return;
+  }
+
+  f32x16 prev;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) prev[r] = 0.f;
+#pragma unroll 1
+  for (int j = 0; j < nch; ++j) {
+    unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+    if constexpr (STAMP) t0 = stamp();
+    // Every wave waits for its OWN DMA pieces (explicitly: hipcc puts no vmcnt wait in front of a barrier for LDS-DMA writes),
+    // then the barrier publishes chunk j and frees slot (j - 1) % SLOTS.  vmcnt(0) also covers the wave's own stores, which is
+    // why the epilogue of chunk j - 1 is issued AFTER this barrier: its stores then have a whole chunk of MFMAs to complete in.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (STAMP) t1 = stamp();
+    __syncthreads();
+    if constexpr (STAMP) t2 = stamp();
+    if constexpr (RES) { if (j > 0) res_load(j - 1); }
+    if constexpr (!RES && TSTORE) { if (j > 0) epilogue(prev, j - 1); }      // (its LDS round trip ends before the ring's counted waits begin)
+    if (j + SLOTS - 1 < nch) issue_chunk(j + SLOTS - 1);
+    if constexpr (STAMP) t3 = stamp();
+    prev = mfma_seq(
+        j, [&] { if constexpr (!RES && !TSTORE) { if (j > 0) epilogue(prev, j - 1); } },
+        [&] { if constexpr (RES) { if (j > 0) epilogue(prev, j - 1); } });
     if constexpr (STAMP) {
       asm volatile("" : "+v"(prev));
       const unsigned long long t4 = stamp();
       seg[0] += t1 - t0; seg[1] += t2 - t1; seg[2] += t3 - t2; seg[3] += t4 - t3;
     }
-  };
-  if constexpr (INTER) {
-    interval(std::true_type{}, 0);
-#pragma unroll 1
-    for (int j = 1; j < nch; ++j) interval(std::false_type{}, j);
-  } else {
-#pragma unroll 1
-    for (int j = 0; j < nch; ++j) interval(std::false_type{}, j);
   }
   if constexpr (STAMP) {
     const unsigned long long t_end = stamp();
@@ -287,13 +332,13 @@ __global__ __launch_bounds__(TL_NW * 64, 2) void tok_linear_kernel(const void* _
   epilogue(prev, nch - 1);
 }
 
-template <int K, bool LN, bool RES, bool GELU, bool TSTORE, bool STAMP = false, bool INTER = false>
+template <int K, bool LN, bool RES, bool GELU, bool TSTORE, bool STAMP = false, int PP = 0>
 int launch_tl1(const void* in, int in_ld, const float* gamma, const float* beta, float eps, const void* wp, void* out, int out_ld, long long rows,
               int N, hipStream_t s) {
   using Cfg = TlCfg<K>;
-  static hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&tok_linear_kernel<K, LN, RES, GELU, TSTORE, STAMP, INTER>), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
+  static hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&tok_linear_kernel<K, LN, RES, GELU, TSTORE, STAMP, PP>), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
   CVMI_HIP(attr);
-  hipLaunchKernelGGL((tok_linear_kernel<K, LN, RES, GELU, TSTORE, STAMP, INTER>), dim3((unsigned)(rows / 256)), dim3(TL_NW * 64), Cfg::LDS, s, in, in_ld, gamma, beta, eps,
+  hipLaunchKernelGGL((tok_linear_kernel<K, LN, RES, GELU, TSTORE, STAMP, PP>), dim3((unsigned)(rows / 256)), dim3(TL_NW * 64), Cfg::LDS, s, in, in_ld, gamma, beta, eps,
                      (const char*)wp, out, out_ld, rows, N);
   CVMI_LAUNCH_CHECK();
   return 0;
@@ -302,18 +347,27 @@ int launch_tl1(const void* in, int in_ld, const float* gamma, const float* beta,
 template <int K, bool LN, bool RES, bool GELU>
 int launch_tl(const void* in, int in_ld, const float* gamma, const float* beta, float eps, const void* wp, void* out, int out_ld, long long rows,
               int N, hipStream_t s) {
-  static const int inter = getenv("CVMI_TOKLIN_INTER") ? atoi(getenv("CVMI_TOKLIN_INTER")) : 1;        // 0 = block epilogue (A/B measurements)
-  if (inter && N % 32 == 0) return launch_tl1<K, LN, RES, GELU, false, false, true>(in, in_ld, gamma, beta, eps, wp, out, out_ld, rows, N, s);
-  if constexpr (!RES) {
-    static const int ts = getenv("CVMI_TOKLIN_TSTORE") ? atoi(getenv("CVMI_TOKLIN_TSTORE")) : 1;       // 0 = direct stores (A/B measurements)
+  static const int pp = getenv("CVMI_TOKLIN_PP") ? atoi(getenv("CVMI_TOKLIN_PP")) : 1;                 // 0 = one barrier per chunk (A/B measurements)
+  static const int ts = getenv("CVMI_TOKLIN_TSTORE") ? atoi(getenv("CVMI_TOKLIN_TSTORE")) : 1;         // 0 = direct stores (A/B measurements)
+  const bool tstore = !RES && ts && N % 8 == 0 && out_ld % 8 == 0;
 #ifndef CVMI_OPERAND_BF16
-    static const int st = getenv("CVMI_TOKLIN_STAMP") ? atoi(getenv("CVMI_TOKLIN_STAMP")) : 0;         // diagnostic build, never for timing
-    if constexpr (K == 576 && LN) {
-      if (st && N % 8 == 0) return launch_tl1<K, LN, RES, GELU, true, true>(in, in_ld, gamma, beta, eps, wp, out, out_ld, rows, N, s);
+  static const int st = getenv("CVMI_TOKLIN_STAMP") ? atoi(getenv("CVMI_TOKLIN_STAMP")) : 0;           // diagnostic build, never for timing
+  if constexpr (K == 576 && LN && !RES) {
+    if (st && tstore && (st == 1 || (st == 2) == GELU)) {       // 2: only the GELU launches (fc1), 3: only the plain ones (qkv)
+      if (pp) return launch_tl1<K, LN, RES, GELU, true, true, 1>(in, in_ld, gamma, beta, eps, wp, out, out_ld, rows, N, s);
+      return launch_tl1<K, LN, RES, GELU, true, true>(in, in_ld, gamma, beta, eps, wp, out, out_ld, rows, N, s);
     }
-#endif
-    if (ts && N % 8 == 0 && out_ld % 8 == 0) return launch_tl1<K, LN, RES, GELU, true>(in, in_ld, gamma, beta, eps, wp, out, out_ld, rows, N, s);
   }
+#endif
+  if constexpr (!RES) {
+    if (tstore) {
+      if (pp == 2) return launch_tl1<K, LN, RES, GELU, true, false, 2>(in, in_ld, gamma, beta, eps, wp, out, out_ld, rows, N, s);
+      if (pp) return launch_tl1<K, LN, RES, GELU, true, false, 1>(in, in_ld, gamma, beta, eps, wp, out, out_ld, rows, N, s);
+      return launch_tl1<K, LN, RES, GELU, true>(in, in_ld, gamma, beta, eps, wp, out, out_ld, rows, N, s);
+    }
+  }
+  if (pp == 2) return launch_tl1<K, LN, RES, GELU, false, false, 2>(in, in_ld, gamma, beta, eps, wp, out, out_ld, rows, N, s);
+  if (pp) return launch_tl1<K, LN, RES, GELU, false, false, 1>(in, in_ld, gamma, beta, eps, wp, out, out_ld, rows, N, s);
   return launch_tl1<K, LN, RES, GELU, false>(in, in_ld, gamma, beta, eps, wp, out, out_ld, rows, N, s);
 }
 
@@ -336,10 +390,12 @@ int dispatch_tl(bool ln, bool res, int act, const void* in, int in_ld, const flo
 }  // namespace
 
 #ifndef CVMI_OPERAND_BF16
-// diagnostic: read and clear the segment sums of the CVMI_TOKLIN_STAMP build: {wait, barrier, issue, mfma, total, chunks, launches, -}
-extern "C" int cvmi_debug_stamps(unsigned long long* out8) {
-  CVMI_HIP(hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_tl_stamp), 8 * sizeof(unsigned long long)));
-  unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+// diagnostic: read and clear the segment sums of the CVMI_TOKLIN_STAMP build.  Ping-pong schedule: [0 .. 8] = wave 0 {b1 wait, MFMAs, vmcnt wait,
+// b2 wait, epilogue, prefetch issue, total, chunks, launches}, [12 .. 20] = wave 4 {b1 wait, epilogue, b2 wait, MFMAs, vmcnt wait, prefetch issue,
+// total, chunks, launches}.  One-barrier schedule (CVMI_TOKLIN_PP=0): [0 .. 6] = {vmcnt wait, barrier, issue, MFMAs, total, chunks, launches}.
+extern "C" int cvmi_debug_stamps(unsigned long long* out24) {
+  CVMI_HIP(hipMemcpyFromSymbol(out24, HIP_SYMBOL(g_tl_stamp), 24 * sizeof(unsigned long long)));
+  unsigned long long z[24] = {};
   CVMI_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_tl_stamp), z, sizeof(z)));
   return 0;
 }

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define CVMI_VERSION 109
+#define CVMI_VERSION 110
 
 typedef void* cvmi_stream_t; /* hipStream_t */
 
@@ -255,9 +255,11 @@ int cvmi_tok_linear(const void* in, int in_ld, int in_f32_layernorm, const float
                     int dtype /* CVMI_F16 | CVMI_BF16: type of w_packed and of the 16-bit input / output */, cvmi_stream_t stream);
 
 /* Diagnostic only (CVMI_TOKLIN_STAMP=1 selects a stamped build of the K = 576 LayerNorm form of cvmi_tok_linear, never for timing
- * runs): reads and clears the s_memtime sums of workgroup 0 / wave 0: {DMA wait, barrier, issue (epilogue + prefetch), MFMA sequence,
- * whole kernel, chunks, launches, 0} in shader cycles. */
-int cvmi_debug_stamps(unsigned long long* out8);
+ * runs): reads and clears 24 s_memtime sums (shader cycles) of workgroup 0.  Ping-pong schedule: [0..8] = wave 0 {b1 wait, MFMAs,
+ * vmcnt wait, b2 wait, epilogue, prefetch issue, whole kernel, chunks, launches}, [12..20] = wave 4 {b1 wait, epilogue, b2 wait,
+ * MFMAs, vmcnt wait, prefetch issue, whole kernel, chunks, launches}.  One-barrier schedule (CVMI_TOKLIN_PP=0): [0..6] = {vmcnt wait,
+ * barrier, issue (epilogue + prefetch), MFMAs, whole kernel, chunks, launches}. */
+int cvmi_debug_stamps(unsigned long long* out24);
 
 /* 2x2 / stride 2 max-pool, NHWC (Hiera shortcut path of the q-pooling blocks: do_pool(proj(x))). */
 int cvmi_maxpool2x2(const void* x, int x_ld, void* y, int y_ld, int B, int H, int W, int C, int dtype,
