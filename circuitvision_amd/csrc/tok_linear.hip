@@ -35,7 +35,7 @@ template <int K> struct TlCfg {
 // g_tl_stamp (read by cvmi_debug_stamps).  Never used for timing runs: the stamps serialise what the real kernel overlaps.
 __device__ unsigned long long g_tl_stamp[24];
 
-template <int K, bool LN, bool RES, bool GELU, bool TSTORE, bool STAMP = false, int PP = 0>
+template <int K, bool LN, bool RES, bool GELU, bool TSTORE, bool STAMP = false, bool PP = false>
 __global__ __launch_bounds__(TL_NW * 64, 2) void tok_linear_kernel(const void* __restrict__ in, int in_ld, const float* __restrict__ gamma,
                                                                    const float* __restrict__ beta, float eps, const char* __restrict__ wp,
                                                                    void* __restrict__ out, int out_ld, long long rows, int N) {
@@ -254,13 +254,13 @@ __global__ __launch_bounds__(TL_NW * 64, 2) void tok_linear_kernel(const void* _
         bar();
         tick(0, t);
         if constexpr (RES) res_load(j);
-        acc = mfma_seq(j, [&] { if constexpr (PP == 2) { if (j + SLOTS - 1 < nch) issue_chunk(j + SLOTS - 1); } }, nothing);
+        acc = mfma_seq(j, nothing, nothing);
         if constexpr (STAMP) { asm volatile("" : "+v"(acc)); tick(1, t); }
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(acc) :: "memory");
         tick(2, t);
         bar();
         tick(3, t);
-        if constexpr (PP == 1) { if (j + SLOTS - 1 < nch) issue_chunk(j + SLOTS - 1); }
+        if (j + SLOTS - 1 < nch) issue_chunk(j + SLOTS - 1);
         tick(5, t);
         epilogue(acc, j);
         tick(4, t);
@@ -270,14 +270,14 @@ __global__ __launch_bounds__(TL_NW * 64, 2) void tok_linear_kernel(const void* _
       for (int j = 0; j < nch; ++j) {
         bar();
         tick(0, t);
-        if constexpr (PP == 1) { if (j + SLOTS - 1 < nch) issue_chunk(j + SLOTS - 1); }
+        if (j + SLOTS - 1 < nch) issue_chunk(j + SLOTS - 1);
         tick(5, t);
         if (j > 0) epilogue(acc, j - 1);
         if constexpr (RES) res_load(j);
         tick(1, t);
         bar();
         tick(2, t);
-        acc = mfma_seq(j, [&] { if constexpr (PP == 2) { if (j + SLOTS - 1 < nch) issue_chunk(j + SLOTS - 1); } }, nothing);
+        acc = mfma_seq(j, nothing, nothing);
         if constexpr (STAMP) { asm volatile("" : "+v"(acc)); tick(3, t); }
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(acc) :: "memory");
         tick(4, t);
@@ -332,7 +332,7 @@ __global__ __launch_bounds__(TL_NW * 64, 2) void tok_linear_kernel(const void* _
   epilogue(prev, nch - 1);
 }
 
-template <int K, bool LN, bool RES, bool GELU, bool TSTORE, bool STAMP = false, int PP = 0>
+template <int K, bool LN, bool RES, bool GELU, bool TSTORE, bool STAMP = false, bool PP = false>
 int launch_tl1(const void* in, int in_ld, const float* gamma, const float* beta, float eps, const void* wp, void* out, int out_ld, long long rows,
               int N, hipStream_t s) {
   using Cfg = TlCfg<K>;
@@ -354,20 +354,18 @@ int launch_tl(const void* in, int in_ld, const float* gamma, const float* beta, 
   static const int st = getenv("CVMI_TOKLIN_STAMP") ? atoi(getenv("CVMI_TOKLIN_STAMP")) : 0;           // diagnostic build, never for timing
   if constexpr (K == 576 && LN && !RES) {
     if (st && tstore && (st == 1 || (st == 2) == GELU)) {       // 2: only the GELU launches (fc1), 3: only the plain ones (qkv)
-      if (pp) return launch_tl1<K, LN, RES, GELU, true, true, 1>(in, in_ld, gamma, beta, eps, wp, out, out_ld, rows, N, s);
+      if (pp) return launch_tl1<K, LN, RES, GELU, true, true, true>(in, in_ld, gamma, beta, eps, wp, out, out_ld, rows, N, s);
       return launch_tl1<K, LN, RES, GELU, true, true>(in, in_ld, gamma, beta, eps, wp, out, out_ld, rows, N, s);
     }
   }
 #endif
   if constexpr (!RES) {
     if (tstore) {
-      if (pp == 2) return launch_tl1<K, LN, RES, GELU, true, false, 2>(in, in_ld, gamma, beta, eps, wp, out, out_ld, rows, N, s);
-      if (pp) return launch_tl1<K, LN, RES, GELU, true, false, 1>(in, in_ld, gamma, beta, eps, wp, out, out_ld, rows, N, s);
+      if (pp) return launch_tl1<K, LN, RES, GELU, true, false, true>(in, in_ld, gamma, beta, eps, wp, out, out_ld, rows, N, s);
       return launch_tl1<K, LN, RES, GELU, true>(in, in_ld, gamma, beta, eps, wp, out, out_ld, rows, N, s);
     }
   }
-  if (pp == 2) return launch_tl1<K, LN, RES, GELU, false, false, 2>(in, in_ld, gamma, beta, eps, wp, out, out_ld, rows, N, s);
-  if (pp) return launch_tl1<K, LN, RES, GELU, false, false, 1>(in, in_ld, gamma, beta, eps, wp, out, out_ld, rows, N, s);
+  if (pp) return launch_tl1<K, LN, RES, GELU, false, false, true>(in, in_ld, gamma, beta, eps, wp, out, out_ld, rows, N, s);
   return launch_tl1<K, LN, RES, GELU, false>(in, in_ld, gamma, beta, eps, wp, out, out_ld, rows, N, s);
 }
 
