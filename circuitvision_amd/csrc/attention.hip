@@ -581,6 +581,19 @@ int launch_attn64(const AttnArgs& a, hipStream_t stream) {
   return 0;
 }
 
+// ---- head_dim 72 kernels below: which key a score row stands for --------------------------------------------------------
+// K and V live in LDS as unpadded 144-byte rows (what the LDS-DMA writes).  The V^T operand is gathered by ds_read_b64_tr_b16: a
+// 32-lane half reads FOUR key rows x 64 bytes, and with consecutive rows at a 36-dword stride two of the four fall on the same
+// banks (PMC: SQ_LDS_BANK_CONFLICT = 1/3 of SQ_LDS_IDX_ACTIVE in all three kernels).  Rows 4 apart do not collide (4 x 36 = 144 =
+// 16 mod 64: the four 16-bank spans tile the 64 banks).  So score row i of a 32-key tile stands for key key_perm72(i): lane lr
+// feeds K row key_perm72(lr) to the QK^T MFMA (still one distinct 4-bank span per lane of a ds_read_b128 group), the softmax does not
+// care, and the P fragment's k index (16 s + 8 (j >> 2) + 4 lh + (j & 3)) then wants V rows 16 s + lh + 4 (j & 3) + 2 (j >> 2):
+// two transposing reads whose four rows are 4 apart, the second 2 rows below the first.
+__device__ __forceinline__ int key_perm72(int i) {            // i = 4 a + b  ->  16 (a >> 2) + 4 b + (a & 3)
+  const int a = i >> 2;
+  return 16 * (a >> 2) + 4 * (i & 3) + (a & 3);
+}
+
 // ---- 256-key windows of head_dim 72 (Hiera stage 3, 16 x 16): K and V of the whole window resident in LDS --------------
 // A (window, head) has only four 64-key tiles; with tile-by-tile staging the Q / first-tile latency, eight barriers and the
 // staging bookkeeping cost more than the 88 MFMAs.  Here every wave DMAs its share of the window's K and V rows
@@ -673,8 +686,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_res256_kernel(const AttnArgs 
   float m_run = -INFINITY, l_run = 0.f;
   const float c = p.scale * 1.44269504088896340736f;
   const int li = lane & 15;
-  const char* const vt = Vs + (4 * lh + (li >> 2)) * ROW + (16 * (lr >> 4) + 4 * (li & 3)) * 2;
-  const char* const kq = Ks + lr * ROW + lh * 16;
+  const char* const vt = Vs + (lh + 4 * (li >> 2)) * ROW + (16 * (lr >> 4) + 4 * (li & 3)) * 2;      // key rows 4 apart: see key_perm72
+  const char* const kq = Ks + key_perm72(lr) * ROW + lh * 16;
   __syncthreads();                                          // drains every wave's DMA (vmcnt(0)) and publishes the window
 
 #pragma unroll 1
@@ -726,7 +739,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_res256_kernel(const AttnArgs 
         for (int t = 0; t < DT; ++t) {
           const char* a0 = vt + (kc * 64 + u * 32 + s * 16) * ROW + t * 64;
           const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0));
-          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0 + 8 * ROW));
+          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0 + 2 * ROW));
           const u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
           const u32x4 vv = {l2[0], l2[1], h2[0], h2[1]};
           oacc[t] = CVMI_MFMA_32X32X16(__builtin_bit_cast(f16x8, vv), pf[u][s], oacc[t], 0, 0, 0);
@@ -848,8 +861,8 @@ __global__ __launch_bounds__(QT * 128, 4) void attn_res64_kernel(const AttnArgs 
   float m_run = -INFINITY, l_run = 0.f;
   const float c = p.scale * 1.44269504088896340736f;
   const int li = lane & 15;
-  const char* const vt = Vs + (4 * lh + (li >> 2)) * ROW + (16 * (lr >> 4) + 4 * (li & 3)) * 2;
-  const char* const kq = Ks + lr * ROW + lh * 16;
+  const char* const vt = Vs + (lh + 4 * (li >> 2)) * ROW + (16 * (lr >> 4) + 4 * (li & 3)) * 2;      // key rows 4 apart: see key_perm72
+  const char* const kq = Ks + key_perm72(lr) * ROW + lh * 16;
   __syncthreads();                                          // drains every wave's DMA (vmcnt(0)) and publishes the window
 
   {
@@ -901,7 +914,7 @@ __global__ __launch_bounds__(QT * 128, 4) void attn_res64_kernel(const AttnArgs 
         for (int t = 0; t < DT; ++t) {
           const char* a0 = vt + (kc * 64 + u * 32 + s * 16) * ROW + t * 64;
           const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0));
-          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0 + 8 * ROW));
+          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0 + 2 * ROW));
           const u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
           const u32x4 vv = {l2[0], l2[1], h2[0], h2[1]};
           oacc[t] = CVMI_MFMA_32X32X16(__builtin_bit_cast(f16x8, vv), pf[u][s], oacc[t], 0, 0, 0);
@@ -1037,8 +1050,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_dma72_kernel(const AttnArgs p
   float m_run = -INFINITY, l_run = 0.f;
   const float c = p.scale * 1.44269504088896340736f;
   const int li = lane & 15;
-  const int vt_off = TILE_B + (4 * lh + (li >> 2)) * ROW + (16 * (lr >> 4) + 4 * (li & 3)) * 2;
-  const int kq_off = lr * ROW + lh * 16;
+  const int vt_off = TILE_B + (lh + 4 * (li >> 2)) * ROW + (16 * (lr >> 4) + 4 * (li & 3)) * 2;      // key rows 4 apart: see key_perm72
+  const int kq_off = key_perm72(lr) * ROW + lh * 16;
   __syncthreads();                                          // tile 0 landed (the barrier's fence drains the DMA queue)
 
 #pragma unroll 1
@@ -1064,7 +1077,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_dma72_kernel(const AttnArgs p
       for (int u = 0; u < 2; ++u)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int key = kt * TK + u * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          const int key = kt * TK + u * 32 + key_perm72((r & 3) + 8 * (r >> 2) + 4 * lh);
           if (key >= p.Nk) sacc[u][r] = -INFINITY;
         }
     }
@@ -1103,7 +1116,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_dma72_kernel(const AttnArgs p
         for (int t = 0; t < DT; ++t) {
           const char* a0 = vt + (kc * 64 + u * 32 + s * 16) * ROW + t * 64;
           const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0));
-          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0 + 8 * ROW));
+          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0 + 2 * ROW));
           const u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
           const u32x4 vv = {l2[0], l2[1], h2[0], h2[1]};
           oacc[t] = CVMI_MFMA_32X32X16(__builtin_bit_cast(f16x8, vv), pf[u][s], oacc[t], 0, 0, 0);
