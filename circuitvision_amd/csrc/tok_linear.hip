@@ -35,16 +35,26 @@ template <int K> struct TlCfg {
 // g_tl_stamp (read by cvmi_debug_stamps).  Never used for timing runs: the stamps serialise what the real kernel overlaps.
 __device__ unsigned long long g_tl_stamp[24];
 
-template <int K, bool LN, bool RES, bool GELU, bool TSTORE, bool STAMP = false, bool PP = false>
+template <int K, bool LN, bool RES, bool GELU, bool TSTORE, bool STAMP = false, bool PP = false, bool POOL = false>
 __global__ __launch_bounds__(TL_NW * 64, 2) void tok_linear_kernel(const void* __restrict__ in, int in_ld, const float* __restrict__ gamma,
                                                                    const float* __restrict__ beta, float eps, const char* __restrict__ wp,
-                                                                   void* __restrict__ out, int out_ld, long long rows, int N) {
+                                                                   void* __restrict__ out, int out_ld, long long rows, int N, int pool_w, int pool_hw2) {
   using Cfg = TlCfg<K>;
   constexpr int KS = Cfg::KS, KS1 = Cfg::KS1, CHB = Cfg::CHB, SLOTS = Cfg::SLOTS;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int lr = lane & 31, lh = lane >> 5;
-  const long long row = ((long long)blockIdx.x * TL_NW + wv) * 32 + lr;          // rows % 256 == 0 (checked by the host): every row exists
+  // rows % 256 == 0 (checked by the host): every row exists.  POOL: lane quad q = lr / 4 holds the four tokens (dy, dx) = ((lr / 2) & 1, lr & 1)
+  // of 2 x 2 block `prow` of the [B, H, W] token grid (pool_w = W, pool_hw2 = (H / 2)(W / 2)); out is the pooled [B, H/2, W/2, N] f32 map.
+  long long row = ((long long)blockIdx.x * TL_NW + wv) * 32 + lr;
+  long long prow = 0;
+  if constexpr (POOL) {
+    prow = row >> 2;
+    const long long b = prow / pool_hw2;
+    const int r = (int)(prow - b * pool_hw2), w2 = pool_w >> 1;
+    const int py = r / w2, px = r - py * w2;
+    row = b * 4 * pool_hw2 + (long long)(2 * py + ((lr >> 1) & 1)) * pool_w + 2 * px + (lr & 1);
+  }
   const int nch = (N + 31) / 32;
 
   // chunk j -> ring slot j % SLOTS; wave w moves fragments w, w + 8, ...
@@ -136,7 +146,22 @@ __global__ __launch_bounds__(TL_NW * 64, 2) void tok_linear_kernel(const void* _
   char* const stage = smem + SLOTS * CHB + wv * Cfg::STG;
   const long long wrow0 = ((long long)blockIdx.x * TL_NW + wv) * 32;
   auto epilogue = [&](const f32x16& acc, int j) {
-    if constexpr (RES) {
+    if constexpr (POOL) {
+      // 2 x 2 max over the lane quad (two DPP quad permutes per value: lanes ^ 1, lanes ^ 2), then the quad's first lane stores
+      float* o = reinterpret_cast<float*>(out) + prow * (long long)out_ld + 32 * j + 4 * lh;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float a = acc[4 * g + e];
+          a = fmaxf(a, __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, a), 0xB1, 0xF, 0xF, true)));   // quad_perm [1,0,3,2]
+          a = fmaxf(a, __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, a), 0x4E, 0xF, 0xF, true)));   // quad_perm [2,3,0,1]
+          v[e] = a;
+        }
+        if ((lr & 3) == 0 && 32 * j + 8 * g + 4 * lh < N) *reinterpret_cast<f32x4*>(o + 8 * g) = v;
+      }
+    } else if constexpr (RES) {
       float* o = reinterpret_cast<float*>(out) + row * (long long)out_ld + 32 * j + 4 * lh;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
@@ -332,14 +357,14 @@ __global__ __launch_bounds__(TL_NW * 64, 2) void tok_linear_kernel(const void* _
   epilogue(prev, nch - 1);
 }
 
-template <int K, bool LN, bool RES, bool GELU, bool TSTORE, bool STAMP = false, bool PP = false>
+template <int K, bool LN, bool RES, bool GELU, bool TSTORE, bool STAMP = false, bool PP = false, bool POOL = false>
 int launch_tl1(const void* in, int in_ld, const float* gamma, const float* beta, float eps, const void* wp, void* out, int out_ld, long long rows,
-              int N, hipStream_t s) {
+              int N, hipStream_t s, int pool_w = 0, int pool_hw2 = 0) {
   using Cfg = TlCfg<K>;
-  static hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&tok_linear_kernel<K, LN, RES, GELU, TSTORE, STAMP, PP>), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
+  static hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&tok_linear_kernel<K, LN, RES, GELU, TSTORE, STAMP, PP, POOL>), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
   CVMI_HIP(attr);
-  hipLaunchKernelGGL((tok_linear_kernel<K, LN, RES, GELU, TSTORE, STAMP, PP>), dim3((unsigned)(rows / 256)), dim3(TL_NW * 64), Cfg::LDS, s, in, in_ld, gamma, beta, eps,
-                     (const char*)wp, out, out_ld, rows, N);
+  hipLaunchKernelGGL((tok_linear_kernel<K, LN, RES, GELU, TSTORE, STAMP, PP, POOL>), dim3((unsigned)(rows / 256)), dim3(TL_NW * 64), Cfg::LDS, s, in, in_ld, gamma, beta, eps,
+                     (const char*)wp, out, out_ld, rows, N, pool_w, pool_hw2);
   CVMI_LAUNCH_CHECK();
   return 0;
 }
@@ -431,5 +456,35 @@ extern "C" int CVMI_ENTRY(cvmi_tok_linear)(const void* in, int in_ld, int in_f32
     case 144: return dispatch_tl<144>(ln, res, act, in, in_ld, gamma, beta, eps, w_packed, out, out_ld, rows, N, s);
     case 288: return dispatch_tl<288>(ln, res, act, in, in_ld, gamma, beta, eps, w_packed, out, out_ld, rows, N, s);
     default: return dispatch_tl<576>(ln, res, act, in, in_ld, gamma, beta, eps, w_packed, out, out_ld, rows, N, s);
+  }
+}
+
+#ifndef CVMI_OPERAND_BF16
+extern "C" int cvmi_tok_linear_pool_bf16(const void* in, int in_ld, const float* gamma, const float* beta, float eps, const void* w_packed, void* out,
+                                         int out_ld, int B, int H, int W, int K, int N, int dtype, cvmi_stream_t stream_);
+#endif
+
+// out[b, y, x, :] = max over the 2 x 2 token block of ( LayerNorm(in[b, 2y + dy, 2x + dx, :]) W^T + bias ): the shortcut path of a Hiera
+// q-pooling block, `do_pool(self.proj(x_norm))` (sam2 hieradet MultiScaleBlock.forward, behind /root/reference/src/sam2_infer.py:226), in one
+// launch -- the full-resolution f32 projection (1.2 GB at the stage 1 -> 2 transition, B = 16) is neither written nor read back.
+extern "C" int CVMI_ENTRY(cvmi_tok_linear_pool)(const void* in, int in_ld, const float* gamma, const float* beta, float eps, const void* w_packed,
+                                                void* out, int out_ld, int B, int H, int W, int K, int N, int dtype, cvmi_stream_t stream_) {
+#ifndef CVMI_OPERAND_BF16
+  if (dtype == CVMI_BF16) return cvmi_tok_linear_pool_bf16(in, in_ld, gamma, beta, eps, w_packed, out, out_ld, B, H, W, K, N, dtype, stream_);
+#endif
+  CVMI_CHECK(dtype == CVMI_T16, "tok_linear_pool: dtype must be CVMI_F16 or CVMI_BF16");
+  const long long rows = (long long)B * H * W;
+  CVMI_CHECK(in && w_packed && out && gamma && beta && B > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && rows % 256 == 0 && N > 0,
+             "tok_linear_pool: bad arguments (H, W even; B*H*W a multiple of 256)");
+  CVMI_CHECK(K == 144 || K == 288 || K == 576, "tok_linear_pool: K=%d is not built (144, 288, 576)", K);
+  CVMI_CHECK(in_ld >= K && in_ld % 4 == 0 && out_ld >= N && out_ld % 4 == 0 && N % 4 == 0 &&
+                 (((uintptr_t)in | (uintptr_t)w_packed | (uintptr_t)out | (uintptr_t)gamma | (uintptr_t)beta) & 15) == 0,
+             "tok_linear_pool: pointers / ld not aligned (in_ld=%d out_ld=%d N=%d)", in_ld, out_ld, N);
+  hipStream_t s = (hipStream_t)stream_;
+  const int hw2 = (H / 2) * (W / 2);
+  switch (K) {
+    case 144: return launch_tl1<144, true, false, false, false, false, true, true>(in, in_ld, gamma, beta, eps, w_packed, out, out_ld, rows, N, s, W, hw2);
+    case 288: return launch_tl1<288, true, false, false, false, false, true, true>(in, in_ld, gamma, beta, eps, w_packed, out, out_ld, rows, N, s, W, hw2);
+    default: return launch_tl1<576, true, false, false, false, false, true, true>(in, in_ld, gamma, beta, eps, w_packed, out, out_ld, rows, N, s, W, hw2);
   }
 }

@@ -579,3 +579,23 @@ def op_tok_linear(plan, label, pt, src, dst, ln=None, act=_lib.ACT_NONE, residua
 
     bytes_ = src.rows * (pt.K * ESIZE[src.dtype] + pt.N * ESIZE[dst.dtype] * (2 if residual else 1))
     plan.add(label, kind, thunk, bytes_, 2 * src.rows * pt.N * pt.K)
+
+
+def op_tok_linear_pool(plan, label, pt, src, dst, ln, kind="gemm"):
+    """dst[b, y, x, :] = max over the 2 x 2 token block of (LayerNorm(src) W^T + b): src an f32 [B, H, W, K] View, dst f32 [B, H/2, W/2, N]
+    (`do_pool(self.proj(norm1(x)))` of a Hiera q-pooling block in one launch)."""
+    lib = _lib.load()
+    B, H, W = src.B, src.H, src.W
+    assert src.dtype == F32 and dst.dtype == F32 and src.c == pt.K and dst.c == pt.N, label
+    assert (dst.B, dst.H, dst.W) == (B, H // 2, W // 2) and H % 2 == 0 and W % 2 == 0 and (B * H * W) % 256 == 0, label
+    gam, bet, eps = ln
+    args = (src.ptr, src.ld, gam.data_ptr(), bet.data_ptr(), float(eps), pt.w.data_ptr(), dst.ptr, dst.ld, B, H, W, pt.K, pt.N, pt.dtype)
+    plan.keep.append((pt, src, dst, gam, bet))
+    sp0, fn = plan.sptr, lib.cvmi_tok_linear_pool
+
+    def thunk(sp=None):
+        sp = sp0 if sp is None else sp
+        _lib.check(fn(*args, sp), label)
+
+    rows = B * H * W
+    plan.add(label, kind, thunk, rows * pt.K * 4 + rows // 4 * pt.N * 4, 2 * rows * pt.N * pt.K)

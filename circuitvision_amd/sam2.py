@@ -30,7 +30,8 @@ import torch.nn.functional as TF
 from . import _lib
 from ._lib import ACT_GELU, ACT_NONE, ACT_RELU, ACT_SIGMOID, BF16, F16, F32
 from .engine import (ESIZE, TORCH_DTYPE, is16, Buf, PackedConv, PackedHieraMlp, PackedTokLinear, Plan, Rows, hiera_mlp_supported, make_attn_desc, op_attention,
-                     op_call, op_cast, op_conv, op_hiera_mlp, op_layernorm, op_maxpool2, op_tok_linear, require_gpu, tok_linear_supported)
+                     op_call, op_cast, op_conv, op_hiera_mlp, op_layernorm, op_maxpool2, op_tok_linear, op_tok_linear_pool, require_gpu,
+                     tok_linear_supported)
 
 HIERA_L = dict(embed_dim=144, num_heads=2, stages=(2, 6, 36, 4), global_att_blocks=(23, 33, 43), window_spec=(8, 4, 16, 8))
 HIERA_T = dict(embed_dim=96, num_heads=1, stages=(1, 2, 7, 2), global_att_blocks=(5, 7, 9), window_spec=(8, 4, 14, 7))
@@ -226,7 +227,7 @@ class Sam2Weights:
                 dim_out, heads, cur = dim * 2, heads * 2, cur + 1
             b = f"{T}.blocks.{i}"
             self._norm(f"b{i}.norm1", f"{b}.norm1", dim)
-            self._linear(f"b{i}.qkv", f"{b}.attn.qkv", 3 * dim_out, dim, tok=dim == dim_out)
+            self._linear(f"b{i}.qkv", f"{b}.attn.qkv", 3 * dim_out, dim, tok=True)
             self._linear(f"b{i}.proj", f"{b}.attn.proj", dim_out, dim_out, tok=True)
             self._norm(f"b{i}.norm2", f"{b}.norm2", dim_out)
             if self.fused_mlp and hiera_mlp_supported(dim_out, self.dtype):
@@ -239,7 +240,7 @@ class Sam2Weights:
                 self._linear(f"b{i}.fc1", f"{b}.mlp.layers.0", 4 * dim_out, dim_out, tok=True)
                 self._linear(f"b{i}.fc2", f"{b}.mlp.layers.1", dim_out, 4 * dim_out)
             if dim != dim_out:
-                self._linear(f"b{i}.dimproj", f"{b}.proj", dim_out, dim)
+                self._linear(f"b{i}.dimproj", f"{b}.proj", dim_out, dim, tok=True)
             self.blocks.append(dict(dim=dim, dim_out=dim_out, heads=heads, window=window, q_pool=i in q_pool_blocks))
             if window > 0 and i in q_pool_blocks and window % 2:
                 raise ValueError("q-pool block with odd window")
@@ -458,18 +459,24 @@ class Sam2Plan:
         if blk["q_pool"] and (ws == 0 or ws % 2 or Hp % 2 or Wp % 2):
             raise NotImplementedError("q-pool block needs an even window")
         tok_rows = not padded and (B * H * W) % 256 == 0          # token-stationary linears (tok_linear.hip) take 256-row workgroups
-        tok_qkv = tok_rows and f"b{i}.qkv" in wt.tl                # ... and fuse norm1 into the qkv projection (dim == dim_out blocks)
+        tok_qkv = tok_rows and f"b{i}.qkv" in wt.tl                # ... and fuse norm1 into the qkv projection
+        if dim != dout and os.environ.get("CVMI_SAM_QKVTOK_TRANS", "1") == "0":
+            tok_qkv = False                                        # (A/B: the transition blocks' qkv through the tiled GEMM + a norm1 launch)
+        tok_pool = tok_rows and dim != dout and f"b{i}.dimproj" in wt.tl and os.environ.get("CVMI_SAM_POOLFUSE", "1") != "0"     # norm1 + dimproj + 2 x 2 max-pool in one launch
         if padded:
             xn = self.buf(Hp, Wp, dim, tag="xn_padded", zero=True)
             op_layernorm(self.plan, f"b{i}.norm1", x.view(), gam, bet, xn.view(), 1e-6, pad=(H, W, Hp, Wp))
-        elif not tok_qkv:
+        elif not tok_qkv or (dim != dout and not tok_pool):
             xn = self.buf(H, W, dim, tag="xn")
             op_layernorm(self.plan, f"b{i}.norm1", x.view(), gam, bet, xn.view(), 1e-6)
         if dim != dout:
-            pj = self.buf(H, W, dout, F32, tag="dimproj")
-            self.gemm(f"b{i}.dimproj", f"b{i}.dimproj", xn.view(), pj.view(), out_hw=(H, W) if padded else None)
             short = self.buf(H // 2, W // 2, dout, F32)
-            op_maxpool2(self.plan, f"b{i}.pool", pj.view(), short.view())
+            if tok_pool:
+                op_tok_linear_pool(self.plan, f"b{i}.dimproj_pool", wt.tl[f"b{i}.dimproj"], x.view(), short.view(), (gam, bet, 1e-6))
+            else:
+                pj = self.buf(H, W, dout, F32, tag="dimproj")
+                self.gemm(f"b{i}.dimproj", f"b{i}.dimproj", xn.view(), pj.view(), out_hw=(H, W) if padded else None)
+                op_maxpool2(self.plan, f"b{i}.pool", pj.view(), short.view())
         else:
             short = x
         qkv = self.buf(Hp, Wp, 3 * dout, tag="qkv")

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define CVMI_VERSION 110
+#define CVMI_VERSION 111
 
 typedef void* cvmi_stream_t; /* hipStream_t */
 
@@ -253,6 +253,13 @@ size_t cvmi_tok_linear_packed_bytes(int K, int N);
 int cvmi_tok_linear(const void* in, int in_ld, int in_f32_layernorm, const float* gamma, const float* beta, float eps,
                     const void* w_packed, void* out, int out_ld, int out_f32_residual, long long rows, int K, int N, int act,
                     int dtype /* CVMI_F16 | CVMI_BF16: type of w_packed and of the 16-bit input / output */, cvmi_stream_t stream);
+
+/* Shortcut path of a Hiera q-pooling block in ONE launch: out[b, y, x, :] = max over the 2 x 2 token block of
+ * ( LayerNorm(in[b, 2y + dy, 2x + dx, :]) W^T + bias )  = `do_pool(self.proj(norm1(x)))` of sam2 hieradet MultiScaleBlock.forward (behind
+ * /root/reference/src/sam2_infer.py:226).  in: f32 [B, H, W, K] token grid (row stride in_ld); out: f32 [B, H/2, W/2, N] (row stride out_ld);
+ * w_packed as for cvmi_tok_linear; H, W even, B*H*W a multiple of 256, K in {144, 288, 576}. */
+int cvmi_tok_linear_pool(const void* in, int in_ld, const float* gamma, const float* beta, float eps, const void* w_packed, void* out,
+                         int out_ld, int B, int H, int W, int K, int N, int dtype, cvmi_stream_t stream);
 
 /* Diagnostic only (CVMI_TOKLIN_STAMP=1 selects a stamped build of the K = 576 LayerNorm form of cvmi_tok_linear, never for timing
  * runs): reads and clears 24 s_memtime sums (shader cycles) of workgroup 0.  Ping-pong schedule: [0..8] = wave 0 {b1 wait, MFMAs,

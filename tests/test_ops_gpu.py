@@ -504,3 +504,33 @@ def test_tok_linear_vs_torch(K, N, ln, res, act, dt):
     else:
         torch.testing.assert_close(got[:, :N], y, rtol=4e-3 * tol, atol=4e-3 * tol)
         assert bool((got[:, N:] == 7.0).all())               # columns beyond N untouched
+
+
+@pytest.mark.parametrize("K,N,B,H,W", [(144, 288, 2, 16, 24), (288, 576, 1, 16, 16), (576, 1152, 3, 8, 32), (144, 40, 1, 32, 8)])
+@pytest.mark.parametrize("dt", [F16, BF16])
+def test_tok_linear_pool_vs_torch(K, N, B, H, W, dt):
+    """Shortcut path of a Hiera q-pooling block in one launch (tok_linear.hip, POOL form): LayerNorm of the f32 token grid, linear layer,
+    2 x 2 max-pool over the token grid (the four tokens of a block sit in one lane quad), f32 output -- vs fp32 torch on weights rounded
+    to the operand type.  Also: N not a multiple of 32 and columns beyond N untouched."""
+    import torch.nn.functional as TF
+    from circuitvision_amd.engine import Buf, PackedTokLinear, op_tok_linear_pool
+    tol = 1.0 if dt == F16 else 8.0
+    g = torch.Generator().manual_seed(K * 7 + N)
+    w = quant(torch.randn(N, K, generator=g) / K ** 0.5, dt)
+    b = torch.randn(N, generator=g) * 0.3
+    gam, bet = torch.rand(K, generator=g) + 0.5, torch.randn(K, generator=g) * 0.2
+    x = torch.randn(B, H, W, K, generator=g) * 1.5 + 0.7
+    x[..., 5] -= 30.0
+    xin = quant(TF.layer_norm(x, (K,), gam, bet, 1e-6), dt)
+    y = xin @ w.t() + b                                                    # [B, H, W, N]
+    ref = TF.max_pool2d(y.permute(0, 3, 1, 2), 2, 2).permute(0, 2, 3, 1)   # [B, H/2, W/2, N]
+    Np = (N + 7) // 8 * 8
+    src = Buf(B, H, W, K, F32); src.t.copy_(x)
+    dst = Buf(B, H // 2, W // 2, Np, F32); dst.t.fill_(7.0)
+    pt = PackedTokLinear(w, b, dtype=dt)
+    plan = Plan(stream())
+    op_tok_linear_pool(plan, "tlp", pt, src.view(), dst.view(0, N), (gam.cuda(), bet.cuda(), 1e-6))
+    run(plan)
+    got = dst.t.float().cpu()
+    torch.testing.assert_close(got[..., :N], ref, rtol=4e-3 * tol, atol=4e-3 * tol)
+    assert bool((got[..., N:] == 7.0).all())
