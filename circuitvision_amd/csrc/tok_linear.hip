@@ -29,13 +29,14 @@ template <int K> struct TlCfg {
   static constexpr int LDS = SLOTS * CHB + TL_NW * STG;
 };
 
-// LN = true: `in` is the f32 stream (ld in_ld), normalised with gamma / beta / eps.  LN = false: `in` is fp16 [rows, in_ld].
+// LN = 1: `in` is the f32 stream (ld in_ld), normalised with gamma / beta / eps.  LN = 0: `in` is fp16 [rows, in_ld].  LN = 2: f32 rows
+// converted as they are (the neck's lateral convs read the stage outputs of the f32 stream: no cast pass).
 // RES = true: out is f32 (ld out_ld), out[r, n] += y.  RES = false: out is fp16.
 // STAMP: diagnostic build (CVMI_TOKLIN_STAMP=1): wave 0 of workgroup 0 accumulates s_memtime differences of the loop's segments into
 // g_tl_stamp (read by cvmi_debug_stamps).  Never used for timing runs: the stamps serialise what the real kernel overlaps.
 __device__ unsigned long long g_tl_stamp[24];
 
-template <int K, bool LN, bool RES, bool GELU, bool TSTORE, bool STAMP = false, bool PP = false, bool POOL = false>
+template <int K, int LN, bool RES, bool GELU, bool TSTORE, bool STAMP = false, bool PP = false, bool POOL = false>
 __global__ __launch_bounds__(TL_NW * 64, 2) void tok_linear_kernel(const void* __restrict__ in, int in_ld, const float* __restrict__ gamma,
                                                                    const float* __restrict__ beta, float eps, const char* __restrict__ wp,
                                                                    void* __restrict__ out, int out_ld, long long rows, int N, int pool_w, int pool_hw2) {
@@ -75,7 +76,18 @@ __global__ __launch_bounds__(TL_NW * 64, 2) void tok_linear_kernel(const void* _
 
   // ---- B fragments: lane (row lr, half lh) holds in[row][16 s + 8 lh .. + 7]
   u32x4 xn[KS1];
-  if constexpr (LN) {
+  if constexpr (LN == 2) {
+    const float* xr = reinterpret_cast<const float*>(in) + row * (long long)in_ld;
+#pragma unroll
+    for (int k = 0; k < KS; ++k) {
+      if (k % 3 == 0) __builtin_amdgcn_sched_barrier(0);
+      const f32x4 a = *reinterpret_cast<const f32x4*>(xr + 16 * k + 8 * lh), b = *reinterpret_cast<const f32x4*>(xr + 16 * k + 8 * lh + 4);
+      f16x8 h;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { h[e] = (f16)a[e]; h[4 + e] = (f16)b[e]; }
+      xn[k] = __builtin_bit_cast(u32x4, h);
+    }
+  } else if constexpr (LN == 1) {
     // Two passes over the row instead of K/2 live f32 registers per lane (K = 576 would need 288 of the 256 available at two
     // waves per SIMD): pass 1 accumulates sum and sum of squares of (x - x0), x0 = the row's first element (a shift that keeps
     // the single-pass variance formula well conditioned: what cancels is (mean - x0)^2, bounded by the row's own spread);
@@ -357,7 +369,7 @@ __global__ __launch_bounds__(TL_NW * 64, 2) void tok_linear_kernel(const void* _
   epilogue(prev, nch - 1);
 }
 
-template <int K, bool LN, bool RES, bool GELU, bool TSTORE, bool STAMP = false, bool PP = false, bool POOL = false>
+template <int K, int LN, bool RES, bool GELU, bool TSTORE, bool STAMP = false, bool PP = false, bool POOL = false>
 int launch_tl1(const void* in, int in_ld, const float* gamma, const float* beta, float eps, const void* wp, void* out, int out_ld, long long rows,
               int N, hipStream_t s, int pool_w = 0, int pool_hw2 = 0) {
   using Cfg = TlCfg<K>;
@@ -369,7 +381,7 @@ int launch_tl1(const void* in, int in_ld, const float* gamma, const float* beta,
   return 0;
 }
 
-template <int K, bool LN, bool RES, bool GELU>
+template <int K, int LN, bool RES, bool GELU>
 int launch_tl(const void* in, int in_ld, const float* gamma, const float* beta, float eps, const void* wp, void* out, int out_ld, long long rows,
               int N, hipStream_t s) {
   static const int pp = getenv("CVMI_TOKLIN_PP") ? atoi(getenv("CVMI_TOKLIN_PP")) : 1;                 // 0 = one barrier per chunk (A/B measurements)
@@ -377,7 +389,7 @@ int launch_tl(const void* in, int in_ld, const float* gamma, const float* beta, 
   const bool tstore = !RES && ts && N % 8 == 0 && out_ld % 8 == 0;
 #ifndef CVMI_OPERAND_BF16
   static const int st = getenv("CVMI_TOKLIN_STAMP") ? atoi(getenv("CVMI_TOKLIN_STAMP")) : 0;           // diagnostic build, never for timing
-  if constexpr (K == 576 && LN && !RES) {
+  if constexpr (K == 576 && LN == 1 && !RES) {
     if (st && tstore && (st == 1 || (st == 2) == GELU)) {       // 2: only the GELU launches (fc1), 3: only the plain ones (qkv)
       if (pp) return launch_tl1<K, LN, RES, GELU, true, true, true>(in, in_ld, gamma, beta, eps, wp, out, out_ld, rows, N, s);
       return launch_tl1<K, LN, RES, GELU, true, true>(in, in_ld, gamma, beta, eps, wp, out, out_ld, rows, N, s);
@@ -395,19 +407,23 @@ int launch_tl(const void* in, int in_ld, const float* gamma, const float* beta, 
 }
 
 template <int K>
-int dispatch_tl(bool ln, bool res, int act, const void* in, int in_ld, const float* gamma, const float* beta, float eps, const void* wp, void* out,
+int dispatch_tl(int ln, bool res, int act, const void* in, int in_ld, const float* gamma, const float* beta, float eps, const void* wp, void* out,
                 int out_ld, long long rows, int N, hipStream_t s) {
   const bool gelu = act == CVMI_ACT_GELU;
+  if (ln == 2) {
+    if constexpr (K <= 288) return launch_tl<K, 2, false, false>(in, in_ld, gamma, beta, eps, wp, out, out_ld, rows, N, s);
+    CVMI_FAIL("tok_linear: plain f32 input is built for K = 144 and 288");
+  }
   if (res) {
-    if (ln) return launch_tl<K, true, true, false>(in, in_ld, gamma, beta, eps, wp, out, out_ld, rows, N, s);
-    return launch_tl<K, false, true, false>(in, in_ld, gamma, beta, eps, wp, out, out_ld, rows, N, s);
+    if (ln) return launch_tl<K, 1, true, false>(in, in_ld, gamma, beta, eps, wp, out, out_ld, rows, N, s);
+    return launch_tl<K, 0, true, false>(in, in_ld, gamma, beta, eps, wp, out, out_ld, rows, N, s);
   }
   if (ln) {
-    if (gelu) return launch_tl<K, true, false, true>(in, in_ld, gamma, beta, eps, wp, out, out_ld, rows, N, s);
-    return launch_tl<K, true, false, false>(in, in_ld, gamma, beta, eps, wp, out, out_ld, rows, N, s);
+    if (gelu) return launch_tl<K, 1, false, true>(in, in_ld, gamma, beta, eps, wp, out, out_ld, rows, N, s);
+    return launch_tl<K, 1, false, false>(in, in_ld, gamma, beta, eps, wp, out, out_ld, rows, N, s);
   }
-  if (gelu) return launch_tl<K, false, false, true>(in, in_ld, gamma, beta, eps, wp, out, out_ld, rows, N, s);
-  return launch_tl<K, false, false, false>(in, in_ld, gamma, beta, eps, wp, out, out_ld, rows, N, s);
+  if (gelu) return launch_tl<K, 0, false, true>(in, in_ld, gamma, beta, eps, wp, out, out_ld, rows, N, s);
+  return launch_tl<K, 0, false, false>(in, in_ld, gamma, beta, eps, wp, out, out_ld, rows, N, s);
 }
 
 }  // namespace
@@ -444,14 +460,17 @@ extern "C" int CVMI_ENTRY(cvmi_tok_linear)(const void* in, int in_ld, int in_f32
   CVMI_CHECK(dtype == CVMI_T16, "tok_linear: dtype must be CVMI_F16 or CVMI_BF16");
   CVMI_CHECK(in && w_packed && out && rows > 0 && rows % 256 == 0 && N > 0, "tok_linear: bad arguments (rows must be a multiple of 256)");
   CVMI_CHECK(K == 144 || K == 288 || K == 576, "tok_linear: K=%d is not built (144, 288, 576)", K);
-  CVMI_CHECK(!in_f32_layernorm || (gamma && beta), "tok_linear: LayerNorm input needs gamma / beta");
+  CVMI_CHECK(in_f32_layernorm != 1 || (gamma && beta), "tok_linear: LayerNorm input needs gamma / beta");
+  CVMI_CHECK(in_f32_layernorm >= 0 && in_f32_layernorm <= 2 && (in_f32_layernorm != 2 || (!out_f32_residual && act == CVMI_ACT_NONE)),
+             "tok_linear: in_f32_layernorm must be 0, 1 or 2 (2: 16-bit output, no activation)");
   CVMI_CHECK(act == CVMI_ACT_NONE || (act == CVMI_ACT_GELU && !out_f32_residual), "tok_linear: act must be NONE, or GELU with 16-bit output");
   CVMI_CHECK(in_ld >= K && in_ld % (in_f32_layernorm ? 4 : 8) == 0 && out_ld >= N && out_ld % 4 == 0 && N % 4 == 0 &&
                  (((uintptr_t)in | (uintptr_t)w_packed | (uintptr_t)out) & 15) == 0 &&
-                 (!in_f32_layernorm || (((uintptr_t)gamma | (uintptr_t)beta) & 15) == 0),
+                 (in_f32_layernorm != 1 || (((uintptr_t)gamma | (uintptr_t)beta) & 15) == 0),
              "tok_linear: pointers / ld not aligned (in_ld=%d out_ld=%d N=%d)", in_ld, out_ld, N);
   hipStream_t s = (hipStream_t)stream_;
-  const bool ln = in_f32_layernorm != 0, res = out_f32_residual != 0;
+  const int ln = in_f32_layernorm;
+  const bool res = out_f32_residual != 0;
   switch (K) {
     case 144: return dispatch_tl<144>(ln, res, act, in, in_ld, gamma, beta, eps, w_packed, out, out_ld, rows, N, s);
     case 288: return dispatch_tl<288>(ln, res, act, in, in_ld, gamma, beta, eps, w_packed, out, out_ld, rows, N, s);
@@ -483,8 +502,8 @@ extern "C" int CVMI_ENTRY(cvmi_tok_linear_pool)(const void* in, int in_ld, const
   hipStream_t s = (hipStream_t)stream_;
   const int hw2 = (H / 2) * (W / 2);
   switch (K) {
-    case 144: return launch_tl1<144, true, false, false, false, false, true, true>(in, in_ld, gamma, beta, eps, w_packed, out, out_ld, rows, N, s, W, hw2);
-    case 288: return launch_tl1<288, true, false, false, false, false, true, true>(in, in_ld, gamma, beta, eps, w_packed, out, out_ld, rows, N, s, W, hw2);
-    default: return launch_tl1<576, true, false, false, false, false, true, true>(in, in_ld, gamma, beta, eps, w_packed, out, out_ld, rows, N, s, W, hw2);
+    case 144: return launch_tl1<144, 1, false, false, false, false, true, true>(in, in_ld, gamma, beta, eps, w_packed, out, out_ld, rows, N, s, W, hw2);
+    case 288: return launch_tl1<288, 1, false, false, false, false, true, true>(in, in_ld, gamma, beta, eps, w_packed, out, out_ld, rows, N, s, W, hw2);
+    default: return launch_tl1<576, 1, false, false, false, false, true, true>(in, in_ld, gamma, beta, eps, w_packed, out, out_ld, rows, N, s, W, hw2);
   }
 }

@@ -561,14 +561,17 @@ class PackedTokLinear:
 
 
 def op_tok_linear(plan, label, pt, src, dst, ln=None, act=_lib.ACT_NONE, residual=False, kind="gemm"):
-    """src: f32 View with ln = (gamma, beta, eps), or an fp16 View.  dst: fp16 View, or (residual=True) the f32 View updated in place."""
+    """src: f32 View with ln = (gamma, beta, eps) or ln = "cast" (f32 rows converted as they are, K <= 288), or an fp16 View.
+    dst: fp16 View, or (residual=True) the f32 View updated in place."""
     lib = _lib.load()
     src, dst = _as_rows(src), _as_rows(dst)
     assert src.C == pt.K and dst.C == pt.N and src.rows == dst.rows and src.rows % 256 == 0, label
     assert (src.dtype == F32) == (ln is not None) and (dst.dtype == F32) == bool(residual), label
     assert (ln is not None or src.dtype == pt.dtype) and (residual or dst.dtype == pt.dtype), label
-    gam, bet, eps = ln if ln is not None else (None, None, 0.0)
-    args = (src.ptr, src.ld, 1 if ln is not None else 0, gam.data_ptr() if ln is not None else None, bet.data_ptr() if ln is not None else None,
+    cast = isinstance(ln, str)
+    assert not cast or ln == "cast", label
+    gam, bet, eps = ln if (ln is not None and not cast) else (None, None, 0.0)
+    args = (src.ptr, src.ld, 2 if cast else 1 if ln is not None else 0, gam.data_ptr() if gam is not None else None, bet.data_ptr() if bet is not None else None,
             float(eps), pt.w.data_ptr(), dst.ptr, dst.ld, 1 if residual else 0, src.rows, pt.K, pt.N, act, pt.dtype)
     plan.keep.append((pt, src, dst, gam, bet))
     sp0, fn = plan.sptr, lib.cvmi_tok_linear

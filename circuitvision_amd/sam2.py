@@ -257,6 +257,10 @@ class Sam2Weights:
         # level 0 (256^2, 144 ch): conv_s0 o lateral ; level 1 (128^2, 288 ch): conv_s1 o lateral
         self._pack("feat_s0", _lin(ws0 @ wn[3]), ws0 @ bn[3] + bs0)
         self._pack("feat_s1", _lin(ws1 @ wn[2]), ws1 @ bn[2] + bs1)
+        if self.use_tok and is16(self.dtype):                    # ... and for tok_linear's plain-f32-input form: the stage outputs need no cast pass
+            for key, w_, b_ in (("feat_s0", ws0 @ wn[3], ws0 @ bn[3] + bs0), ("feat_s1", ws1 @ wn[2], ws1 @ bn[2] + bs1)):
+                if tok_linear_supported(w_.shape[1], self.dtype, 256) and w_.shape[1] <= 288:
+                    self.tl[key] = PackedTokLinear(w_, b_, self.device, self.dtype)
         # level 2 (64^2): lateral(stage 3, 576) + nearest2x(lateral(stage 4, 1152)) as one K-concatenated GEMM
         self._pack("embed", _lin(torch.cat((wn[1], wn[0]), 1)), bn[1] + bn[0])
         fs = self.image_size // 16
@@ -543,11 +547,15 @@ class Sam2Plan:
             o = self.buf(buf.H, buf.W, buf.C, dt)
             op_cast(self.plan, f"cast.{tag}", buf.view(), o.view())
             return o
-        s0, s1, s2, s3 = (cast(b, f"s{j}") for j, b in enumerate(st))
         feat_s0 = self.buf(f0, f0, 32)
         feat_s1 = self.buf(f1, f1, 64)
-        self.gemm("feat_s0", "feat_s0", s0.view(), feat_s0.view(), kind="neck")
-        self.gemm("feat_s1", "feat_s1", s1.view(), feat_s1.view(), kind="neck")
+        fused = os.environ.get("CVMI_SAM_NECKCAST", "1") != "0"
+        for key, src, dstb, tag in (("feat_s0", st[0], feat_s0, "s0"), ("feat_s1", st[1], feat_s1, "s1")):
+            if fused and key in wt.tl and src.dtype == F32 and (B * src.H * src.W) % 256 == 0:
+                op_tok_linear(self.plan, key, wt.tl[key], src.view(), dstb.view(), ln="cast", kind="neck")     # reads the f32 stage output itself
+            else:
+                self.gemm(key, key, cast(src, tag).view(), dstb.view(), kind="neck")
+        s2, s3 = cast(st[2], "s2"), cast(st[3], "s3")
         lib = _lib.load()
         NP = self.P                                   # prompts per image (0: learned prompts)
         NB = B * NP if NP else B                      # decoder batch: (image, prompt) pairs, image-major

@@ -242,7 +242,8 @@ int cvmi_hiera_mlp(void* x, int x_ld, const float* gamma, const float* beta, flo
  * mlp.layers[0](norm2(x)) + GELU; behind sam2_infer.py:226):
  *   y[r, n] = act( sum_k in[r, k] * W[n, k] + b[n] ),   r < rows (a multiple of 256), n < N, K in {144, 288, 576}
  *   in_f32_layernorm = 1: in is the f32 residual stream, normalised on the fly with gamma / beta / eps (the separate LayerNorm pass
- *                         and its fp16 copy disappear); 0: in is an fp16 matrix
+ *                         and its fp16 copy disappear); 0: in is an fp16 matrix; 2: in is an f32 matrix converted as it is (K = 144, 288;
+ *                         16-bit output, no activation: the neck's lateral convs read the f32 stage outputs, FpnNeck behind sam2_infer.py:226)
  *   out_f32_residual = 1: out is the f32 residual stream, updated in place (out[r, n] += y[r, n], act must be NONE);
  *                      0: out is fp16 (act NONE or GELU)
  * w_packed: ceil(N/32) chunks of (K/16 + 1) MFMA fragments of 1 KiB, fragment (j, s), lane l (r = l & 31, h = l >> 5), element e:

@@ -458,7 +458,8 @@ def test_hiera_mlp_fused_vs_torch(C_, rows, dt):
 
 @pytest.mark.parametrize("K,N,ln,res,act", [(144, 432, True, False, ACT_NONE), (288, 864, True, False, ACT_NONE), (576, 1728, True, False, ACT_NONE),
                                             (576, 2304, True, False, ACT_GELU), (576, 576, False, True, ACT_NONE), (144, 144, False, True, ACT_NONE),
-                                            (288, 104, False, False, ACT_GELU), (576, 40, True, True, ACT_NONE), (144, 432, True, False, ACT_GELU), (288, 288, True, True, ACT_NONE)])
+                                            (288, 104, False, False, ACT_GELU), (576, 40, True, True, ACT_NONE), (144, 432, True, False, ACT_GELU), (288, 288, True, True, ACT_NONE),
+                                            (144, 32, "cast", False, ACT_NONE), (288, 64, "cast", False, ACT_NONE)])
 @pytest.mark.parametrize("dt", [F16, BF16])
 def test_tok_linear_vs_torch(K, N, ln, res, act, dt):
     """Token-stationary linear layer (tok_linear.hip): optional fused LayerNorm of the f32 stream on the way in, 16-bit output with
@@ -473,7 +474,11 @@ def test_tok_linear_vs_torch(K, N, ln, res, act, dt):
     w = quant(torch.randn(N, K, generator=g) / K ** 0.5, dt)
     b = torch.randn(N, generator=g) * 0.3
     gam, bet = torch.rand(K, generator=g) + 0.5, torch.randn(K, generator=g) * 0.2
-    if ln:
+    if ln == "cast":                                        # f32 rows converted as they are (the neck's lateral convs on the f32 stream)
+        x = torch.randn(rows, K, generator=g) * 1.5 + 0.7
+        xin = quant(x, dt)
+        src_t = x.cuda()
+    elif ln:
         x = torch.randn(rows, K, generator=g) * 1.5 + 0.7
         x[:, 3] += 40.0                                     # an outlier channel: the variance pass must cope
         xin = quant(TF.layer_norm(x, (K,), gam, bet, 1e-6), dt)
@@ -495,7 +500,7 @@ def test_tok_linear_vs_torch(K, N, ln, res, act, dt):
         dst_t = torch.full((rows, Np), 7.0, dtype=td, device="cuda")
     pt = PackedTokLinear(w, b, dtype=dt)
     plan = Plan(stream())
-    op_tok_linear(plan, "tl", pt, Rows(src_t, rows, K), Rows(dst_t, rows, N, ld=Np), ln=(gam.cuda(), bet.cuda(), 1e-6) if ln else None,
+    op_tok_linear(plan, "tl", pt, Rows(src_t, rows, K), Rows(dst_t, rows, N, ld=Np), ln="cast" if ln == "cast" else (gam.cuda(), bet.cuda(), 1e-6) if ln else None,
                   act=act, residual=res)
     run(plan)
     got = dst_t.float().cpu()
