@@ -30,6 +30,15 @@ struct AttnArgs {
   FastDiv div_win; // window mode: key -> (row, column) inside the window without a hardware division
 };
 
+// fmaxf compiles to v_max_f32 plus a canonicalising `v_max_f32 x, x, x` for every operand that comes out of an MFMA (llvm.maxnum wants
+// quieted inputs): the row maximum of a 64-key tile cost 54 VALU instructions for 32 values.  v_max3_f32 through (non-volatile) asm is
+// 17.  NaN handling is the instruction's own (a NaN operand is ignored while another operand is a number).
+__device__ __forceinline__ float max3f(float a, float b, float c) {
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+
 // element offset of token t of batch entry b (window mode: b enumerates windows of an image grid)
 __device__ __forceinline__ long long tok_off(int b, int t, long long sb, long long st, int win, int gh, int gw) {
   if (win <= 0) return (long long)b * sb + (long long)t * st;
@@ -250,11 +259,11 @@ __global__ __launch_bounds__(256) void attn_f16_kernel(const AttnArgs p) {
         if (key >= p.Nk) sacc[r] = -INFINITY;
       }
     }
-    float mx = sacc[0];
+    float mxa = max3f(sacc[0], sacc[1], sacc[2]);
 #pragma unroll
-    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sacc[r]);
-    mx = fmaxf(mx, __shfl_xor(mx, 32));
-    const float m_new = fmaxf(m_run, mx);
+    for (int r = 3; r < 15; r += 2) mxa = max3f(mxa, sacc[r], sacc[r + 1]);
+    const float mx = max3f(mxa, sacc[15], sacc[15]);
+    const float m_new = max3f(m_run, mx, __shfl_xor(mx, 32));
     // raw v_exp_f32: arguments are <= 0, so exp2f's denormal-range rescue (5 extra instructions per value) buys nothing
     const float mc = m_new * c;
     const float alpha = __builtin_amdgcn_exp2f(fmaf(m_run, c, -mc));
@@ -498,11 +507,11 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn64_kernel(const 
           if (key >= p.Nk) sacc[u][r] = -INFINITY;
         }
     }
-    float mx = fmaxf(sacc[0][0], sacc[1][0]);
+    float mxa = max3f(sacc[0][0], sacc[1][0], sacc[0][8]), mxb = max3f(sacc[1][8], sacc[0][1], sacc[1][1]);      // two chains of v_max3_f32
 #pragma unroll
-    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, fmaxf(sacc[0][r], sacc[1][r]));
-    mx = fmaxf(mx, __shfl_xor(mx, 32));
-    const float m_new = fmaxf(m_run, mx);
+    for (int r = 2; r < 8; ++r) { mxa = max3f(mxa, sacc[0][r], sacc[1][r]); mxb = max3f(mxb, sacc[0][r + 7], sacc[1][r + 7]); }
+    const float mx = max3f(mxa, mxb, max3f(sacc[0][15], sacc[1][15], mxa));
+    const float m_new = max3f(m_run, mx, __shfl_xor(mx, 32));
     const float mc = m_new * c;
     const float alpha = __builtin_amdgcn_exp2f(fmaf(m_run, c, -mc));
     float psum = 0.f;
@@ -704,11 +713,11 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_res256_kernel(const AttnArgs 
         const f16x8 kf = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(kq + (kc * 64 + u * 32) * ROW + s * 32));
         sacc[u] = CVMI_MFMA_32X32X16(kf, __builtin_bit_cast(f16x8, qf[s]), sacc[u], 0, 0, 0);
       }
-    float mx = fmaxf(sacc[0][0], sacc[1][0]);
+    float mxa = max3f(sacc[0][0], sacc[1][0], sacc[0][8]), mxb = max3f(sacc[1][8], sacc[0][1], sacc[1][1]);      // two chains of v_max3_f32
 #pragma unroll
-    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, fmaxf(sacc[0][r], sacc[1][r]));
-    mx = fmaxf(mx, __shfl_xor(mx, 32));
-    const float m_new = fmaxf(m_run, mx);
+    for (int r = 2; r < 8; ++r) { mxa = max3f(mxa, sacc[0][r], sacc[1][r]); mxb = max3f(mxb, sacc[0][r + 7], sacc[1][r + 7]); }
+    const float mx = max3f(mxa, mxb, max3f(sacc[0][15], sacc[1][15], mxa));
+    const float m_new = max3f(m_run, mx, __shfl_xor(mx, 32));
     const float mc = m_new * c;
     const float alpha = __builtin_amdgcn_exp2f(fmaf(m_run, c, -mc));
     float psum = 0.f;
@@ -879,11 +888,11 @@ __global__ __launch_bounds__(QT * 128, 4) void attn_res64_kernel(const AttnArgs 
         const f16x8 kf = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(kq + (kc * 64 + u * 32) * ROW + s * 32));
         sacc[u] = CVMI_MFMA_32X32X16(kf, __builtin_bit_cast(f16x8, qf[s]), sacc[u], 0, 0, 0);
       }
-    float mx = fmaxf(sacc[0][0], sacc[1][0]);
+    float mxa = max3f(sacc[0][0], sacc[1][0], sacc[0][8]), mxb = max3f(sacc[1][8], sacc[0][1], sacc[1][1]);      // two chains of v_max3_f32
 #pragma unroll
-    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, fmaxf(sacc[0][r], sacc[1][r]));
-    mx = fmaxf(mx, __shfl_xor(mx, 32));
-    const float m_new = fmaxf(m_run, mx);
+    for (int r = 2; r < 8; ++r) { mxa = max3f(mxa, sacc[0][r], sacc[1][r]); mxb = max3f(mxb, sacc[0][r + 7], sacc[1][r + 7]); }
+    const float mx = max3f(mxa, mxb, max3f(sacc[0][15], sacc[1][15], mxa));
+    const float m_new = max3f(m_run, mx, __shfl_xor(mx, 32));
     const float mc = m_new * c;
     const float alpha = __builtin_amdgcn_exp2f(fmaf(m_run, c, -mc));
     float psum = 0.f;
@@ -1081,11 +1090,11 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_dma72_kernel(const AttnArgs p
           if (key >= p.Nk) sacc[u][r] = -INFINITY;
         }
     }
-    float mx = fmaxf(sacc[0][0], sacc[1][0]);
+    float mxa = max3f(sacc[0][0], sacc[1][0], sacc[0][8]), mxb = max3f(sacc[1][8], sacc[0][1], sacc[1][1]);      // two chains of v_max3_f32
 #pragma unroll
-    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, fmaxf(sacc[0][r], sacc[1][r]));
-    mx = fmaxf(mx, __shfl_xor(mx, 32));
-    const float m_new = fmaxf(m_run, mx);
+    for (int r = 2; r < 8; ++r) { mxa = max3f(mxa, sacc[0][r], sacc[1][r]); mxb = max3f(mxb, sacc[0][r + 7], sacc[1][r + 7]); }
+    const float mx = max3f(mxa, mxb, max3f(sacc[0][15], sacc[1][15], mxa));
+    const float m_new = max3f(m_run, mx, __shfl_xor(mx, 32));
     const float mc = m_new * c;
     const float alpha = __builtin_amdgcn_exp2f(fmaf(m_run, c, -mc));
     float psum = 0.f;
