@@ -30,14 +30,12 @@ struct AttnArgs {
   FastDiv div_win; // window mode: key -> (row, column) inside the window without a hardware division
 };
 
-// fmaxf compiles to v_max_f32 plus a canonicalising `v_max_f32 x, x, x` for every operand that comes out of an MFMA (llvm.maxnum wants
-// quieted inputs): the row maximum of a 64-key tile cost 54 VALU instructions for 32 values.  v_max3_f32 through (non-volatile) asm is
-// 17.  NaN handling is the instruction's own (a NaN operand is ignored while another operand is a number).
-__device__ __forceinline__ float max3f(float a, float b, float c) {
-  float r;
-  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-  return r;
-}
+// Row maxima of the score tiles.  fmaxf on values that come out of an MFMA compiles to v_max_f32 plus a canonicalising `v_max_f32 x, x, x`
+// per operand (llvm.maxnum wants quieted inputs): 54 VALU instructions for the 32 values of a 64-key tile.  This translation unit is built
+// with -fno-honor-nans (Makefile), under which the same source becomes 16 v_max3_f32.  NOT inline asm: hipcc's hazard recogniser cannot
+// see into an asm statement, so an asm v_max3 reading an MFMA result gets no XDL-write -> VALU-read wait states and returns stale
+// accumulators now and then (measured: replays of the same graph differed in the last bits -- tests/*_replay_properties).
+__device__ __forceinline__ float max3f(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
 
 // element offset of token t of batch entry b (window mode: b enumerates windows of an image grid)
 __device__ __forceinline__ long long tok_off(int b, int t, long long sb, long long st, int win, int gh, int gw) {
@@ -590,6 +588,11 @@ int launch_attn64(const AttnArgs& a, hipStream_t stream) {
   return 0;
 }
 
+// hipcc places NO `s_waitcnt vmcnt(0)` in front of an s_barrier for in-flight LDS-DMA writes (global_load_lds): __syncthreads()'s fence only
+// produces one when an ordinary load happens to be outstanding -- which is how these kernels passed until an unrelated change moved their
+// Q-fragment loads.  Every barrier that publishes DMA'd data is therefore preceded by this explicit wait.
+__device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 // ---- head_dim 72 kernels below: which key a score row stands for --------------------------------------------------------
 // K and V live in LDS as unpadded 144-byte rows (what the LDS-DMA writes).  The V^T operand is gathered by ds_read_b64_tr_b16: a
 // 32-lane half reads FOUR key rows x 64 bytes, and with consecutive rows at a 36-dword stride two of the four fall on the same
@@ -697,7 +700,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_res256_kernel(const AttnArgs 
   const int li = lane & 15;
   const char* const vt = Vs + (lh + 4 * (li >> 2)) * ROW + (16 * (lr >> 4) + 4 * (li & 3)) * 2;      // key rows 4 apart: see key_perm72
   const char* const kq = Ks + key_perm72(lr) * ROW + lh * 16;
-  __syncthreads();                                          // drains every wave's DMA (vmcnt(0)) and publishes the window
+  dma_wait();                                               // every wave waits for its OWN LDS-DMA pieces ...
+  __syncthreads();                                          // ... and the barrier publishes the window
 
 #pragma unroll 1
   for (int kc = 0; kc < NK / 64; ++kc) {
@@ -872,7 +876,8 @@ __global__ __launch_bounds__(QT * 128, 4) void attn_res64_kernel(const AttnArgs 
   const int li = lane & 15;
   const char* const vt = Vs + (lh + 4 * (li >> 2)) * ROW + (16 * (lr >> 4) + 4 * (li & 3)) * 2;      // key rows 4 apart: see key_perm72
   const char* const kq = Ks + key_perm72(lr) * ROW + lh * 16;
-  __syncthreads();                                          // drains every wave's DMA (vmcnt(0)) and publishes the window
+  dma_wait();                                               // every wave waits for its OWN LDS-DMA pieces ...
+  __syncthreads();                                          // ... and the barrier publishes the window
 
   {
     constexpr int kc = 0;
@@ -1061,7 +1066,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_dma72_kernel(const AttnArgs p
   const int li = lane & 15;
   const int vt_off = TILE_B + (lh + 4 * (li >> 2)) * ROW + (16 * (lr >> 4) + 4 * (li & 3)) * 2;      // key rows 4 apart: see key_perm72
   const int kq_off = key_perm72(lr) * ROW + lh * 16;
-  __syncthreads();                                          // tile 0 landed (the barrier's fence drains the DMA queue)
+  dma_wait();
+  __syncthreads();                                          // tile 0 landed
 
 #pragma unroll 1
   for (int kt = 0; kt < nkt; ++kt) {
@@ -1130,6 +1136,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_dma72_kernel(const AttnArgs p
           const u32x4 vv = {l2[0], l2[1], h2[0], h2[1]};
           oacc[t] = CVMI_MFMA_32X32X16(__builtin_bit_cast(f16x8, vv), pf[u][s], oacc[t], 0, 0, 0);
         }
+    dma_wait();                                             // this wave's pieces of tile kt + 1 (issued a whole tile of MFMAs ago)
     __syncthreads();                                        // tile kt fully read; tile kt + 1 landed in every wave
   }
   if (q_ok) {

@@ -582,6 +582,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_glds_kernel(const ConvKA
   for (int i = 0; i < TN; ++i) { const int row = BM + wn * WTN + i * 32 + lr; w_off[i] = row * BKB; w_sw[i] = (row >> 1) & 7; }
 
   issue(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // explicit: hipcc puts no vmcnt wait in front of a barrier for LDS-DMA writes
   __syncthreads();
   for (int kt = 0; kt < nk; ++kt) {
     const char* st = smem + (kt & 1) * STAGE;
@@ -598,7 +599,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_glds_kernel(const ConvKA
 #pragma unroll
         for (int j = 0; j < TM; ++j) Mma<T>::run(wf[i], xf[j], acc[i][j]);
     }
-    __syncthreads();                               // drains this wave's DMA (vmcnt(0)) and frees the stage just read
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces of the next stage (explicit, see above)
+    __syncthreads();                               // publishes them and frees the stage just read
   }
   gemm_epilogue<T, TO, BM, BN, WM, WN>(p, acc, smem, m0, n0);
 }
