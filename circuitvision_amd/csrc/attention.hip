@@ -1418,6 +1418,10 @@ int launch_f16_gs(const AttnArgs& a, hipStream_t stream) {
   static const int use64 = getenv("CVMI_ATTN64") ? atoi(getenv("CVMI_ATTN64")) : 2;      // tuning experiments only: 0 old, 1 four waves, 2 eight
   if (a.qtiles >= 8 && use64 == 2) return launch_attn64<DQKP, DVP, 8>(a, stream);
   if (a.qtiles >= 4) return use64 ? launch_attn64<DQKP, DVP, 4>(a, stream) : launch_f16<DQKP, DVP, 256>(a, stream);
+  // two or three query tiles against a LONG key axis (mask-decoder token -> image attention: 38 tokens x 4096 positions): alone, each wave
+  // walks 128 key tiles through its private LDS slice; in the shared-tile kernel the idle waves of the workgroup help to stage the tiles
+  static const int longk = getenv("CVMI_ATTN64_LONGK") ? atoi(getenv("CVMI_ATTN64_LONGK")) : 1;         // tuning experiments only
+  if (longk && use64 && a.qtiles >= 2 && a.Nk >= 2048 && a.win == 0) return longk == 2 ? launch_attn64<DQKP, DVP, 8>(a, stream) : launch_attn64<DQKP, DVP, 4>(a, stream);
   return launch_f16<DQKP, DVP, 64>(a, stream);
 }
 
