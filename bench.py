@@ -18,7 +18,8 @@ over 64 images TOTAL, sharded over the ranks -- strong scaling).
 GPU); under torchrun WORLD_SIZE must equal --gpus.
 
 Prints ONE JSON line (rank 0).  Extra objects:
-  roofline      the dominant kernel family of the workload (default: the Hiera linear-layer GEMMs, MFMA-bound);
+  roofline      the dominant kernel of the workload (default: Hiera stage-3 fc1 = tok_linear_kernel<576, LN, GELU>, MFMA-bound: 36 launches per
+                B=16 pass, algorithmic flops per launch / average HIP-event duration of those launches);
   rooflines     every family the north_star sets a target on: YOLO11-n conv stack vs the HBM roof (SURVEY.md 8(d) algorithmic
                 bytes: 81.8 MB fp16 activations / image + 5.2 MB weights / batch), Hiera GEMMs, global and windowed attention vs
                 the dense fp16 MFMA peak.  `achieved` = algorithmic bytes (flops) / the summed duration of those launches,
@@ -312,13 +313,25 @@ class SamStage:
 
     def profile(self, reps=2):
         acc = {}
+        dom = [0.0, 0, 0.0]                                       # the single dominant kernel: stage-3 fc1 (tok_linear, K=576, N=2304, LayerNorm + GELU fused)
         self.plan.timed_eager()
         for _ in range(reps):
             for label, kind, ms, b, f in self.plan.timed_eager():
                 k = acc.setdefault(kind, [0.0, 0, 0, 0])
                 k[0] += ms / reps; k[1] += 1; k[2] += b / reps; k[3] += f / reps
+                if label.endswith(".fc1") and f == 2.0 * self.B * 4096 * 576 * 2304:
+                    dom[0] += ms; dom[1] += 1; dom[2] = f
         total_ms = sum(v[0] for v in acc.values())
         roofs = {}
+        if dom[1]:
+            us = dom[0] / dom[1] * 1e3
+            ach = dom[2] / (us * 1e-6) / 1e12
+            roofs["sam2l_fc1_tok_linear"] = {
+                "bound": "mfma", "achieved": round(ach, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                "kernel": f"tok_linear_kernel<576, LN, GELU> (Hiera stage-3 fc1: {self.B * 4096} rows x K=576 x N=2304, LayerNorm and GELU fused), the launch with the "
+                          f"largest share of the step: {dom[1] // reps} launches per pass, average of HIP event pairs on the engine stream; compare the same kernel's "
+                          "average in profiles/r02_sam2l_b16_kernel_stats.md",
+                "us_per_launch": round(us, 2), "algorithmic_flops_per_launch": int(dom[2])}
         if "mlp_fused" in acc:                                    # the fused stage-1 / 2 MLP launches are linear-layer flops too
             g, m = acc.setdefault("gemm", [0.0, 0, 0, 0]), acc["mlp_fused"]
             acc["linear"] = [g[0] + m[0], g[1] + m[1], g[2] + m[2], g[3] + m[3]]
@@ -465,7 +478,9 @@ def main():
 
     if rank == 0:
         # the dominant kernel family by time: Hiera linear GEMMs wherever SAM runs, else the detector's conv stack
-        top = rooflines.get("sam2l_linear_gemm") or next(iter(rooflines.values()), None)
+        # `roofline` = the single launch shape with the largest share of the step (its average duration can be checked against the rocprofv3
+        # summary in profiles/); the family aggregates stay in `rooflines`
+        top = rooflines.get("sam2l_fc1_tok_linear") or rooflines.get("sam2l_linear_gemm") or next(iter(rooflines.values()), None)
         cpu = None
         if cpu_parts:
             if len(cpu_parts) == 1:
