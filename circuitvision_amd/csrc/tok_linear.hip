@@ -36,11 +36,22 @@ template <int K> struct TlCfg {
 // g_tl_stamp (read by cvmi_debug_stamps).  Never used for timing runs: the stamps serialise what the real kernel overlaps.
 __device__ unsigned long long g_tl_stamp[24];
 
+// Optional extras of a launch.  pool_*: the POOL form's token grid.  stats_in: LN = 1 only -- per-row (mean, rstd) of the LayerNorm, written by the
+// launch that produced the rows (the prologue then reads every row ONCE instead of twice).  stats_out: RES only -- after the in-place update, the
+// (mean, rstd) over the N updated values of every row, for the LayerNorm (eps = stats_eps) of the NEXT launch.
+struct TlExtra {
+  int pool_w, pool_hw2;
+  const float* stats_in;
+  float* stats_out;
+  float stats_eps;
+};
+
 template <int K, int LN, bool RES, bool GELU, bool TSTORE, bool STAMP = false, bool PP = false, bool POOL = false>
 __global__ __launch_bounds__(TL_NW * 64, 2) void tok_linear_kernel(const void* __restrict__ in, int in_ld, const float* __restrict__ gamma,
                                                                    const float* __restrict__ beta, float eps, const char* __restrict__ wp,
-                                                                   void* __restrict__ out, int out_ld, long long rows, int N, int pool_w, int pool_hw2) {
+                                                                   void* __restrict__ out, int out_ld, long long rows, int N, const TlExtra ex) {
   using Cfg = TlCfg<K>;
+  const int pool_w = ex.pool_w, pool_hw2 = ex.pool_hw2;
   constexpr int KS = Cfg::KS, KS1 = Cfg::KS1, CHB = Cfg::CHB, SLOTS = Cfg::SLOTS;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
@@ -94,24 +105,30 @@ __global__ __launch_bounds__(TL_NW * 64, 2) void tok_linear_kernel(const void* _
     // pass 2 re-reads the row -- from L1 / L2, the workgroup's 256 rows were touched a few hundred cycles earlier -- and writes
     // the fp16 fragments.
     const float* xr = reinterpret_cast<const float*>(in) + row * (long long)in_ld;
-    const float x0 = xr[0];
-    float s = 0.f, q = 0.f;
+    float mean, rstd;
+    if (ex.stats_in) {                                       // forwarded by the producer of these rows: pass 1 disappears
+      const float2 st = *reinterpret_cast<const float2*>(ex.stats_in + 2 * row);
+      mean = st.x; rstd = st.y;
+    } else {
+      const float x0 = xr[0];
+      float s = 0.f, q = 0.f;
 #pragma unroll 6
-    for (int k = 0; k < KS; ++k) {
-      const f32x4 a = *reinterpret_cast<const f32x4*>(xr + 16 * k + 8 * lh), b = *reinterpret_cast<const f32x4*>(xr + 16 * k + 8 * lh + 4);
+      for (int k = 0; k < KS; ++k) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(xr + 16 * k + 8 * lh), b = *reinterpret_cast<const f32x4*>(xr + 16 * k + 8 * lh + 4);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float da = a[e] - x0, db = b[e] - x0;
-        s += da + db;
-        q = fmaf(da, da, fmaf(db, db, q));
+        for (int e = 0; e < 4; ++e) {
+          const float da = a[e] - x0, db = b[e] - x0;
+          s += da + db;
+          q = fmaf(da, da, fmaf(db, db, q));
+        }
       }
+      s += __shfl_xor(s, 32);
+      q += __shfl_xor(q, 32);
+      const float dm = s / (float)K;                           // mean - x0
+      mean = x0 + dm;
+      const float var = fmaxf(q / (float)K - dm * dm, 0.f);
+      rstd = 1.0f / sqrtf(var + eps);
     }
-    s += __shfl_xor(s, 32);
-    q += __shfl_xor(q, 32);
-    const float dm = s / (float)K;                           // mean - x0
-    const float mean = x0 + dm;
-    const float var = fmaxf(q / (float)K - dm * dm, 0.f);
-    const float rstd = 1.0f / sqrtf(var + eps);
 #pragma unroll
     for (int k = 0; k < KS; ++k) {
       if (k % 3 == 0) __builtin_amdgcn_sched_barrier(0);      // at most 3 steps' loads in flight: no hoisting of all K/16 of them
@@ -155,6 +172,7 @@ __global__ __launch_bounds__(TL_NW * 64, 2) void tok_linear_kernel(const void* _
   // The accumulator has the row on the lane: written out directly, every lane of a store touches a different cache line (8-byte / 16-byte
   // pieces, 64 lines per instruction).  TSTORE: the chunk goes through a wave-private LDS stage and leaves as whole 64-byte (16-bit) /
   // 128-byte (f32) row pieces -- 4 / 8 lanes per row, 16 / 8 rows per instruction.
+  float st_shift = 0.f, st_s = 0.f, st_q = 0.f;               // RES + stats_out: shifted sums over the row's updated values (this lane's half)
   char* const stage = smem + SLOTS * CHB + wv * Cfg::STG;
   const long long wrow0 = ((long long)blockIdx.x * TL_NW + wv) * 32;
   auto epilogue = [&](const f32x16& acc, int j) {
@@ -175,13 +193,19 @@ __global__ __launch_bounds__(TL_NW * 64, 2) void tok_linear_kernel(const void* _
       }
     } else if constexpr (RES) {
       float* o = reinterpret_cast<float*>(out) + row * (long long)out_ld + 32 * j + 4 * lh;
+      const bool stats = ex.stats_out != nullptr;              // (uniform)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        if (32 * j + 8 * g + 4 * lh < N) {
-          f32x4 v = r4[g];
+        f32x4 v = r4[g];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] += acc[4 * g + e];
+        for (int e = 0; e < 4; ++e) v[e] += acc[4 * g + e];
+        if (stats && j == 0 && g == 0) st_shift = __shfl(v[0], lr);      // the row's first updated value (held by the lane of half 0): the variance shift
+        if (32 * j + 8 * g + 4 * lh < N) {
           *reinterpret_cast<f32x4*>(o + 8 * g) = v;
+          if (stats) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float dv = v[e] - st_shift; st_s += dv; st_q = fmaf(dv, dv, st_q); }
+          }
         }
       }
     } else if constexpr (TSTORE) {
@@ -211,6 +235,16 @@ __global__ __launch_bounds__(TL_NW * 64, 2) void tok_linear_kernel(const void* _
     }
   };
 
+  auto stats_tail = [&]() {                                    // after the last chunk's epilogue
+    if constexpr (RES) {
+      if (ex.stats_out) {
+        const float ss = st_s + __shfl_xor(st_s, 32), qq = st_q + __shfl_xor(st_q, 32);
+        const float dm = ss / (float)N;
+        const float var = fmaxf(qq / (float)N - dm * dm, 0.f);
+        if (lh == 0) *reinterpret_cast<float2*>(ex.stats_out + 2 * row) = make_float2(st_shift + dm, 1.0f / sqrtf(var + ex.stats_eps));
+      }
+    }
+  };
   constexpr int PF = K >= 576 ? 6 : 8;          // ring depth (K = 576: the 148 Xn registers leave less room)
   // The K/16 + 1 MFMAs of chunk j.  A-fragment ring: PF ds_read_b128 stay in flight ahead of the MFMA that consumes them.  The reads and
   // their COUNTED waits are inline asm: left to hipcc the same source becomes read -> lgkmcnt(0) -> MFMA (every MFMA then waits a full LDS
@@ -321,6 +355,7 @@ __global__ __launch_bounds__(TL_NW * 64, 2) void tok_linear_kernel(const void* _
       }
       epilogue(acc, nch - 1);
     }
+    stats_tail();
     if constexpr (STAMP) {
       if (blockIdx.x == 0 && (tid == 0 || tid == 256)) {
         unsigned long long* g = g_tl_stamp + (tid ? 12 : 0);
@@ -367,23 +402,24 @@ __global__ __launch_bounds__(TL_NW * 64, 2) void tok_linear_kernel(const void* _
   }
   if constexpr (RES) res_load(nch - 1);
   epilogue(prev, nch - 1);
+  stats_tail();
 }
 
 template <int K, int LN, bool RES, bool GELU, bool TSTORE, bool STAMP = false, bool PP = false, bool POOL = false>
 int launch_tl1(const void* in, int in_ld, const float* gamma, const float* beta, float eps, const void* wp, void* out, int out_ld, long long rows,
-              int N, hipStream_t s, int pool_w = 0, int pool_hw2 = 0) {
+              int N, hipStream_t s, const TlExtra& ex) {
   using Cfg = TlCfg<K>;
   static hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&tok_linear_kernel<K, LN, RES, GELU, TSTORE, STAMP, PP, POOL>), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
   CVMI_HIP(attr);
   hipLaunchKernelGGL((tok_linear_kernel<K, LN, RES, GELU, TSTORE, STAMP, PP, POOL>), dim3((unsigned)(rows / 256)), dim3(TL_NW * 64), Cfg::LDS, s, in, in_ld, gamma, beta, eps,
-                     (const char*)wp, out, out_ld, rows, N, pool_w, pool_hw2);
+                     (const char*)wp, out, out_ld, rows, N, ex);
   CVMI_LAUNCH_CHECK();
   return 0;
 }
 
 template <int K, int LN, bool RES, bool GELU>
 int launch_tl(const void* in, int in_ld, const float* gamma, const float* beta, float eps, const void* wp, void* out, int out_ld, long long rows,
-              int N, hipStream_t s) {
+              int N, hipStream_t s, const TlExtra& ex) {
   static const int pp = getenv("CVMI_TOKLIN_PP") ? atoi(getenv("CVMI_TOKLIN_PP")) : 1;                 // 0 = one barrier per chunk (A/B measurements)
   static const int ts = getenv("CVMI_TOKLIN_TSTORE") ? atoi(getenv("CVMI_TOKLIN_TSTORE")) : 1;         // 0 = direct stores (A/B measurements)
   const bool tstore = !RES && ts && N % 8 == 0 && out_ld % 8 == 0;
@@ -391,39 +427,39 @@ int launch_tl(const void* in, int in_ld, const float* gamma, const float* beta, 
   static const int st = getenv("CVMI_TOKLIN_STAMP") ? atoi(getenv("CVMI_TOKLIN_STAMP")) : 0;           // diagnostic build, never for timing
   if constexpr (K == 576 && LN == 1 && !RES) {
     if (st && tstore && (st == 1 || (st == 2) == GELU)) {       // 2: only the GELU launches (fc1), 3: only the plain ones (qkv)
-      if (pp) return launch_tl1<K, LN, RES, GELU, true, true, true>(in, in_ld, gamma, beta, eps, wp, out, out_ld, rows, N, s);
-      return launch_tl1<K, LN, RES, GELU, true, true>(in, in_ld, gamma, beta, eps, wp, out, out_ld, rows, N, s);
+      if (pp) return launch_tl1<K, LN, RES, GELU, true, true, true>(in, in_ld, gamma, beta, eps, wp, out, out_ld, rows, N, s, ex);
+      return launch_tl1<K, LN, RES, GELU, true, true>(in, in_ld, gamma, beta, eps, wp, out, out_ld, rows, N, s, ex);
     }
   }
 #endif
   if constexpr (!RES) {
     if (tstore) {
-      if (pp) return launch_tl1<K, LN, RES, GELU, true, false, true>(in, in_ld, gamma, beta, eps, wp, out, out_ld, rows, N, s);
-      return launch_tl1<K, LN, RES, GELU, true>(in, in_ld, gamma, beta, eps, wp, out, out_ld, rows, N, s);
+      if (pp) return launch_tl1<K, LN, RES, GELU, true, false, true>(in, in_ld, gamma, beta, eps, wp, out, out_ld, rows, N, s, ex);
+      return launch_tl1<K, LN, RES, GELU, true>(in, in_ld, gamma, beta, eps, wp, out, out_ld, rows, N, s, ex);
     }
   }
-  if (pp) return launch_tl1<K, LN, RES, GELU, false, false, true>(in, in_ld, gamma, beta, eps, wp, out, out_ld, rows, N, s);
-  return launch_tl1<K, LN, RES, GELU, false>(in, in_ld, gamma, beta, eps, wp, out, out_ld, rows, N, s);
+  if (pp) return launch_tl1<K, LN, RES, GELU, false, false, true>(in, in_ld, gamma, beta, eps, wp, out, out_ld, rows, N, s, ex);
+  return launch_tl1<K, LN, RES, GELU, false>(in, in_ld, gamma, beta, eps, wp, out, out_ld, rows, N, s, ex);
 }
 
 template <int K>
 int dispatch_tl(int ln, bool res, int act, const void* in, int in_ld, const float* gamma, const float* beta, float eps, const void* wp, void* out,
-                int out_ld, long long rows, int N, hipStream_t s) {
+                int out_ld, long long rows, int N, hipStream_t s, const TlExtra& ex) {
   const bool gelu = act == CVMI_ACT_GELU;
   if (ln == 2) {
-    if constexpr (K <= 288) return launch_tl<K, 2, false, false>(in, in_ld, gamma, beta, eps, wp, out, out_ld, rows, N, s);
+    if constexpr (K <= 288) return launch_tl<K, 2, false, false>(in, in_ld, gamma, beta, eps, wp, out, out_ld, rows, N, s, ex);
     CVMI_FAIL("tok_linear: plain f32 input is built for K = 144 and 288");
   }
   if (res) {
-    if (ln) return launch_tl<K, 1, true, false>(in, in_ld, gamma, beta, eps, wp, out, out_ld, rows, N, s);
-    return launch_tl<K, 0, true, false>(in, in_ld, gamma, beta, eps, wp, out, out_ld, rows, N, s);
+    if (ln) return launch_tl<K, 1, true, false>(in, in_ld, gamma, beta, eps, wp, out, out_ld, rows, N, s, ex);
+    return launch_tl<K, 0, true, false>(in, in_ld, gamma, beta, eps, wp, out, out_ld, rows, N, s, ex);
   }
   if (ln) {
-    if (gelu) return launch_tl<K, 1, false, true>(in, in_ld, gamma, beta, eps, wp, out, out_ld, rows, N, s);
-    return launch_tl<K, 1, false, false>(in, in_ld, gamma, beta, eps, wp, out, out_ld, rows, N, s);
+    if (gelu) return launch_tl<K, 1, false, true>(in, in_ld, gamma, beta, eps, wp, out, out_ld, rows, N, s, ex);
+    return launch_tl<K, 1, false, false>(in, in_ld, gamma, beta, eps, wp, out, out_ld, rows, N, s, ex);
   }
-  if (gelu) return launch_tl<K, 0, false, true>(in, in_ld, gamma, beta, eps, wp, out, out_ld, rows, N, s);
-  return launch_tl<K, 0, false, false>(in, in_ld, gamma, beta, eps, wp, out, out_ld, rows, N, s);
+  if (gelu) return launch_tl<K, 0, false, true>(in, in_ld, gamma, beta, eps, wp, out, out_ld, rows, N, s, ex);
+  return launch_tl<K, 0, false, false>(in, in_ld, gamma, beta, eps, wp, out, out_ld, rows, N, s, ex);
 }
 
 }  // namespace
@@ -445,17 +481,22 @@ extern "C" size_t cvmi_tok_linear_packed_bytes(int K, int N) {
   if (!cvmi_tok_linear_supported(K) || N <= 0) return 0;
   return (size_t)(((N + 31) / 32 + 1) / 2 * 2) * (size_t)(K / 16 + 1) * 1024;        // chunk count padded to even
 }
-extern "C" int cvmi_tok_linear_bf16(const void* in, int in_ld, int in_f32_layernorm, const float* gamma, const float* beta, float eps,
-                                    const void* w_packed, void* out, int out_ld, int out_f32_residual, long long rows, int K, int N, int act,
-                                    int dtype, cvmi_stream_t stream_);
+extern "C" int cvmi_tok_linear_stats_bf16(const void* in, int in_ld, int in_f32_layernorm, const float* gamma, const float* beta, float eps,
+                                          const void* w_packed, void* out, int out_ld, int out_f32_residual, long long rows, int K, int N, int act,
+                                          int dtype, const float* ln_stats_in, float* ln_stats_out, float ln_stats_eps, cvmi_stream_t stream_);
 #endif
 
-extern "C" int CVMI_ENTRY(cvmi_tok_linear)(const void* in, int in_ld, int in_f32_layernorm, const float* gamma, const float* beta, float eps,
-                                           const void* w_packed, void* out, int out_ld, int out_f32_residual, long long rows, int K, int N, int act,
-                                           int dtype, cvmi_stream_t stream_) {
+// cvmi_tok_linear with LayerNorm statistics handed from the launch that WRITES the residual stream to the launch that normalises it:
+//   ln_stats_out (out_f32_residual = 1): float2 per row = (mean, 1 / sqrt(var + ln_stats_eps)) over the N updated values of the row
+//   ln_stats_in  (in_f32_layernorm = 1): the same pair per row; the prologue then reads every row once instead of twice
+// (x = x + proj(attn) followed by mlp.layers[0](norm2(x)) in sam2 hieradet MultiScaleBlock; behind /root/reference/src/sam2_infer.py:226).
+extern "C" int CVMI_ENTRY(cvmi_tok_linear_stats)(const void* in, int in_ld, int in_f32_layernorm, const float* gamma, const float* beta, float eps,
+                                                 const void* w_packed, void* out, int out_ld, int out_f32_residual, long long rows, int K, int N, int act,
+                                                 int dtype, const float* ln_stats_in, float* ln_stats_out, float ln_stats_eps, cvmi_stream_t stream_) {
 #ifndef CVMI_OPERAND_BF16
   if (dtype == CVMI_BF16)
-    return cvmi_tok_linear_bf16(in, in_ld, in_f32_layernorm, gamma, beta, eps, w_packed, out, out_ld, out_f32_residual, rows, K, N, act, dtype, stream_);
+    return cvmi_tok_linear_stats_bf16(in, in_ld, in_f32_layernorm, gamma, beta, eps, w_packed, out, out_ld, out_f32_residual, rows, K, N, act, dtype,
+                                      ln_stats_in, ln_stats_out, ln_stats_eps, stream_);
 #endif
   CVMI_CHECK(dtype == CVMI_T16, "tok_linear: dtype must be CVMI_F16 or CVMI_BF16");
   CVMI_CHECK(in && w_packed && out && rows > 0 && rows % 256 == 0 && N > 0, "tok_linear: bad arguments (rows must be a multiple of 256)");
@@ -468,14 +509,24 @@ extern "C" int CVMI_ENTRY(cvmi_tok_linear)(const void* in, int in_ld, int in_f32
                  (((uintptr_t)in | (uintptr_t)w_packed | (uintptr_t)out) & 15) == 0 &&
                  (in_f32_layernorm != 1 || (((uintptr_t)gamma | (uintptr_t)beta) & 15) == 0),
              "tok_linear: pointers / ld not aligned (in_ld=%d out_ld=%d N=%d)", in_ld, out_ld, N);
+  CVMI_CHECK((!ln_stats_in || in_f32_layernorm == 1) && (!ln_stats_out || out_f32_residual) && (((uintptr_t)ln_stats_in | (uintptr_t)ln_stats_out) & 7) == 0,
+             "tok_linear: ln_stats_in needs the LayerNorm input form, ln_stats_out the residual output form (8-byte aligned)");
   hipStream_t s = (hipStream_t)stream_;
   const int ln = in_f32_layernorm;
   const bool res = out_f32_residual != 0;
+  const TlExtra ex{0, 0, ln_stats_in, ln_stats_out, ln_stats_eps};
   switch (K) {
-    case 144: return dispatch_tl<144>(ln, res, act, in, in_ld, gamma, beta, eps, w_packed, out, out_ld, rows, N, s);
-    case 288: return dispatch_tl<288>(ln, res, act, in, in_ld, gamma, beta, eps, w_packed, out, out_ld, rows, N, s);
-    default: return dispatch_tl<576>(ln, res, act, in, in_ld, gamma, beta, eps, w_packed, out, out_ld, rows, N, s);
+    case 144: return dispatch_tl<144>(ln, res, act, in, in_ld, gamma, beta, eps, w_packed, out, out_ld, rows, N, s, ex);
+    case 288: return dispatch_tl<288>(ln, res, act, in, in_ld, gamma, beta, eps, w_packed, out, out_ld, rows, N, s, ex);
+    default: return dispatch_tl<576>(ln, res, act, in, in_ld, gamma, beta, eps, w_packed, out, out_ld, rows, N, s, ex);
   }
+}
+
+extern "C" int CVMI_ENTRY(cvmi_tok_linear)(const void* in, int in_ld, int in_f32_layernorm, const float* gamma, const float* beta, float eps,
+                                           const void* w_packed, void* out, int out_ld, int out_f32_residual, long long rows, int K, int N, int act,
+                                           int dtype, cvmi_stream_t stream_) {
+  return CVMI_ENTRY(cvmi_tok_linear_stats)(in, in_ld, in_f32_layernorm, gamma, beta, eps, w_packed, out, out_ld, out_f32_residual, rows, K, N, act, dtype,
+                                           nullptr, nullptr, 0.f, stream_);
 }
 
 #ifndef CVMI_OPERAND_BF16
@@ -502,8 +553,8 @@ extern "C" int CVMI_ENTRY(cvmi_tok_linear_pool)(const void* in, int in_ld, const
   hipStream_t s = (hipStream_t)stream_;
   const int hw2 = (H / 2) * (W / 2);
   switch (K) {
-    case 144: return launch_tl1<144, 1, false, false, false, false, true, true>(in, in_ld, gamma, beta, eps, w_packed, out, out_ld, rows, N, s, W, hw2);
-    case 288: return launch_tl1<288, 1, false, false, false, false, true, true>(in, in_ld, gamma, beta, eps, w_packed, out, out_ld, rows, N, s, W, hw2);
-    default: return launch_tl1<576, 1, false, false, false, false, true, true>(in, in_ld, gamma, beta, eps, w_packed, out, out_ld, rows, N, s, W, hw2);
+    case 144: return launch_tl1<144, 1, false, false, false, false, true, true>(in, in_ld, gamma, beta, eps, w_packed, out, out_ld, rows, N, s, TlExtra{W, hw2, nullptr, nullptr, 0.f});
+    case 288: return launch_tl1<288, 1, false, false, false, false, true, true>(in, in_ld, gamma, beta, eps, w_packed, out, out_ld, rows, N, s, TlExtra{W, hw2, nullptr, nullptr, 0.f});
+    default: return launch_tl1<576, 1, false, false, false, false, true, true>(in, in_ld, gamma, beta, eps, w_packed, out, out_ld, rows, N, s, TlExtra{W, hw2, nullptr, nullptr, 0.f});
   }
 }

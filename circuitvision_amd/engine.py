@@ -560,9 +560,11 @@ class PackedTokLinear:
         self.param_bytes = N * K * 2
 
 
-def op_tok_linear(plan, label, pt, src, dst, ln=None, act=_lib.ACT_NONE, residual=False, kind="gemm"):
+def op_tok_linear(plan, label, pt, src, dst, ln=None, act=_lib.ACT_NONE, residual=False, kind="gemm", stats_in=None, stats_out=None, stats_eps=1e-6):
     """src: f32 View with ln = (gamma, beta, eps) or ln = "cast" (f32 rows converted as they are, K <= 288), or an fp16 View.
-    dst: fp16 View, or (residual=True) the f32 View updated in place."""
+    dst: fp16 View, or (residual=True) the f32 View updated in place.
+    stats_out (residual=True): f32 tensor [rows, 2] that receives each updated row's (mean, rstd) for the NEXT LayerNorm (eps = stats_eps);
+    stats_in (ln = (gamma, beta, eps)): such a tensor written by the launch that produced src -- the prologue then reads src once."""
     lib = _lib.load()
     src, dst = _as_rows(src), _as_rows(dst)
     assert src.C == pt.K and dst.C == pt.N and src.rows == dst.rows and src.rows % 256 == 0, label
@@ -570,11 +572,16 @@ def op_tok_linear(plan, label, pt, src, dst, ln=None, act=_lib.ACT_NONE, residua
     assert (ln is not None or src.dtype == pt.dtype) and (residual or dst.dtype == pt.dtype), label
     cast = isinstance(ln, str)
     assert not cast or ln == "cast", label
+    assert stats_in is None or (ln is not None and not cast), label
+    assert stats_out is None or residual, label
+    for st in (stats_in, stats_out):
+        assert st is None or (st.dtype == torch.float32 and st.numel() == 2 * src.rows and st.is_contiguous()), label
     gam, bet, eps = ln if (ln is not None and not cast) else (None, None, 0.0)
     args = (src.ptr, src.ld, 2 if cast else 1 if ln is not None else 0, gam.data_ptr() if gam is not None else None, bet.data_ptr() if bet is not None else None,
-            float(eps), pt.w.data_ptr(), dst.ptr, dst.ld, 1 if residual else 0, src.rows, pt.K, pt.N, act, pt.dtype)
-    plan.keep.append((pt, src, dst, gam, bet))
-    sp0, fn = plan.sptr, lib.cvmi_tok_linear
+            float(eps), pt.w.data_ptr(), dst.ptr, dst.ld, 1 if residual else 0, src.rows, pt.K, pt.N, act, pt.dtype,
+            stats_in.data_ptr() if stats_in is not None else None, stats_out.data_ptr() if stats_out is not None else None, float(stats_eps))
+    plan.keep.append((pt, src, dst, gam, bet, stats_in, stats_out))
+    sp0, fn = plan.sptr, lib.cvmi_tok_linear_stats
 
     def thunk(sp=None):
         sp = sp0 if sp is None else sp

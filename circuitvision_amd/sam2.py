@@ -513,8 +513,12 @@ class Sam2Plan:
         self.plan.ops[-1] = (self.plan.ops[-1][0], "attn_global" if ws == 0 else "attn_window") + self.plan.ops[-1][2:]
         # x = shortcut + proj(attn)   (in place on the f32 residual stream)
         tok_out = not padded and (B * OH * OW) % 256 == 0
+        # norm2's statistics travel from the launch that writes x to the launch that normalises it (fc1 then reads x once, not twice)
+        fwd = (tok_out and f"b{i}.proj" in wt.tl and f"b{i}" not in wt.mlp and f"b{i}.fc1" in wt.tl
+               and os.environ.get("CVMI_SAM_LNSTATS", "1") != "0")
+        stats = torch.empty(B * OH * OW, 2, dtype=torch.float32, device=self.dev) if fwd else None
         if tok_out and f"b{i}.proj" in wt.tl:
-            op_tok_linear(self.plan, f"b{i}.proj", wt.tl[f"b{i}.proj"], ao.view(), short.view(), residual=True)
+            op_tok_linear(self.plan, f"b{i}.proj", wt.tl[f"b{i}.proj"], ao.view(), short.view(), residual=True, stats_out=stats, stats_eps=1e-6)
         else:
             self.gemm(f"b{i}.proj", f"b{i}.proj", ao.view(), short.view(), res=short.view(), out_hw=(OH, OW) if padded else None)
         x = short
@@ -524,7 +528,7 @@ class Sam2Plan:
         else:
             hid = self.buf(OH, OW, 4 * dout, tag="hid")
             if tok_out and f"b{i}.fc1" in wt.tl:                   # norm2 fused into fc1 (+ GELU)
-                op_tok_linear(self.plan, f"b{i}.fc1", wt.tl[f"b{i}.fc1"], x.view(), hid.view(), ln=(gam, bet, 1e-6), act=ACT_GELU)
+                op_tok_linear(self.plan, f"b{i}.fc1", wt.tl[f"b{i}.fc1"], x.view(), hid.view(), ln=(gam, bet, 1e-6), act=ACT_GELU, stats_in=stats)
             else:
                 xn2 = self.buf(OH, OW, dout, tag="xn")
                 op_layernorm(self.plan, f"b{i}.norm2", x.view(), gam, bet, xn2.view(), 1e-6)

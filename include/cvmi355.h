@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define CVMI_VERSION 111
+#define CVMI_VERSION 112
 
 typedef void* cvmi_stream_t; /* hipStream_t */
 
@@ -254,6 +254,14 @@ size_t cvmi_tok_linear_packed_bytes(int K, int N);
 int cvmi_tok_linear(const void* in, int in_ld, int in_f32_layernorm, const float* gamma, const float* beta, float eps,
                     const void* w_packed, void* out, int out_ld, int out_f32_residual, long long rows, int K, int N, int act,
                     int dtype /* CVMI_F16 | CVMI_BF16: type of w_packed and of the 16-bit input / output */, cvmi_stream_t stream);
+
+/* cvmi_tok_linear with LayerNorm statistics handed from the launch that writes the f32 residual stream to the launch that normalises it
+ * (sam2 hieradet MultiScaleBlock: x = shortcut + proj(attn), then mlp.layers[0](norm2(x)); behind sam2_infer.py:226):
+ *   ln_stats_out (out_f32_residual = 1, may be NULL): float[2 * rows] = per row (mean, 1 / sqrt(var + ln_stats_eps)) over the N updated values
+ *   ln_stats_in  (in_f32_layernorm = 1, may be NULL): the same pairs; the LayerNorm prologue then reads every row once instead of twice. */
+int cvmi_tok_linear_stats(const void* in, int in_ld, int in_f32_layernorm, const float* gamma, const float* beta, float eps,
+                          const void* w_packed, void* out, int out_ld, int out_f32_residual, long long rows, int K, int N, int act,
+                          int dtype, const float* ln_stats_in, float* ln_stats_out, float ln_stats_eps, cvmi_stream_t stream);
 
 /* Shortcut path of a Hiera q-pooling block in ONE launch: out[b, y, x, :] = max over the 2 x 2 token block of
  * ( LayerNorm(in[b, 2y + dy, 2x + dx, :]) W^T + bias )  = `do_pool(self.proj(norm1(x)))` of sam2 hieradet MultiScaleBlock.forward (behind

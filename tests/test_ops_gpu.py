@@ -539,3 +539,45 @@ def test_tok_linear_pool_vs_torch(K, N, B, H, W, dt):
     got = dst.t.float().cpu()
     torch.testing.assert_close(got[..., :N], ref, rtol=4e-3 * tol, atol=4e-3 * tol)
     assert bool((got[..., N:] == 7.0).all())
+
+
+@pytest.mark.parametrize("K,N2", [(576, 2304), (288, 1152), (144, 576)])
+@pytest.mark.parametrize("dt", [F16, BF16])
+def test_tok_linear_forwarded_layernorm_statistics(K, N2, dt):
+    """x = x + proj(a) writes each updated row's LayerNorm statistics (mean, rstd); the next launch, GELU(fc1(LayerNorm(x))), takes them
+    instead of computing them in a first pass over x (cvmi_tok_linear_stats).  Statistics vs fp32 torch on the updated rows (an outlier
+    channel and a common offset included); the fc1 output with forwarded statistics vs the one with the two-pass prologue and vs torch."""
+    import torch.nn.functional as TF
+    from circuitvision_amd.engine import TORCH_DTYPE, PackedTokLinear, Rows, op_tok_linear
+    td = TORCH_DTYPE[dt]
+    tol = 1.0 if dt == F16 else 8.0
+    rows = 512
+    g = torch.Generator().manual_seed(K)
+    wp = quant(torch.randn(K, K, generator=g) / K ** 0.5, dt); bp = torch.randn(K, generator=g) * 0.2
+    w1 = quant(torch.randn(N2, K, generator=g) / K ** 0.5, dt); b1 = torch.randn(N2, generator=g) * 0.2
+    gam, bet = torch.rand(K, generator=g) + 0.5, torch.randn(K, generator=g) * 0.2
+    a = quant(torch.randn(rows, K, generator=g), dt)
+    x0 = torch.randn(rows, K, generator=g) * 1.5 + 3.0
+    x0[:, 7] += 50.0
+    x1 = x0 + a @ wp.t() + bp                                              # the updated stream
+    mean, var = x1.mean(1), x1.var(1, unbiased=False)
+    ref_stats = torch.stack((mean, 1.0 / torch.sqrt(var + 1e-6)), 1)
+    y_ref = TF.gelu(quant(TF.layer_norm(x1, (K,), gam, bet, 1e-6), dt) @ w1.t() + b1)
+    xd = x0.cuda()
+    stats = torch.zeros(rows, 2, device="cuda")
+    out_a = torch.empty(rows, N2, dtype=td, device="cuda"); out_b = torch.empty_like(out_a)
+    pp_, p1 = PackedTokLinear(wp, bp, dtype=dt), PackedTokLinear(w1, b1, dtype=dt)
+    plan = Plan(stream())
+    op_tok_linear(plan, "proj", pp_, Rows(a.to(td).cuda(), rows, K), Rows(xd, rows, K), residual=True, stats_out=stats, stats_eps=1e-6)
+    op_tok_linear(plan, "fc1_fwd", p1, Rows(xd, rows, K), Rows(out_a, rows, N2), ln=(gam.cuda(), bet.cuda(), 1e-6), act=ACT_GELU, stats_in=stats)
+    op_tok_linear(plan, "fc1_two_pass", p1, Rows(xd, rows, K), Rows(out_b, rows, N2), ln=(gam.cuda(), bet.cuda(), 1e-6), act=ACT_GELU)
+    run(plan)
+    torch.testing.assert_close(xd.cpu(), x1, rtol=3e-3 * tol, atol=3e-3 * tol)
+    got = stats.cpu()
+    x1d = xd.cpu()                                                          # statistics are those of the rows as WRITTEN
+    exp = torch.stack((x1d.mean(1), 1.0 / torch.sqrt(x1d.var(1, unbiased=False) + 1e-6)), 1)
+    torch.testing.assert_close(got, exp, rtol=2e-5, atol=2e-5)
+    torch.testing.assert_close(got, ref_stats, rtol=5e-3 * tol, atol=5e-3 * tol)
+    ya, yb = out_a.float().cpu(), out_b.float().cpu()
+    torch.testing.assert_close(ya, yb, rtol=2e-3 * tol, atol=2e-3 * tol)     # same rows, same statistics up to summation order
+    torch.testing.assert_close(ya, y_ref, rtol=6e-3 * tol, atol=6e-3 * tol)
