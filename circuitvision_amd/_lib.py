@@ -97,10 +97,12 @@ SIGNATURES = {
     "cvmi_hiera_mlp_supported": (_i, [_i]),
     "cvmi_hiera_mlp_packed_bytes": (C.c_size_t, [_i]),
     "cvmi_hiera_mlp": (_i, [_vp, _i, _vp, _vp, _f, _vp, _vp, C.c_longlong, _i, _i, _vp]),
+    "cvmi_hiera_mlp_stats": (_i, [_vp, _i, _vp, _vp, _f, _vp, _vp, C.c_longlong, _i, _i, _vp, _f, _vp]),
     "cvmi_tok_linear_supported": (_i, [_i]),
     "cvmi_tok_linear_packed_bytes": (C.c_size_t, [_i, _i]),
     "cvmi_tok_linear": (_i, [_vp, _i, _i, _vp, _vp, _f, _vp, _vp, _i, _i, C.c_longlong, _i, _i, _i, _i, _vp]),
     "cvmi_tok_linear_stats": (_i, [_vp, _i, _i, _vp, _vp, _f, _vp, _vp, _i, _i, C.c_longlong, _i, _i, _i, _i, _vp, _vp, _f, _vp]),
+    "cvmi_tok_linear_pool_stats": (_i, [_vp, _i, _vp, _vp, _f, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "cvmi_tok_linear_pool": (_i, [_vp, _i, _vp, _vp, _f, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "cvmi_debug_stamps": (_i, [C.POINTER(C.c_ulonglong)]),
     "cvmi_maxpool2x2": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp]),

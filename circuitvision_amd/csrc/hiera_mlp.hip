@@ -39,7 +39,7 @@ template <int C>
 __global__ __launch_bounds__(MlpCfg<C>::NW * 64, MlpCfg<C>::WPS) void hiera_mlp_kernel(float* __restrict__ x, int x_ld, const float* __restrict__ gamma,
                                                                                       const float* __restrict__ beta, float eps,
                                                                                       const char* __restrict__ wp, const float* __restrict__ b2,
-                                                                                      long long rows) {
+                                                                                      long long rows, float* __restrict__ stats_out, float stats_eps) {
   using Cfg = MlpCfg<C>;
   constexpr int KS = Cfg::KS, KS1 = Cfg::KS1, NT = Cfg::NT, NCH = Cfg::NCH, FR = Cfg::FR, CHB = Cfg::CHB, NW = Cfg::NW;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -158,7 +158,14 @@ __global__ __launch_bounds__(MlpCfg<C>::NW * 64, MlpCfg<C>::WPS) void hiera_mlp_
     }
   }
 
-  // ---- epilogue: x += y + b2; lane (token lr, half lh) owns channels 32 t + 8 g + 4 lh .. + 3
+  // ---- epilogue: x += y + b2; lane (token lr, half lh) owns channels 32 t + 8 g + 4 lh .. + 3.
+  // stats_out: the updated row's LayerNorm statistics (mean, 1 / sqrt(var + stats_eps)) for the launch that normalises it next (the next
+  // block's norm1): shifted sums over this lane's half of the row, the shift being the row's first updated value.
+  float st_shift = 0.f, st_s = 0.f, st_q = 0.f;
+  if (stats_out) {
+    const float o0 = row_ok ? xr[0] + (yacc[0][0] + b2[0]) : 0.f;       // (the value the lane of half 0 stores at channel 0)
+    st_shift = __shfl(o0, lr);
+  }
   if (row_ok) {
 #pragma unroll
     for (int t = 0; t < NT; ++t)
@@ -171,19 +178,30 @@ __global__ __launch_bounds__(MlpCfg<C>::NW * 64, MlpCfg<C>::WPS) void hiera_mlp_
 #pragma unroll
           for (int e = 0; e < 4; ++e) o[e] += yacc[t][4 * g + e] + bb[e];
           *reinterpret_cast<f32x4*>(xr + c0) = o;
+          if (stats_out) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float dv = o[e] - st_shift; st_s += dv; st_q = fmaf(dv, dv, st_q); }
+          }
         }
       }
+  }
+  if (stats_out) {
+    const float ss = st_s + __shfl_xor(st_s, 32), qq = st_q + __shfl_xor(st_q, 32);
+    const float dm = ss / (float)C;
+    const float var = fmaxf(qq / (float)C - dm * dm, 0.f);
+    if (row_ok && lh == 0) *reinterpret_cast<float2*>(stats_out + 2 * row_raw) = make_float2(st_shift + dm, 1.0f / sqrtf(var + stats_eps));
   }
 }
 
 template <int C>
-int launch_mlp(float* x, int x_ld, const float* gamma, const float* beta, float eps, const void* wp, const float* b2, long long rows, hipStream_t s) {
+int launch_mlp(float* x, int x_ld, const float* gamma, const float* beta, float eps, const void* wp, const float* b2, long long rows, hipStream_t s,
+               float* stats_out, float stats_eps) {
   using Cfg = MlpCfg<C>;
   static hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&hiera_mlp_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
   CVMI_HIP(attr);
   const long long per = (long long)Cfg::NW * 32;
   hipLaunchKernelGGL((hiera_mlp_kernel<C>), dim3((unsigned)((rows + per - 1) / per)), dim3(Cfg::NW * 64), Cfg::LDS, s, x, x_ld, gamma, beta, eps,
-                     (const char*)wp, b2, rows);
+                     (const char*)wp, b2, rows, stats_out, stats_eps);
   CVMI_LAUNCH_CHECK();
   return 0;
 }
@@ -200,22 +218,30 @@ extern "C" size_t cvmi_hiera_mlp_packed_bytes(int C) {
   const size_t fr = (size_t)(C / 16 + 1) + 2 * (size_t)((C + 31) / 32);
   return (size_t)(4 * C / 32) * fr * 1024;
 }
-extern "C" int cvmi_hiera_mlp_bf16(void* x, int x_ld, const float* gamma, const float* beta, float eps, const void* w_packed, const float* b2,
-                                   long long rows, int C, int dtype, cvmi_stream_t stream_);
+extern "C" int cvmi_hiera_mlp_stats_bf16(void* x, int x_ld, const float* gamma, const float* beta, float eps, const void* w_packed, const float* b2,
+                                         long long rows, int C, int dtype, float* ln_stats_out, float ln_stats_eps, cvmi_stream_t stream_);
 #endif
 
-extern "C" int CVMI_ENTRY(cvmi_hiera_mlp)(void* x, int x_ld, const float* gamma, const float* beta, float eps, const void* w_packed, const float* b2,
-                                          long long rows, int C, int dtype, cvmi_stream_t stream_) {
+// cvmi_hiera_mlp that also writes, per updated row, the LayerNorm statistics (mean, 1 / sqrt(var + ln_stats_eps)) the NEXT launch needs
+// (the next block's norm1, fused into cvmi_tok_linear_stats / cvmi_tok_linear_pool_stats): ln_stats_out = float[2 * rows] or NULL.
+extern "C" int CVMI_ENTRY(cvmi_hiera_mlp_stats)(void* x, int x_ld, const float* gamma, const float* beta, float eps, const void* w_packed, const float* b2,
+                                                long long rows, int C, int dtype, float* ln_stats_out, float ln_stats_eps, cvmi_stream_t stream_) {
 #ifndef CVMI_OPERAND_BF16
-  if (dtype == CVMI_BF16) return cvmi_hiera_mlp_bf16(x, x_ld, gamma, beta, eps, w_packed, b2, rows, C, dtype, stream_);
+  if (dtype == CVMI_BF16) return cvmi_hiera_mlp_stats_bf16(x, x_ld, gamma, beta, eps, w_packed, b2, rows, C, dtype, ln_stats_out, ln_stats_eps, stream_);
 #endif
   CVMI_CHECK(dtype == CVMI_T16, "hiera_mlp: dtype must be CVMI_F16 or CVMI_BF16");
   CVMI_CHECK(x && gamma && beta && w_packed && b2 && rows > 0, "hiera_mlp: bad arguments");
   CVMI_CHECK(C == 144 || C == 288, "hiera_mlp: C=%d is not built (144, 288)", C);
-  CVMI_CHECK(x_ld >= C && x_ld % 4 == 0 && (((uintptr_t)x | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)w_packed | (uintptr_t)b2) & 15) == 0,
+  CVMI_CHECK(x_ld >= C && x_ld % 4 == 0 && (((uintptr_t)x | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)w_packed | (uintptr_t)b2) & 15) == 0 &&
+                 ((uintptr_t)ln_stats_out & 7) == 0,
              "hiera_mlp: pointers / ld must be 16-byte aligned");
   hipStream_t s = (hipStream_t)stream_;
   float* xf = (float*)x;
-  if (C == 144) return launch_mlp<144>(xf, x_ld, gamma, beta, eps, w_packed, b2, rows, s);
-  return launch_mlp<288>(xf, x_ld, gamma, beta, eps, w_packed, b2, rows, s);
+  if (C == 144) return launch_mlp<144>(xf, x_ld, gamma, beta, eps, w_packed, b2, rows, s, ln_stats_out, ln_stats_eps);
+  return launch_mlp<288>(xf, x_ld, gamma, beta, eps, w_packed, b2, rows, s, ln_stats_out, ln_stats_eps);
+}
+
+extern "C" int CVMI_ENTRY(cvmi_hiera_mlp)(void* x, int x_ld, const float* gamma, const float* beta, float eps, const void* w_packed, const float* b2,
+                                          long long rows, int C, int dtype, cvmi_stream_t stream_) {
+  return CVMI_ENTRY(cvmi_hiera_mlp_stats)(x, x_ld, gamma, beta, eps, w_packed, b2, rows, C, dtype, nullptr, 0.f, stream_);
 }

@@ -530,17 +530,20 @@ extern "C" int CVMI_ENTRY(cvmi_tok_linear)(const void* in, int in_ld, int in_f32
 }
 
 #ifndef CVMI_OPERAND_BF16
-extern "C" int cvmi_tok_linear_pool_bf16(const void* in, int in_ld, const float* gamma, const float* beta, float eps, const void* w_packed, void* out,
-                                         int out_ld, int B, int H, int W, int K, int N, int dtype, cvmi_stream_t stream_);
+extern "C" int cvmi_tok_linear_pool_stats_bf16(const void* in, int in_ld, const float* gamma, const float* beta, float eps, const void* w_packed, void* out,
+                                               int out_ld, int B, int H, int W, int K, int N, int dtype, const float* ln_stats_in, cvmi_stream_t stream_);
 #endif
 
 // out[b, y, x, :] = max over the 2 x 2 token block of ( LayerNorm(in[b, 2y + dy, 2x + dx, :]) W^T + bias ): the shortcut path of a Hiera
 // q-pooling block, `do_pool(self.proj(x_norm))` (sam2 hieradet MultiScaleBlock.forward, behind /root/reference/src/sam2_infer.py:226), in one
 // launch -- the full-resolution f32 projection (1.2 GB at the stage 1 -> 2 transition, B = 16) is neither written nor read back.
-extern "C" int CVMI_ENTRY(cvmi_tok_linear_pool)(const void* in, int in_ld, const float* gamma, const float* beta, float eps, const void* w_packed,
-                                                void* out, int out_ld, int B, int H, int W, int K, int N, int dtype, cvmi_stream_t stream_) {
+// ln_stats_in (may be NULL): per source row (mean, rstd) as written by cvmi_hiera_mlp_stats / cvmi_tok_linear_stats -- one pass over the rows.
+extern "C" int CVMI_ENTRY(cvmi_tok_linear_pool_stats)(const void* in, int in_ld, const float* gamma, const float* beta, float eps, const void* w_packed,
+                                                      void* out, int out_ld, int B, int H, int W, int K, int N, int dtype, const float* ln_stats_in,
+                                                      cvmi_stream_t stream_) {
 #ifndef CVMI_OPERAND_BF16
-  if (dtype == CVMI_BF16) return cvmi_tok_linear_pool_bf16(in, in_ld, gamma, beta, eps, w_packed, out, out_ld, B, H, W, K, N, dtype, stream_);
+  if (dtype == CVMI_BF16)
+    return cvmi_tok_linear_pool_stats_bf16(in, in_ld, gamma, beta, eps, w_packed, out, out_ld, B, H, W, K, N, dtype, ln_stats_in, stream_);
 #endif
   CVMI_CHECK(dtype == CVMI_T16, "tok_linear_pool: dtype must be CVMI_F16 or CVMI_BF16");
   const long long rows = (long long)B * H * W;
@@ -553,8 +556,13 @@ extern "C" int CVMI_ENTRY(cvmi_tok_linear_pool)(const void* in, int in_ld, const
   hipStream_t s = (hipStream_t)stream_;
   const int hw2 = (H / 2) * (W / 2);
   switch (K) {
-    case 144: return launch_tl1<144, 1, false, false, false, false, true, true>(in, in_ld, gamma, beta, eps, w_packed, out, out_ld, rows, N, s, TlExtra{W, hw2, nullptr, nullptr, 0.f});
-    case 288: return launch_tl1<288, 1, false, false, false, false, true, true>(in, in_ld, gamma, beta, eps, w_packed, out, out_ld, rows, N, s, TlExtra{W, hw2, nullptr, nullptr, 0.f});
-    default: return launch_tl1<576, 1, false, false, false, false, true, true>(in, in_ld, gamma, beta, eps, w_packed, out, out_ld, rows, N, s, TlExtra{W, hw2, nullptr, nullptr, 0.f});
+    case 144: return launch_tl1<144, 1, false, false, false, false, true, true>(in, in_ld, gamma, beta, eps, w_packed, out, out_ld, rows, N, s, TlExtra{W, hw2, ln_stats_in, nullptr, 0.f});
+    case 288: return launch_tl1<288, 1, false, false, false, false, true, true>(in, in_ld, gamma, beta, eps, w_packed, out, out_ld, rows, N, s, TlExtra{W, hw2, ln_stats_in, nullptr, 0.f});
+    default: return launch_tl1<576, 1, false, false, false, false, true, true>(in, in_ld, gamma, beta, eps, w_packed, out, out_ld, rows, N, s, TlExtra{W, hw2, ln_stats_in, nullptr, 0.f});
   }
+}
+
+extern "C" int CVMI_ENTRY(cvmi_tok_linear_pool)(const void* in, int in_ld, const float* gamma, const float* beta, float eps, const void* w_packed,
+                                                void* out, int out_ld, int B, int H, int W, int K, int N, int dtype, cvmi_stream_t stream_) {
+  return CVMI_ENTRY(cvmi_tok_linear_pool_stats)(in, in_ld, gamma, beta, eps, w_packed, out, out_ld, B, H, W, K, N, dtype, nullptr, stream_);
 }

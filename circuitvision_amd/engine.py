@@ -518,14 +518,17 @@ class PackedHieraMlp:
         self.param_bytes = 2 * Hd * C_ * 2
 
 
-def op_hiera_mlp(plan, label, pm, x, gamma, beta, eps=1e-6):
-    """x <- x + fc2(GELU(fc1(LayerNorm(x)))) in place; x: f32 View (full rows)."""
+def op_hiera_mlp(plan, label, pm, x, gamma, beta, eps=1e-6, stats_out=None, stats_eps=1e-6):
+    """x <- x + fc2(GELU(fc1(LayerNorm(x)))) in place; x: f32 View (full rows).  stats_out: f32 tensor [rows, 2] that receives each updated
+    row's (mean, rstd) for the NEXT LayerNorm over x (eps = stats_eps)."""
     lib = _lib.load()
     assert x.dtype == F32 and x.c == pm.C and x.c0 == 0
     rows = x.B * x.H * x.W
-    args = (x.ptr, x.ld, gamma.data_ptr(), beta.data_ptr(), float(eps), pm.w.data_ptr(), pm.bias.data_ptr(), rows, pm.C, pm.dtype)
-    plan.keep.append((pm, x, gamma, beta))
-    sp0, fn = plan.sptr, lib.cvmi_hiera_mlp
+    assert stats_out is None or (stats_out.dtype == torch.float32 and stats_out.numel() == 2 * rows and stats_out.is_contiguous()), label
+    args = (x.ptr, x.ld, gamma.data_ptr(), beta.data_ptr(), float(eps), pm.w.data_ptr(), pm.bias.data_ptr(), rows, pm.C, pm.dtype,
+            stats_out.data_ptr() if stats_out is not None else None, float(stats_eps))
+    plan.keep.append((pm, x, gamma, beta, stats_out))
+    sp0, fn = plan.sptr, lib.cvmi_hiera_mlp_stats
 
     def thunk(sp=None):
         sp = sp0 if sp is None else sp
@@ -591,7 +594,7 @@ def op_tok_linear(plan, label, pt, src, dst, ln=None, act=_lib.ACT_NONE, residua
     plan.add(label, kind, thunk, bytes_, 2 * src.rows * pt.N * pt.K)
 
 
-def op_tok_linear_pool(plan, label, pt, src, dst, ln, kind="gemm"):
+def op_tok_linear_pool(plan, label, pt, src, dst, ln, kind="gemm", stats_in=None):
     """dst[b, y, x, :] = max over the 2 x 2 token block of (LayerNorm(src) W^T + b): src an f32 [B, H, W, K] View, dst f32 [B, H/2, W/2, N]
     (`do_pool(self.proj(norm1(x)))` of a Hiera q-pooling block in one launch)."""
     lib = _lib.load()
@@ -599,9 +602,11 @@ def op_tok_linear_pool(plan, label, pt, src, dst, ln, kind="gemm"):
     assert src.dtype == F32 and dst.dtype == F32 and src.c == pt.K and dst.c == pt.N, label
     assert (dst.B, dst.H, dst.W) == (B, H // 2, W // 2) and H % 2 == 0 and W % 2 == 0 and (B * H * W) % 256 == 0, label
     gam, bet, eps = ln
-    args = (src.ptr, src.ld, gam.data_ptr(), bet.data_ptr(), float(eps), pt.w.data_ptr(), dst.ptr, dst.ld, B, H, W, pt.K, pt.N, pt.dtype)
-    plan.keep.append((pt, src, dst, gam, bet))
-    sp0, fn = plan.sptr, lib.cvmi_tok_linear_pool
+    assert stats_in is None or (stats_in.dtype == torch.float32 and stats_in.numel() == 2 * B * H * W and stats_in.is_contiguous()), label
+    args = (src.ptr, src.ld, gam.data_ptr(), bet.data_ptr(), float(eps), pt.w.data_ptr(), dst.ptr, dst.ld, B, H, W, pt.K, pt.N, pt.dtype,
+            stats_in.data_ptr() if stats_in is not None else None)
+    plan.keep.append((pt, src, dst, gam, bet, stats_in))
+    sp0, fn = plan.sptr, lib.cvmi_tok_linear_pool_stats
 
     def thunk(sp=None):
         sp = sp0 if sp is None else sp

@@ -399,6 +399,7 @@ class Sam2Plan:
 
     def __init__(self, wt, B, stream, dynamic_multimask_via_stability=True, prompts=0, points=3, high_res=True):
         self.wt, self.B, self.dt, self.dev = wt, B, wt.dtype, wt.device
+        self._ln1_stats = None                                        # LayerNorm statistics handed from a block's fused MLP to the next block's norm1
         self.P, self.K, self.want_high_res = prompts, points, high_res
         if prompts and not wt.prompt_ok:
             raise _lib.CvmiError("this checkpoint carries no sam_prompt_encoder tensors: box / point prompts are unavailable")
@@ -473,10 +474,12 @@ class Sam2Plan:
         elif not tok_qkv or (dim != dout and not tok_pool):
             xn = self.buf(H, W, dim, tag="xn")
             op_layernorm(self.plan, f"b{i}.norm1", x.view(), gam, bet, xn.view(), 1e-6)
+        ln1_stats = self._ln1_stats if (self._ln1_stats is not None and self._ln1_stats.numel() == 2 * B * H * W) else None
+        self._ln1_stats = None                                     # (written by the previous block's fused MLP for exactly these rows)
         if dim != dout:
             short = self.buf(H // 2, W // 2, dout, F32)
             if tok_pool:
-                op_tok_linear_pool(self.plan, f"b{i}.dimproj_pool", wt.tl[f"b{i}.dimproj"], x.view(), short.view(), (gam, bet, 1e-6))
+                op_tok_linear_pool(self.plan, f"b{i}.dimproj_pool", wt.tl[f"b{i}.dimproj"], x.view(), short.view(), (gam, bet, 1e-6), stats_in=ln1_stats)
             else:
                 pj = self.buf(H, W, dout, F32, tag="dimproj")
                 self.gemm(f"b{i}.dimproj", f"b{i}.dimproj", xn.view(), pj.view(), out_hw=(H, W) if padded else None)
@@ -485,7 +488,7 @@ class Sam2Plan:
             short = x
         qkv = self.buf(Hp, Wp, 3 * dout, tag="qkv")
         if tok_qkv:
-            op_tok_linear(self.plan, f"b{i}.qkv", wt.tl[f"b{i}.qkv"], x.view(), qkv.view(), ln=(gam, bet, 1e-6))
+            op_tok_linear(self.plan, f"b{i}.qkv", wt.tl[f"b{i}.qkv"], x.view(), qkv.view(), ln=(gam, bet, 1e-6), stats_in=ln1_stats)
         else:
             self.gemm(f"b{i}.qkv", f"b{i}.qkv", xn.view(), qkv.view())
         OH, OW = (H // 2, W // 2) if blk["q_pool"] else (H, W)
@@ -524,7 +527,10 @@ class Sam2Plan:
         x = short
         gam, bet = wt.ln[f"b{i}.norm2"]
         if f"b{i}" in wt.mlp:
-            op_hiera_mlp(self.plan, f"b{i}.mlp", wt.mlp[f"b{i}"], x.view(), gam, bet, 1e-6)
+            nxt = wt.blocks[i + 1] if i + 1 < len(wt.blocks) else None
+            if nxt is not None and os.environ.get("CVMI_SAM_LNSTATS", "1") != "0" and f"b{i + 1}.qkv" in wt.tl and (B * OH * OW) % 256 == 0:
+                self._ln1_stats = torch.empty(B * OH * OW, 2, dtype=torch.float32, device=self.dev)      # the next block's norm1 reads x once
+            op_hiera_mlp(self.plan, f"b{i}.mlp", wt.mlp[f"b{i}"], x.view(), gam, bet, 1e-6, stats_out=self._ln1_stats, stats_eps=1e-6)
         else:
             hid = self.buf(OH, OW, 4 * dout, tag="hid")
             if tok_out and f"b{i}.fc1" in wt.tl:                   # norm2 fused into fc1 (+ GELU)

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define CVMI_VERSION 112
+#define CVMI_VERSION 113
 
 typedef void* cvmi_stream_t; /* hipStream_t */
 
@@ -237,6 +237,10 @@ int cvmi_hiera_mlp_supported(int C);
 size_t cvmi_hiera_mlp_packed_bytes(int C);
 int cvmi_hiera_mlp(void* x, int x_ld, const float* gamma, const float* beta, float eps, const void* w_packed,
                    const float* b2, long long rows, int C, int dtype /* CVMI_F16 | CVMI_BF16: type of w_packed */, cvmi_stream_t stream);
+/* same; additionally writes per updated row (mean, 1 / sqrt(var + ln_stats_eps)) to ln_stats_out (float[2 * rows], or NULL): the statistics of
+ * the NEXT LayerNorm over these rows (the next block's norm1), consumed by cvmi_tok_linear_stats / cvmi_tok_linear_pool_stats */
+int cvmi_hiera_mlp_stats(void* x, int x_ld, const float* gamma, const float* beta, float eps, const void* w_packed, const float* b2,
+                         long long rows, int C, int dtype, float* ln_stats_out, float ln_stats_eps, cvmi_stream_t stream);
 
 /* Token-stationary linear layer for Hiera's short-K GEMMs (sam2 hieradet MultiScaleBlock: qkv(norm1(x)), x = shortcut + proj(attn),
  * mlp.layers[0](norm2(x)) + GELU; behind sam2_infer.py:226):
@@ -269,6 +273,9 @@ int cvmi_tok_linear_stats(const void* in, int in_ld, int in_f32_layernorm, const
  * w_packed as for cvmi_tok_linear; H, W even, B*H*W a multiple of 256, K in {144, 288, 576}. */
 int cvmi_tok_linear_pool(const void* in, int in_ld, const float* gamma, const float* beta, float eps, const void* w_packed, void* out,
                          int out_ld, int B, int H, int W, int K, int N, int dtype, cvmi_stream_t stream);
+/* same, with the rows' LayerNorm statistics supplied (float[2 * B*H*W] of (mean, rstd) pairs, or NULL) */
+int cvmi_tok_linear_pool_stats(const void* in, int in_ld, const float* gamma, const float* beta, float eps, const void* w_packed, void* out,
+                               int out_ld, int B, int H, int W, int K, int N, int dtype, const float* ln_stats_in, cvmi_stream_t stream);
 
 /* Diagnostic only (CVMI_TOKLIN_STAMP=1 selects a stamped build of the K = 576 LayerNorm form of cvmi_tok_linear, never for timing
  * runs): reads and clears 24 s_memtime sums (shader cycles) of workgroup 0.  Ping-pong schedule: [0..8] = wave 0 {b1 wait, MFMAs,

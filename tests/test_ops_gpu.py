@@ -443,10 +443,13 @@ def test_hiera_mlp_fused_vs_torch(C_, rows, dt):
     view = xb.images(0, 1).view()
     view.buf.W = rows                                             # the op covers the first `rows` rows only
     plan = Plan(stream())
-    op_hiera_mlp(plan, "mlp", pm, view, gam.cuda(), bet.cuda(), 1e-6)
+    stats = torch.full((rows, 2), -7.0, device="cuda")                 # LayerNorm statistics of the UPDATED rows, for the next block's norm1
+    op_hiera_mlp(plan, "mlp", pm, view, gam.cuda(), bet.cuda(), 1e-6, stats_out=stats, stats_eps=1e-6)
     run(plan)
     got = xb.t.view(rows + 3, C_).cpu()
     assert torch.equal(got[rows:], x[rows:])
+    exp_stats = torch.stack((got[:rows].mean(1), 1.0 / torch.sqrt(got[:rows].var(1, unbiased=False) + 1e-6)), 1)
+    torch.testing.assert_close(stats.cpu(), exp_stats, rtol=2e-5, atol=2e-5)
     err = (got[:rows] - ref).abs().max().item()
     tol = 3e-3 if dt == F16 else 2.4e-2                       # bf16: 8 mantissa bits against 11
     torch.testing.assert_close(got[:rows], ref, rtol=tol, atol=tol), err
@@ -539,6 +542,14 @@ def test_tok_linear_pool_vs_torch(K, N, B, H, W, dt):
     got = dst.t.float().cpu()
     torch.testing.assert_close(got[..., :N], ref, rtol=4e-3 * tol, atol=4e-3 * tol)
     assert bool((got[..., N:] == 7.0).all())
+    # the same launch with the rows' LayerNorm statistics supplied (as the previous block's fused MLP writes them): one pass over the rows
+    xr = x.reshape(-1, K)
+    stats = torch.stack((xr.mean(1), 1.0 / torch.sqrt(xr.var(1, unbiased=False) + 1e-6)), 1).contiguous().cuda()
+    dst2 = Buf(B, H // 2, W // 2, Np, F32); dst2.t.fill_(7.0)
+    plan = Plan(stream())
+    op_tok_linear_pool(plan, "tlp_stats", pt, src.view(), dst2.view(0, N), (gam.cuda(), bet.cuda(), 1e-6), stats_in=stats)
+    run(plan)
+    torch.testing.assert_close(dst2.t.float().cpu()[..., :N], got[..., :N], rtol=2e-3 * tol, atol=2e-3 * tol)
 
 
 @pytest.mark.parametrize("K,N2", [(576, 2304), (288, 1152), (144, 576)])
