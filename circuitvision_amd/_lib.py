@@ -26,6 +26,7 @@ class ConvDesc(C.Structure):
         ("N", C.c_int), ("Kpad", C.c_int), ("act", C.c_int), ("dtype", C.c_int),
         ("out_f32", C.c_int), ("scalar_gather", C.c_int),
         ("res_mod", C.c_int), ("act_after_res", C.c_int), ("shuffle_cout", C.c_int), ("res_rep", C.c_int),
+        ("row_stats", C.c_void_p),
     ]
 
 
@@ -101,7 +102,7 @@ SIGNATURES = {
     "cvmi_tok_linear_supported": (_i, [_i]),
     "cvmi_tok_linear_packed_bytes": (C.c_size_t, [_i, _i]),
     "cvmi_tok_linear": (_i, [_vp, _i, _i, _vp, _vp, _f, _vp, _vp, _i, _i, C.c_longlong, _i, _i, _i, _i, _vp]),
-    "cvmi_tok_linear_stats": (_i, [_vp, _i, _i, _vp, _vp, _f, _vp, _vp, _i, _i, C.c_longlong, _i, _i, _i, _i, _vp, _vp, _f, _vp]),
+    "cvmi_tok_linear_stats": (_i, [_vp, _i, _i, _vp, _vp, _f, _vp, _vp, _i, _i, C.c_longlong, _i, _i, _i, _i, _vp, _i, _vp, _f, _vp]),
     "cvmi_tok_linear_pool_stats": (_i, [_vp, _i, _vp, _vp, _f, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "cvmi_tok_linear_pool": (_i, [_vp, _i, _vp, _vp, _f, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "cvmi_debug_stamps": (_i, [C.POINTER(C.c_ulonglong)]),

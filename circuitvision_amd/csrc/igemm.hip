@@ -36,6 +36,7 @@ struct ConvKArgs {
   int rows2;                             // 1x1 / s1 / p0 over two concatenated sources with channel counts that are K-tile multiples
   int nb_n;
   int bias_off;                          // igemm_kernel: LDS byte offset of the parked bias row
+  float* stats;                          // gemm256x192 (f32 out): per row and 96-column slice (sum, sum of squares) of the values written, or null
   FastDiv div_ctot, div_kw;
 };
 
@@ -1343,8 +1344,28 @@ __global__ __launch_bounds__(512, 1) void gemm256x192_kernel(const ConvKArgs p) 
           for (int e = 0; e < OVEC; ++e) a[e] = act_apply<true>(a[e], p.act);
         }
         cv = pack16<TO>(a);
+        if constexpr (OES == 4) {
+          // row statistics for the NEXT LayerNorm over these rows: this thread's 4 values -> (sum, sum of squares), parked in the chunk slot it
+          // has just consumed (no other thread reads that slot), reduced per row below
+          if (p.stats) *reinterpret_cast<float2*>(Ct + row * CROWB + ch * 16) = make_float2((a[0] + a[1]) + (a[2] + a[3]), fmaf(a[0], a[0], fmaf(a[1], a[1], fmaf(a[2], a[2], a[3] * a[3]))));
+        }
       }
       *reinterpret_cast<u32x4*>(p.y + ((size_t)m * p.y_ld + n) * OES) = cv;
+    }
+    if constexpr (OES == 4) {
+      if (p.stats) {                                        // (uniform; the host admits it only with a residual and whole 96-column slices)
+        __syncthreads();
+        if (tid < BM && m0 + tid < p.M) {
+          float ps = 0.f, pq = 0.f;
+#pragma unroll
+          for (int ch = 0; ch < NCH; ++ch) {                // fixed order: bit-identical replays
+            const float2 t = *reinterpret_cast<const float2*>(Ct + tid * CROWB + ch * 16);
+            ps += t.x; pq += t.y;
+          }
+          const int slices = p.N / CW;
+          *reinterpret_cast<float2*>(p.stats + ((size_t)(m0 + tid) * slices + (n0 / CW + pass)) * 2) = make_float2(ps, pq);
+        }
+      }
     }
     if (pass + 1 < NPASS) __syncthreads();
   }
@@ -1473,7 +1494,7 @@ int launch_typed(ConvKArgs& a, hipStream_t stream) {
     if (use_g256 && a.plain && a.K % 8 == 0 && a.K >= g256_mink && a.Kpad % 64 == 0 && N % 8 == 0 && N >= g256_minn && a.shuf_c == 0 && a.res_rep <= 1) {
       const long long tiles = (long long)cdiv(M, 256) * cdiv(N, 256);
       const double col_eff = (double)N / (cdiv(N, 256) * 256), wave_eff = (double)tiles / (double)(cdiv(tiles, 256) * 256);
-      if (tiles >= 256 && ((col_eff >= 0.8 && wave_eff >= 0.8) || use_g256 >= 3)) {
+      if (!a.stats && tiles >= 256 && ((col_eff >= 0.8 && wave_eff >= 0.8) || use_g256 >= 3)) {
         static const int use_p = getenv("CVMI_G256P") ? atoi(getenv("CVMI_G256P")) : 1;             // tuning experiments only
         if constexpr (sizeof(TO) == 2) {
           if (use_p && !a.res && !a.act_after_res) return launch_g256p(a, stream);
@@ -1489,6 +1510,7 @@ int launch_typed(ConvKArgs& a, hipStream_t stream) {
         return launch_g256x192<TO>(a, stream);
     }
   }
+  CVMI_CHECK(!a.stats, "conv2d: row_stats is produced by the 256 x 192 GEMM only (plain f16 GEMM, N %% 192 == 0, K >= 1024, >= 256 tiles)");
   static const int glds_min_tiles = getenv("CVMI_GLDS_MINTILES") ? atoi(getenv("CVMI_GLDS_MINTILES")) : 512;   // tuning experiments only
   // (K not a multiple of the 128-byte tile: only from K = 256 elements up -- at K = 144 the padded third tile costs more than the DMA saves)
   if (use_glds && (a.plain || a.rows2) && a.K % (16 / (int)sizeof(T)) == 0 && (a.Kpad * (int)sizeof(T)) % 128 == 0 && a.K * (int)sizeof(T) >= 256 &&
@@ -1573,6 +1595,9 @@ extern "C" int CVMI_ENTRY(cvmi_conv2d)(const cvmi_conv_desc* d, cvmi_stream_t st
   a.M = (int)M; a.N = d->N; a.K = (int)K; a.Kpad = d->Kpad;
   a.act = d->act; a.scalar_gather = d->scalar_gather; a.nb_n = 1;
   a.res_mod = d->res_mod; a.act_after_res = d->act_after_res; a.shuf_c = d->shuffle_cout; a.res_rep = d->res_rep;
+  a.stats = d->row_stats;
+  CVMI_CHECK(!d->row_stats || (d->out_f32 && d->res && !d->act_after_res && d->N % 192 == 0 && ((uintptr_t)d->row_stats & 7) == 0),
+             "conv2d: row_stats needs the f32-output residual form with N a multiple of 192");
   a.plain = (d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0 && d->c1 == 0 && d->up0 == 0 && !d->scalar_gather &&
              d->OH == d->H && d->OW == d->W) ? 1 : 0;
   a.rows2 = (!a.plain && d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0 && !d->scalar_gather && d->OH == d->H && d->OW == d->W &&

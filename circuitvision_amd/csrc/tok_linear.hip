@@ -44,6 +44,7 @@ struct TlExtra {
   const float* stats_in;
   float* stats_out;
   float stats_eps;
+  int stats_parts;          // 0: stats_in holds (mean, rstd) per row; P > 0: P raw (sum, sum of squares) partials per row (cvmi_conv_desc.row_stats)
 };
 
 template <int K, int LN, bool RES, bool GELU, bool TSTORE, bool STAMP = false, bool PP = false, bool POOL = false>
@@ -106,9 +107,17 @@ __global__ __launch_bounds__(TL_NW * 64, 2) void tok_linear_kernel(const void* _
     // the fp16 fragments.
     const float* xr = reinterpret_cast<const float*>(in) + row * (long long)in_ld;
     float mean, rstd;
-    if (ex.stats_in) {                                       // forwarded by the producer of these rows: pass 1 disappears
+    if (ex.stats_in && ex.stats_parts == 0) {                // forwarded by the producer of these rows: pass 1 disappears
       const float2 st = *reinterpret_cast<const float2*>(ex.stats_in + 2 * row);
       mean = st.x; rstd = st.y;
+    } else if (ex.stats_in) {                                // raw partial sums of a tiled GEMM's column slices, added in a fixed order
+      float ss = 0.f, qq = 0.f;
+      for (int t = 0; t < ex.stats_parts; ++t) {
+        const float2 st = *reinterpret_cast<const float2*>(ex.stats_in + (row * ex.stats_parts + t) * 2);
+        ss += st.x; qq += st.y;
+      }
+      mean = ss / (float)K;
+      rstd = 1.0f / sqrtf(fmaxf(qq / (float)K - mean * mean, 0.f) + eps);
     } else {
       const float x0 = xr[0];
       float s = 0.f, q = 0.f;
@@ -483,20 +492,21 @@ extern "C" size_t cvmi_tok_linear_packed_bytes(int K, int N) {
 }
 extern "C" int cvmi_tok_linear_stats_bf16(const void* in, int in_ld, int in_f32_layernorm, const float* gamma, const float* beta, float eps,
                                           const void* w_packed, void* out, int out_ld, int out_f32_residual, long long rows, int K, int N, int act,
-                                          int dtype, const float* ln_stats_in, float* ln_stats_out, float ln_stats_eps, cvmi_stream_t stream_);
+                                          int dtype, const float* ln_stats_in, int ln_stats_in_parts, float* ln_stats_out, float ln_stats_eps, cvmi_stream_t stream_);
 #endif
 
 // cvmi_tok_linear with LayerNorm statistics handed from the launch that WRITES the residual stream to the launch that normalises it:
 //   ln_stats_out (out_f32_residual = 1): float2 per row = (mean, 1 / sqrt(var + ln_stats_eps)) over the N updated values of the row
-//   ln_stats_in  (in_f32_layernorm = 1): the same pair per row; the prologue then reads every row once instead of twice
+//   ln_stats_in  (in_f32_layernorm = 1): the same pair per row; the prologue then reads every row once instead of twice.
+//                ln_stats_in_parts = P > 0: instead P raw (sum, sum of squares) pairs per row, as cvmi_conv_desc.row_stats writes them
 // (x = x + proj(attn) followed by mlp.layers[0](norm2(x)) in sam2 hieradet MultiScaleBlock; behind /root/reference/src/sam2_infer.py:226).
 extern "C" int CVMI_ENTRY(cvmi_tok_linear_stats)(const void* in, int in_ld, int in_f32_layernorm, const float* gamma, const float* beta, float eps,
                                                  const void* w_packed, void* out, int out_ld, int out_f32_residual, long long rows, int K, int N, int act,
-                                                 int dtype, const float* ln_stats_in, float* ln_stats_out, float ln_stats_eps, cvmi_stream_t stream_) {
+                                                 int dtype, const float* ln_stats_in, int ln_stats_in_parts, float* ln_stats_out, float ln_stats_eps, cvmi_stream_t stream_) {
 #ifndef CVMI_OPERAND_BF16
   if (dtype == CVMI_BF16)
     return cvmi_tok_linear_stats_bf16(in, in_ld, in_f32_layernorm, gamma, beta, eps, w_packed, out, out_ld, out_f32_residual, rows, K, N, act, dtype,
-                                      ln_stats_in, ln_stats_out, ln_stats_eps, stream_);
+                                      ln_stats_in, ln_stats_in_parts, ln_stats_out, ln_stats_eps, stream_);
 #endif
   CVMI_CHECK(dtype == CVMI_T16, "tok_linear: dtype must be CVMI_F16 or CVMI_BF16");
   CVMI_CHECK(in && w_packed && out && rows > 0 && rows % 256 == 0 && N > 0, "tok_linear: bad arguments (rows must be a multiple of 256)");
@@ -511,10 +521,11 @@ extern "C" int CVMI_ENTRY(cvmi_tok_linear_stats)(const void* in, int in_ld, int 
              "tok_linear: pointers / ld not aligned (in_ld=%d out_ld=%d N=%d)", in_ld, out_ld, N);
   CVMI_CHECK((!ln_stats_in || in_f32_layernorm == 1) && (!ln_stats_out || out_f32_residual) && (((uintptr_t)ln_stats_in | (uintptr_t)ln_stats_out) & 7) == 0,
              "tok_linear: ln_stats_in needs the LayerNorm input form, ln_stats_out the residual output form (8-byte aligned)");
+  CVMI_CHECK(ln_stats_in_parts >= 0 && ln_stats_in_parts <= 64, "tok_linear: ln_stats_in_parts out of range");
   hipStream_t s = (hipStream_t)stream_;
   const int ln = in_f32_layernorm;
   const bool res = out_f32_residual != 0;
-  const TlExtra ex{0, 0, ln_stats_in, ln_stats_out, ln_stats_eps};
+  const TlExtra ex{0, 0, ln_stats_in, ln_stats_out, ln_stats_eps, ln_stats_in_parts};
   switch (K) {
     case 144: return dispatch_tl<144>(ln, res, act, in, in_ld, gamma, beta, eps, w_packed, out, out_ld, rows, N, s, ex);
     case 288: return dispatch_tl<288>(ln, res, act, in, in_ld, gamma, beta, eps, w_packed, out, out_ld, rows, N, s, ex);
@@ -526,7 +537,7 @@ extern "C" int CVMI_ENTRY(cvmi_tok_linear)(const void* in, int in_ld, int in_f32
                                            const void* w_packed, void* out, int out_ld, int out_f32_residual, long long rows, int K, int N, int act,
                                            int dtype, cvmi_stream_t stream_) {
   return CVMI_ENTRY(cvmi_tok_linear_stats)(in, in_ld, in_f32_layernorm, gamma, beta, eps, w_packed, out, out_ld, out_f32_residual, rows, K, N, act, dtype,
-                                           nullptr, nullptr, 0.f, stream_);
+                                           nullptr, 0, nullptr, 0.f, stream_);
 }
 
 #ifndef CVMI_OPERAND_BF16
@@ -556,9 +567,9 @@ extern "C" int CVMI_ENTRY(cvmi_tok_linear_pool_stats)(const void* in, int in_ld,
   hipStream_t s = (hipStream_t)stream_;
   const int hw2 = (H / 2) * (W / 2);
   switch (K) {
-    case 144: return launch_tl1<144, 1, false, false, false, false, true, true>(in, in_ld, gamma, beta, eps, w_packed, out, out_ld, rows, N, s, TlExtra{W, hw2, ln_stats_in, nullptr, 0.f});
-    case 288: return launch_tl1<288, 1, false, false, false, false, true, true>(in, in_ld, gamma, beta, eps, w_packed, out, out_ld, rows, N, s, TlExtra{W, hw2, ln_stats_in, nullptr, 0.f});
-    default: return launch_tl1<576, 1, false, false, false, false, true, true>(in, in_ld, gamma, beta, eps, w_packed, out, out_ld, rows, N, s, TlExtra{W, hw2, ln_stats_in, nullptr, 0.f});
+    case 144: return launch_tl1<144, 1, false, false, false, false, true, true>(in, in_ld, gamma, beta, eps, w_packed, out, out_ld, rows, N, s, TlExtra{W, hw2, ln_stats_in, nullptr, 0.f, 0});
+    case 288: return launch_tl1<288, 1, false, false, false, false, true, true>(in, in_ld, gamma, beta, eps, w_packed, out, out_ld, rows, N, s, TlExtra{W, hw2, ln_stats_in, nullptr, 0.f, 0});
+    default: return launch_tl1<576, 1, false, false, false, false, true, true>(in, in_ld, gamma, beta, eps, w_packed, out, out_ld, rows, N, s, TlExtra{W, hw2, ln_stats_in, nullptr, 0.f, 0});
   }
 }
 

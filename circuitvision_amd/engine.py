@@ -215,8 +215,21 @@ class Plan:
 
 
 # ---- op wrappers (each appends one launch to a plan) --------------------------------------------
+def row_stats_supported(M, N, K):
+    """True when cvmi_conv2d sends a plain 16-bit GEMM [M, K] x [K, N] with f32 output + residual to the 256 x 192 kernel, the one that can write
+    cvmi_conv_desc.row_stats (mirrors launch_typed in igemm.hip: N a multiple of 192 that 256-wide tiles would waste, K >= 1024, at least one
+    tile per CU and >= 80 % of the last round of tiles used)."""
+    if N % 192 or N < 384 or K < 1024 or K % 64:
+        return False
+    t256 = -(-M // 256) * -(-N // 256)
+    if t256 >= 256 and N / (-(-N // 256) * 256) >= 0.8 and t256 / (-(-t256 // 256) * 256) >= 0.8:
+        return False                                  # the 256 x 256 kernel takes it
+    t192 = -(-M // 256) * (N // 192)
+    return t192 >= 256 and t192 / (-(-t192 // 256) * 256) >= 0.8
+
+
 def op_conv(plan, label, pc, srcs, dst, stride=1, pad=None, act=_lib.ACT_NONE, res=None, out_hw=None,
-            scalar_gather=False, kind="conv", res_mod=0, act_after_res=False, shuffle_cout=0, res_rep=0):
+            scalar_gather=False, kind="conv", res_mod=0, act_after_res=False, shuffle_cout=0, res_rep=0, row_stats=None):
     """srcs: [(View, up)] (1 or 2 channel-concatenated sources).  dst / res: View."""
     lib = _lib.load()
     (v0, up0) = srcs[0]
@@ -247,8 +260,11 @@ def op_conv(plan, label, pc, srcs, dst, stride=1, pad=None, act=_lib.ACT_NONE, r
         c0=v0.c, c1=(v1.c if v1 is not None else 0), up0=up0, up1=up1,
         B=v0.B, H=H, W=W, OH=OH, OW=OW, KH=pc.KH, KW=pc.KW, stride=stride, pad=pad,
         N=pc.N, Kpad=pc.Kpad, act=act, dtype=pc.dtype, out_f32=out_f32, scalar_gather=1 if scalar_gather else 0,
-        res_mod=res_mod, act_after_res=1 if act_after_res else 0, shuffle_cout=shuffle_cout, res_rep=res_rep)
-    plan.keep.append((d, pc, srcs, dst, res))
+        res_mod=res_mod, act_after_res=1 if act_after_res else 0, shuffle_cout=shuffle_cout, res_rep=res_rep,
+        row_stats=(row_stats.data_ptr() if row_stats is not None else None))
+    if row_stats is not None:       # f32 [rows, N / 96, 2]: (sum, sum of squares) per 96-column slice of every written row (Hiera stage-3 fc2 shape only)
+        assert row_stats.dtype == torch.float32 and row_stats.is_contiguous() and row_stats.numel() == v0.B * OH * OW * (pc.N // 96) * 2, label
+    plan.keep.append((d, pc, srcs, dst, res, row_stats))
     sp0 = plan.sptr
     fn = lib.cvmi_conv2d
 
@@ -563,11 +579,13 @@ class PackedTokLinear:
         self.param_bytes = N * K * 2
 
 
-def op_tok_linear(plan, label, pt, src, dst, ln=None, act=_lib.ACT_NONE, residual=False, kind="gemm", stats_in=None, stats_out=None, stats_eps=1e-6):
+def op_tok_linear(plan, label, pt, src, dst, ln=None, act=_lib.ACT_NONE, residual=False, kind="gemm", stats_in=None, stats_out=None, stats_eps=1e-6,
+                  stats_parts=0):
     """src: f32 View with ln = (gamma, beta, eps) or ln = "cast" (f32 rows converted as they are, K <= 288), or an fp16 View.
     dst: fp16 View, or (residual=True) the f32 View updated in place.
     stats_out (residual=True): f32 tensor [rows, 2] that receives each updated row's (mean, rstd) for the NEXT LayerNorm (eps = stats_eps);
-    stats_in (ln = (gamma, beta, eps)): such a tensor written by the launch that produced src -- the prologue then reads src once."""
+    stats_in (ln = (gamma, beta, eps)): such a tensor written by the launch that produced src -- the prologue then reads src once.
+    stats_parts = P > 0: stats_in is instead f32 [rows, P, 2] of raw (sum, sum of squares) partials (op_conv(row_stats=...))."""
     lib = _lib.load()
     src, dst = _as_rows(src), _as_rows(dst)
     assert src.C == pt.K and dst.C == pt.N and src.rows == dst.rows and src.rows % 256 == 0, label
@@ -577,12 +595,12 @@ def op_tok_linear(plan, label, pt, src, dst, ln=None, act=_lib.ACT_NONE, residua
     assert not cast or ln == "cast", label
     assert stats_in is None or (ln is not None and not cast), label
     assert stats_out is None or residual, label
-    for st in (stats_in, stats_out):
-        assert st is None or (st.dtype == torch.float32 and st.numel() == 2 * src.rows and st.is_contiguous()), label
+    assert stats_out is None or (stats_out.dtype == torch.float32 and stats_out.numel() == 2 * src.rows and stats_out.is_contiguous()), label
+    assert stats_in is None or (stats_in.dtype == torch.float32 and stats_in.numel() == 2 * src.rows * max(stats_parts, 1) and stats_in.is_contiguous()), label
     gam, bet, eps = ln if (ln is not None and not cast) else (None, None, 0.0)
     args = (src.ptr, src.ld, 2 if cast else 1 if ln is not None else 0, gam.data_ptr() if gam is not None else None, bet.data_ptr() if bet is not None else None,
             float(eps), pt.w.data_ptr(), dst.ptr, dst.ld, 1 if residual else 0, src.rows, pt.K, pt.N, act, pt.dtype,
-            stats_in.data_ptr() if stats_in is not None else None, stats_out.data_ptr() if stats_out is not None else None, float(stats_eps))
+            stats_in.data_ptr() if stats_in is not None else None, int(stats_parts), stats_out.data_ptr() if stats_out is not None else None, float(stats_eps))
     plan.keep.append((pt, src, dst, gam, bet, stats_in, stats_out))
     sp0, fn = plan.sptr, lib.cvmi_tok_linear_stats
 

@@ -30,7 +30,7 @@ import torch.nn.functional as TF
 from . import _lib
 from ._lib import ACT_GELU, ACT_NONE, ACT_RELU, ACT_SIGMOID, BF16, F16, F32
 from .engine import (ESIZE, TORCH_DTYPE, is16, Buf, PackedConv, PackedHieraMlp, PackedTokLinear, Plan, Rows, hiera_mlp_supported, make_attn_desc, op_attention,
-                     op_call, op_cast, op_conv, op_hiera_mlp, op_layernorm, op_maxpool2, op_tok_linear, op_tok_linear_pool, require_gpu,
+                     op_call, op_cast, op_conv, op_hiera_mlp, op_layernorm, op_maxpool2, op_tok_linear, op_tok_linear_pool, require_gpu, row_stats_supported,
                      tok_linear_supported)
 
 HIERA_L = dict(embed_dim=144, num_heads=2, stages=(2, 6, 36, 4), global_att_blocks=(23, 33, 43), window_spec=(8, 4, 16, 8))
@@ -399,7 +399,7 @@ class Sam2Plan:
 
     def __init__(self, wt, B, stream, dynamic_multimask_via_stability=True, prompts=0, points=3, high_res=True):
         self.wt, self.B, self.dt, self.dev = wt, B, wt.dtype, wt.device
-        self._ln1_stats = None                                        # LayerNorm statistics handed from a block's fused MLP to the next block's norm1
+        self._ln1_stats, self._ln1_parts = None, 0                    # LayerNorm statistics handed from a block's MLP to the next block's norm1
         self.P, self.K, self.want_high_res = prompts, points, high_res
         if prompts and not wt.prompt_ok:
             raise _lib.CvmiError("this checkpoint carries no sam_prompt_encoder tensors: box / point prompts are unavailable")
@@ -474,12 +474,14 @@ class Sam2Plan:
         elif not tok_qkv or (dim != dout and not tok_pool):
             xn = self.buf(H, W, dim, tag="xn")
             op_layernorm(self.plan, f"b{i}.norm1", x.view(), gam, bet, xn.view(), 1e-6)
-        ln1_stats = self._ln1_stats if (self._ln1_stats is not None and self._ln1_stats.numel() == 2 * B * H * W) else None
-        self._ln1_stats = None                                     # (written by the previous block's fused MLP for exactly these rows)
+        parts = self._ln1_parts
+        ln1_stats = self._ln1_stats if (self._ln1_stats is not None and self._ln1_stats.numel() == 2 * B * H * W * max(parts, 1)) else None
+        self._ln1_stats, self._ln1_parts = None, 0                 # (written by the previous block's MLP for exactly these rows)
         if dim != dout:
             short = self.buf(H // 2, W // 2, dout, F32)
             if tok_pool:
-                op_tok_linear_pool(self.plan, f"b{i}.dimproj_pool", wt.tl[f"b{i}.dimproj"], x.view(), short.view(), (gam, bet, 1e-6), stats_in=ln1_stats)
+                op_tok_linear_pool(self.plan, f"b{i}.dimproj_pool", wt.tl[f"b{i}.dimproj"], x.view(), short.view(), (gam, bet, 1e-6),
+                                   stats_in=ln1_stats if parts == 0 else None)
             else:
                 pj = self.buf(H, W, dout, F32, tag="dimproj")
                 self.gemm(f"b{i}.dimproj", f"b{i}.dimproj", xn.view(), pj.view(), out_hw=(H, W) if padded else None)
@@ -488,7 +490,7 @@ class Sam2Plan:
             short = x
         qkv = self.buf(Hp, Wp, 3 * dout, tag="qkv")
         if tok_qkv:
-            op_tok_linear(self.plan, f"b{i}.qkv", wt.tl[f"b{i}.qkv"], x.view(), qkv.view(), ln=(gam, bet, 1e-6), stats_in=ln1_stats)
+            op_tok_linear(self.plan, f"b{i}.qkv", wt.tl[f"b{i}.qkv"], x.view(), qkv.view(), ln=(gam, bet, 1e-6), stats_in=ln1_stats, stats_parts=parts)
         else:
             self.gemm(f"b{i}.qkv", f"b{i}.qkv", xn.view(), qkv.view())
         OH, OW = (H // 2, W // 2) if blk["q_pool"] else (H, W)
@@ -539,7 +541,14 @@ class Sam2Plan:
                 xn2 = self.buf(OH, OW, dout, tag="xn")
                 op_layernorm(self.plan, f"b{i}.norm2", x.view(), gam, bet, xn2.view(), 1e-6)
                 self.gemm(f"b{i}.fc1", f"b{i}.fc1", xn2.view(), hid.view(), act=ACT_GELU)
-            self.gemm(f"b{i}.fc2", f"b{i}.fc2", hid.view(), x.view(), res=x.view())
+            # a tiled GEMM hands the next block's norm1 raw per-slice sums (the 256 x 192 kernel: stage-3 fc2 shape); tok_linear adds them up
+            rs = None
+            nxt_qkv = f"b{i + 1}.qkv" in wt.tl and i + 1 < len(wt.blocks) and wt.blocks[i + 1]["dim"] == dout
+            if (nxt_qkv and tok_out and self.dt != F32 and row_stats_supported(B * OH * OW, dout, 4 * dout)
+                    and os.environ.get("CVMI_SAM_LNSTATS", "1") != "0" and os.environ.get("CVMI_SAM_LNSTATS_FC2", "1") != "0"):
+                rs = torch.empty(B * OH * OW, dout // 96, 2, dtype=torch.float32, device=self.dev)
+                self._ln1_stats, self._ln1_parts = rs, dout // 96
+            self.gemm(f"b{i}.fc2", f"b{i}.fc2", hid.view(), x.view(), res=x.view(), row_stats=rs)
         if i in self.wt.stage_ends and i != len(self.wt.blocks) - 1:
             # the next block writes its own shortcut buffer (dim change) -> x stays intact as the stage output
             pass

@@ -592,3 +592,45 @@ def test_tok_linear_forwarded_layernorm_statistics(K, N2, dt):
     ya, yb = out_a.float().cpu(), out_b.float().cpu()
     torch.testing.assert_close(ya, yb, rtol=2e-3 * tol, atol=2e-3 * tol)     # same rows, same statistics up to summation order
     torch.testing.assert_close(ya, y_ref, rtol=6e-3 * tol, atol=6e-3 * tol)
+
+
+@pytest.mark.parametrize("dt", [F16, BF16])
+def test_gemm_row_statistics_feed_the_next_layernorm(dt):
+    """Hiera stage-3 fc2 shape (65536 x 2304 -> 576, f32 residual stream updated in place): the 256 x 192 GEMM also writes, per row and per
+    96-column slice, (sum, sum of squares) of the values it stores (cvmi_conv_desc.row_stats); the next block's qkv (cvmi_tok_linear_stats with
+    ln_stats_in_parts = 6) adds them up instead of reading the rows twice.  Statistics vs float64 sums of the rows AS WRITTEN; the qkv output
+    with forwarded statistics vs the two-pass prologue on the same rows; replays bit-identical."""
+    from circuitvision_amd.engine import TORCH_DTYPE, PackedTokLinear, Rows, op_tok_linear, row_stats_supported
+    td = TORCH_DTYPE[dt]
+    tol = 1.0 if dt == F16 else 8.0
+    M, K, N = 65536, 2304, 576
+    assert row_stats_supported(M, N, K)
+    g = torch.Generator(device="cuda").manual_seed(3)
+    hid = (torch.randn(M, K, generator=g, device="cuda") * 0.5).to(td)
+    w = quant(torch.randn(N, K) / K ** 0.5, dt); b = torch.randn(N) * 0.2
+    x0 = torch.randn(M, N, generator=g, device="cuda") * 1.5 + 0.4
+    x0[:, 11] += 30.0
+    xb = Buf(1, 1, M, N, F32); xb.t.copy_(x0.view(1, 1, M, N))
+    hb = Buf(1, 1, M, K, dt); hb.t.copy_(hid.view(1, 1, M, K))
+    parts = torch.zeros(M, N // 96, 2, device="cuda")
+    pc = PackedConv(w.view(N, K, 1, 1), b, dt)
+    wq = quant(torch.randn(64, N) / N ** 0.5, dt)
+    pq = PackedTokLinear(wq, torch.zeros(64), dtype=dt)
+    gam, bet = (torch.rand(N) + 0.5).cuda(), (torch.randn(N) * 0.2).cuda()
+    oa = torch.empty(M, 64, dtype=td, device="cuda"); ob = torch.empty_like(oa)
+    plan = Plan(stream())
+    op_conv(plan, "fc2", pc, [(hb.view(), 0)], xb.view(), res=xb.view(), row_stats=parts)
+    op_tok_linear(plan, "qkv_fwd", pq, Rows(xb.t.view(M, N), M, N), Rows(oa, M, 64), ln=(gam, bet, 1e-6), stats_in=parts, stats_parts=N // 96)
+    op_tok_linear(plan, "qkv_two_pass", pq, Rows(xb.t.view(M, N), M, N), Rows(ob, M, 64), ln=(gam, bet, 1e-6))
+    run(plan)
+    x1 = xb.t.view(M, N).double()
+    sl = x1.view(M, N // 96, 96)
+    exp = torch.stack((sl.sum(2), (sl * sl).sum(2)), 2).float()
+    torch.testing.assert_close(parts, exp, rtol=2e-5, atol=2e-4)
+    ref_rows = (x0.double() + hid.double() @ w.double().cuda().t() + b.double().cuda())[:512]
+    torch.testing.assert_close(x1[:512], ref_rows, rtol=2e-3 * tol, atol=2e-3 * tol)
+    torch.testing.assert_close(oa.float(), ob.float(), rtol=2e-3 * tol, atol=2e-3 * tol)
+    first = (parts.clone(), oa.clone())
+    xb.t.copy_(x0.view(1, 1, M, N)); parts.zero_()
+    run(plan)
+    assert torch.equal(parts, first[0]) and torch.equal(oa, first[1])
