@@ -71,6 +71,7 @@ SIGNATURES = {
     "cvmi_version": (_i, []),
     "cvmi_last_error": (C.c_char_p, []),
     "cvmi_device_info": (_i, [_i, C.POINTER(_i)]),
+    "cvmi_desc_size": (C.c_size_t, [_i]),
     "cvmi_graph_begin": (_i, [_vp]),
     "cvmi_graph_end": (_i, [_vp, C.POINTER(_vp)]),
     "cvmi_graph_launch": (_i, [_vp, _vp]),
@@ -140,8 +141,23 @@ def load():
         fn = getattr(lib, name)          # AttributeError here = header / library mismatch
         fn.restype = res
         fn.argtypes = args
+    check_abi(lib)
     _lib = lib
     return lib
+
+
+# kind (include/cvmi355.h: CVMI_DESC_*) -> the ctypes mirror of that descriptor struct
+DESC_MIRRORS = {0: ConvDesc, 1: C3k2Desc, 2: DwPwDesc, 3: AttnDesc}
+
+
+def check_abi(lib, mirrors=None):
+    """Every descriptor mirror must have exactly the size the library was compiled with: a mirror that is short by a trailing
+    field would make the kernels' host code read past its end (cvmi_desc_size, include/cvmi355.h)."""
+    for kind, cls in (mirrors or DESC_MIRRORS).items():
+        want = int(lib.cvmi_desc_size(kind))
+        if want != C.sizeof(cls):
+            raise CvmiError(f"ABI mismatch: {cls.__name__} is {C.sizeof(cls)} bytes in this binding but {want} bytes in {LIB_PATH} "
+                            f"(cvmi_desc_size({kind})); rebuild the library or update the binding to include/cvmi355.h")
 
 
 def check(rc, what=""):

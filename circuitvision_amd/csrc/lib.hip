@@ -15,6 +15,16 @@ void cvmi_set_error(const char* fmt, ...) {
 extern "C" int cvmi_version(void) { return CVMI_VERSION; }
 extern "C" const char* cvmi_last_error(void) { return g_err; }
 
+extern "C" size_t cvmi_desc_size(int kind) {
+  switch (kind) {
+    case CVMI_DESC_CONV: return sizeof(cvmi_conv_desc);
+    case CVMI_DESC_C3K2: return sizeof(cvmi_c3k2_desc);
+    case CVMI_DESC_DWPW: return sizeof(cvmi_dwpw_desc);
+    case CVMI_DESC_ATTN: return sizeof(cvmi_attn_desc);
+    default: return 0;
+  }
+}
+
 extern "C" int cvmi_device_info(int device, int* out4) {
   CVMI_CHECK(out4, "device_info: null pointer");
   hipDeviceProp_t prop;

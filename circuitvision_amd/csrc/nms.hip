@@ -17,6 +17,9 @@ namespace {
 
 constexpr int NMS_THREADS = 1024;
 constexpr int NMS_LDS_A = 16384;                   // sort keys live in LDS up to this many anchors (imgsz <= 864 square) ...
+// byte offset of the GK sort keys in the workspace: behind the candidates + best score / class arrays, rounded up to 16 bytes (u64 keys:
+// B * A * 28 + 256 alone is only 4-byte aligned when B * A is odd, e.g. imgsz 928 -> A = 17661 at B = 1)
+__host__ __device__ inline size_t nms_keys_offset(size_t nb, size_t A) { return (nb * A * 28 + 256 + 15) & ~(size_t)15; }
 constexpr int NMS_MAX_A = 65536;                   // ... and in the workspace above it (checkpoints trained at imgsz 960 / 1024 / 1280)
 constexpr int NMS_MAX_DET = 4096;                  // LDS list of kept positions
 
@@ -56,7 +59,8 @@ __global__ __launch_bounds__(NMS_THREADS) void yolo_nms_kernel(const float* __re
   unsigned long long* keys;                                                          // [P]
   unsigned long long* supp;                                                          // [P/64] bitmask, always LDS
   if constexpr (GK) {
-    keys = reinterpret_cast<unsigned long long*>(workspace + (size_t)nb * (size_t)A * (sizeof(Cand) + sizeof(float) + sizeof(int)) + 256) + (size_t)b * P;
+    static_assert(sizeof(Cand) + sizeof(float) + sizeof(int) == 28, "nms_keys_offset assumes 28 bytes per anchor");
+    keys = reinterpret_cast<unsigned long long*>(workspace + nms_keys_offset(nb, A)) + (size_t)b * P;
     supp = reinterpret_cast<unsigned long long*>(smem);
   } else {
     keys = reinterpret_cast<unsigned long long*>(smem);
@@ -183,7 +187,7 @@ extern "C" size_t cvmi_yolo_nms_workspace(int B, int A) {
   if (B <= 0 || A <= 0) return 0;
   size_t P = 1024;
   while (P < (size_t)A) P <<= 1;
-  return (size_t)B * (size_t)A * (sizeof(Cand) + sizeof(float) + sizeof(int)) + 256 + (A > NMS_LDS_A ? (size_t)B * P * 8 : 0);
+  return nms_keys_offset(B, A) + (A > NMS_LDS_A ? (size_t)B * P * 8 : 0);
 }
 
 static int nms_launch(const float* pred, const float* best_score, const int* best_cls, int B, int nc, int A, float conf_thres, float iou_thres,

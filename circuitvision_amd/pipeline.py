@@ -119,11 +119,29 @@ class CircuitPipeline:
 
 def gather_results(results, key="mask", dst=0):
     """Collect one same-shaped tensor per image (e.g. the u8 mask of equally sized images) from every rank on `dst`:
-    returns {global index: tensor} there, None elsewhere.  Shards may be uneven."""
-    if not results:
-        raise ValueError("gather_results needs at least one local result per rank (pad the batch or skip the gather)")
-    idx = torch.tensor([i for i, _ in results], dtype=torch.int64, device=results[0][1][key].device)
-    vals = torch.stack([r[key] for _, r in results])
+    returns {global index: tensor} there, None elsewhere.  Shards may be uneven, and a rank may hold NO image (more ranks than
+    images): it still enters the collectives -- with zero rows of the dtype / trailing shape the other ranks report -- instead
+    of leaving them waiting."""
+    import torch.distributed as dist
+    local = [r[key] for _, r in results]
+    multi = dist.is_initialized() and dist.get_world_size() > 1
+    meta = (local[0].dtype, tuple(local[0].shape), str(local[0].device)) if local else None
+    if multi:
+        metas = [None] * dist.get_world_size()
+        dist.all_gather_object(metas, meta)                                # every rank, before anything that could raise
+        known = [m for m in metas if m is not None]
+        if not known:
+            return {} if dist.get_rank() == dst else None
+        if any(m[:2] != known[0][:2] for m in known):
+            raise ValueError(f"gather_results: ranks disagree on the dtype / shape of '{key}': {sorted(set(m[:2] for m in known), key=str)}")
+        if meta is None:                                                   # empty shard: zero rows, on this rank's device
+            dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+            meta = (known[0][0], known[0][1], str(dev))
+    elif meta is None:
+        return {}
+    dev = torch.device(meta[2])
+    idx = torch.tensor([i for i, _ in results], dtype=torch.int64, device=dev)
+    vals = torch.stack(local) if local else torch.zeros((0,) + meta[1], dtype=meta[0], device=dev)
     gi, gv = gather_rows(idx, dst), gather_rows(vals, dst)
     if gi is None:
         return None

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define CVMI_VERSION 114
+#define CVMI_VERSION 120
 
 typedef void* cvmi_stream_t; /* hipStream_t */
 
@@ -43,6 +43,12 @@ int cvmi_version(void);
 const char* cvmi_last_error(void);
 /* fills: [0] CU count, [1] wave size, [2] LDS bytes per CU-workgroup, [3] gfx arch number (950) */
 int cvmi_device_info(int device, int* out4);
+/* ABI guard for the descriptor structs below: sizeof(struct) as THIS library was compiled, for kind = CVMI_DESC_CONV / _C3K2 / _DWPW /
+ * _ATTN (0 for an unknown kind).  A binding compares it with the size of its own mirror of the struct once, at load, and refuses to
+ * continue on a mismatch (circuitvision_amd/_lib.py does; INTEGRATION.md shows the check): a struct that is short by a trailing field
+ * would otherwise be read past its end. */
+enum { CVMI_DESC_CONV = 0, CVMI_DESC_C3K2 = 1, CVMI_DESC_DWPW = 2, CVMI_DESC_ATTN = 3 };
+size_t cvmi_desc_size(int kind);
 
 /* ---- HIP graph capture of a launch sequence (replaces per-op Python dispatch) ---------------- */
 int cvmi_graph_begin(cvmi_stream_t stream);

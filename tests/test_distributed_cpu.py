@@ -171,6 +171,33 @@ def test_pipeline_sharded_equals_unsharded_gloo_world2():
         assert i == j and torch.equal(m, r["masks"]) and torch.equal(iou, r["iou"]) and m.shape[0] == min(4, len(r["bboxes"])) > 0
 
 
+def _empty_shard_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from circuitvision_amd.pipeline import gather_results
+    images = _pipeline_images(1)                                    # 1 image over 2 ranks: rank 1 holds nothing
+    res = _fake_pipeline().run_batch(images, "learned", rank, world)
+    masks = gather_results(res, "mask", dst=0)                      # must not hang or raise on the empty rank
+    none_at_all = gather_results([], "mask", dst=0)                 # no rank has a result
+    out[rank] = (len(res), None if masks is None else {k: v.clone() for k, v in masks.items()}, none_at_all)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gather_results_with_an_empty_shard_gloo_world2():
+    """a rank whose shard is empty (world > number of images) takes part in the gather with zero rows instead of raising
+    before the collective (which left the other ranks hanging)."""
+    world, port = 2, 35000 + os.getpid() % 2000
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_empty_shard_worker, args=(world, port, out), nprocs=world, join=True)
+    ref = _fake_pipeline().run_batch(_pipeline_images(1), "learned")
+    assert out[0][0] == 1 and out[1][0] == 0
+    assert out[1][1] is None and sorted(out[0][1]) == [0] and torch.equal(out[0][1][0], ref[0][1]["mask"])
+    assert out[0][2] == {} and out[1][2] is None
+
+
 def _uneven_gather_worker(rank, world, port, out):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))

@@ -127,7 +127,33 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in cvmi355.h but not exported"
     assert set(_lib.SIGNATURES) == declared
-    assert lib.cvmi_version() >= 100
+    assert lib.cvmi_version() >= 120
+
+
+def test_descriptor_mirrors_match_the_library_and_a_short_struct_is_rejected():
+    """The ctypes mirrors of the four descriptor structs must have the size libcvmi355.so was compiled with (cvmi_desc_size), field
+    order as in include/cvmi355.h; a mirror that is short by its trailing field (INTEGRATION.md once documented cvmi_conv_desc without
+    `row_stats`) is refused at load instead of being read past its end."""
+    from circuitvision_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        pytest.skip("libcvmi355.so not built")
+    lib = _lib.load()                                     # runs check_abi
+    for kind, cls in _lib.DESC_MIRRORS.items():
+        assert lib.cvmi_desc_size(kind) == ctypes.sizeof(cls) > 0
+    assert lib.cvmi_desc_size(99) == 0
+    hdr = open(os.path.join(ROOT, "include", "cvmi355.h")).read()
+    body = hdr[hdr.index("typedef struct cvmi_conv_desc {"):hdr.index("} cvmi_conv_desc;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = [n for decl in re.findall(r"(?:const\s+)?(?:void|float|int)\s*\*?\s*([^;{]+);", body) for n in re.findall(r"\*?\s*([a-zA-Z_0-9]+)", decl)]
+    assert fields == [n for n, _ in _lib.ConvDesc._fields_], "ConvDesc field order differs from cvmi_conv_desc"
+
+    class ShortConvDesc(ctypes.Structure):                # the stale documented form: everything but the last field
+        _fields_ = _lib.ConvDesc._fields_[:-1]
+    with pytest.raises(_lib.CvmiError, match="ABI mismatch"):
+        _lib.check_abi(lib, {0: ShortConvDesc})
+    # the binding INTEGRATION.md documents is the full struct
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    assert '"row_stats"' in doc and "cvmi_desc_size" in doc
 
 
 def test_product_fails_loudly_without_gpu():

@@ -421,12 +421,13 @@ def test_config1_sample_image_yolo11n_plus_sam2_tiny(tmp_path):
     oracle = YOLO11("n", 62).eval()
     oracle.load_state_dict(yp.state_dict(), strict=True)
     with torch.no_grad():
-        ref, ref_idx = onms.yolo_nms(oracle(x), 0.25, 0.7, 300, return_indices=True)
+        opred = oracle(x)
+    ref, ref_idx = onms.yolo_nms(opred, 0.25, 0.7, 300, return_indices=True)
     ref, ref_idx = ref[0], ref_idx[0]
     ref[:, :4] = onms.scale_boxes(x.shape[2:], ref[:, :4], img.shape[:2])
     from helpers import assert_same_detections
     assert ref.shape[0] >= 20
-    assert_same_detections("config 1 detector", r.anchor_idx.cpu().tolist(), ref_idx.tolist())
+    assert_same_detections("config 1 detector", r.anchor_idx.cpu().tolist(), ref_idx.tolist(), pred=opred[0])
     if r.anchor_idx.cpu().tolist() == ref_idx.tolist():
         assert r.boxes.cls.cpu().tolist() == ref[:, 5].tolist()
         np.testing.assert_allclose(r.boxes.xyxy.cpu().numpy(), ref[:, :4].numpy(), atol=0.05)

@@ -141,7 +141,7 @@ def _test_images(B, H, W, dtype, seed=0):
     return x.to(TORCH_DTYPE[dtype]).float()
 
 
-def _match_detections(name, plan, ref_det, ref_idx, exact):
+def _match_detections(name, plan, ref_det, ref_idx, exact, pred=None):
     """GPU detections (plan.det / det_idx / det_count) vs the oracle's NMS on the ORACLE's predictions.
     exact (f32 mode): same kept anchor indices in the same order, same classes, conf within 1e-3, boxes within 0.05 px.
     otherwise (f16): report the identical-box rate |common anchors| / |union| (>= 0.8 required); on the common ones the class
@@ -156,7 +156,7 @@ def _match_detections(name, plan, ref_det, ref_idx, exact):
         rm = {int(a): i for i, a in enumerate(r_idx)}
         common = sorted(set(gm) & set(rm))
         if exact:
-            assert_same_detections(f"{name} image {b}", g_idx.tolist(), r_idx.tolist())
+            assert_same_detections(f"{name} image {b}", g_idx.tolist(), r_idx.tolist(), pred=None if pred is None else pred[b])
             gi, ri = [gm[a] for a in common], [rm[a] for a in common]
             assert g[gi, 5].tolist() == r[ri, 5].tolist(), (name, b)
             torch.testing.assert_close(g[gi, 4], r[ri, 4], rtol=0, atol=1e-3)
@@ -227,7 +227,7 @@ def test_yolo11_forward_matches_oracle(dtype, scale, B, H, W):
         assert torch.equal(plan.det[b, :n].cpu(), ref_det[b])
     # ... and against the oracle end to end (oracle network -> oracle NMS): identical integer anchor indices in f32
     o_det, o_idx = onms.yolo_nms(ref, 0.25, 0.7, 300, return_indices=True)
-    _match_detections(tag, plan, o_det, o_idx, exact=dtype == F32)
+    _match_detections(tag, plan, o_det, o_idx, exact=dtype == F32, pred=ref)
 
 
 def _boundary_case(tmp_path, dtype, img, seed=3, scale="n", nc=62):
@@ -266,9 +266,16 @@ def test_predict_boundary_matches_oracle_pipeline(tmp_path, hw):
     ref[:, :4] = onms.scale_boxes(x.shape[2:], ref[:, :4], img.shape[:2])
     assert ref.shape[0] >= 20, ref.shape                                          # the comparison below is not about empty lists
     assert float((ref[:, :4] - unscaled).abs().max()) > 5.0                        # scale_boxes does move these boxes
-    assert_same_detections("predict f32", r.anchor_idx.cpu().tolist(), ref_idx.tolist())      # identical integer anchor indices
-    if r.anchor_idx.cpu().tolist() != ref_idx.tolist():
-        pytest.skip("a rounding-noise tie changed one kept box; the positional comparisons below need identical lists")
+    got_idx = r.anchor_idx.cpu().tolist()
+    assert_same_detections("predict f32", got_idx, ref_idx.tolist(), pred=pred[0])      # identical integer anchor indices (or a CHECKED threshold tie)
+    # positional comparisons on the anchors both sides kept (all of them unless a checked tie flipped one)
+    gm, rm = {a: i for i, a in enumerate(got_idx)}, {int(a): i for i, a in enumerate(ref_idx)}
+    common = [a for a in got_idx if a in rm]
+    assert len(common) >= 20
+    gi, ri = [gm[a] for a in common], [rm[a] for a in common]
+    full = got_idx == ref_idx.tolist()
+    cls, conf, xyxy, got_d = [cls[i] for i in gi], [conf[i] for i in gi], [xyxy[i] for i in gi], [got_d[i] for i in gi]
+    ref = ref[ri]
     assert cls == ref[:, 5].tolist()
     np.testing.assert_allclose(conf, ref[:, 4].numpy(), atol=1e-3)
     np.testing.assert_allclose(np.asarray(xyxy).reshape(-1, 4), ref[:, :4].numpy().reshape(-1, 4), atol=0.05)
@@ -281,7 +288,7 @@ def test_predict_boundary_matches_oracle_pipeline(tmp_path, hw):
     a = [b["persistent_uid"] for b in non_max_suppression_by_confidence(ref_d, 0.6)]
     b = [b["persistent_uid"] for b in onms.nms_by_confidence(ref_d, 0.6)]
     assert a == b and 0 < len(a) <= len(ref_d)
-    if all(g_["persistent_uid"] == r_["persistent_uid"] for g_, r_ in zip(got_d, ref_d)):
+    if full and all(g_["persistent_uid"] == r_["persistent_uid"] for g_, r_ in zip(got_d, ref_d)):
         assert [b["persistent_uid"] for b in non_max_suppression_by_confidence(got_d, 0.6)] == b
 
 
@@ -323,9 +330,10 @@ def test_predict_honours_checkpoint_imgsz_and_large_inputs(tmp_path):
     r = det.predict(img, verbose=False)[0]
     oracle = _oracle_from(params, "n", 62)
     with torch.no_grad():
-        ref, ref_idx = onms.yolo_nms(oracle(x), 0.25, 0.7, 300, return_indices=True)
+        pred1024 = oracle(x)
+    ref, ref_idx = onms.yolo_nms(pred1024, 0.25, 0.7, 300, return_indices=True)
     assert ref[0].shape[0] >= 20
-    assert_same_detections("predict imgsz 1024", r.anchor_idx.cpu().tolist(), ref_idx[0].tolist())
+    assert_same_detections("predict imgsz 1024", r.anchor_idx.cpu().tolist(), ref_idx[0].tolist(), pred=pred1024[0])
     r640 = det.predict(img, verbose=False, imgsz=640)[0]
     assert next(k for k in det._plans if k[1:3] == (448, 640))
     assert len(r640) != len(r) or not torch.equal(r640.boxes.data, r.boxes.data)
