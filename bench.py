@@ -18,8 +18,11 @@ over 64 images TOTAL, sharded over the ranks -- strong scaling).
 GPU); under torchrun WORLD_SIZE must equal --gpus.
 
 Prints ONE JSON line (rank 0).  Extra objects:
-  roofline      the dominant kernel of the workload (default: Hiera stage-3 fc1 = tok_linear_kernel<576, LN, GELU>, MFMA-bound: 36 launches per
-                B=16 pass, algorithmic flops per launch / average HIP-event duration of those launches);
+  roofline      the dominant launch SHAPE of the workload, selected by MEASURED time share: launches of the profiling pass are grouped by
+                (kernel the library dispatched to -- cvmi_last_kernel(), the name rocprofv3 lists --, flops, bytes) and the group with the largest
+                summed duration wins (today: Hiera stage-3 fc2 = gemm256x192_kernel<float> or fc1 = tok_linear_kernel<576, 1, ...>);
+                algorithmic flops per launch / average HIP-event duration of those launches; `traffic` = PMC bytes per launch of that kernel
+                from the committed tools/traffic_sam.py passes.  `top_launches` lists the eight largest shapes the same way;
   rooflines     every family the north_star sets a target on: YOLO11-n conv stack vs the HBM roof (SURVEY.md 8(d) algorithmic
                 bytes: 81.8 MB fp16 activations / image + 5.2 MB weights / batch), Hiera GEMMs, global and windowed attention vs
                 the dense fp16 MFMA peak.  `achieved` = algorithmic bytes (flops) / the summed duration of those launches,
@@ -182,6 +185,26 @@ def synthetic_boxes(B, P, R=1024, seed=0):
     return torch.cat((xy, xy + side), -1)
 
 
+def check_replicas(tensors, what):
+    """After the weight broadcast every rank must hold the same bytes: a float64 checksum per rank, MIN and MAX over the ranks equal
+    (non-zero ranks started from blank buffers, so equality also shows that the broadcast covers every tensor a forward pass reads)."""
+    import torch
+    import torch.distributed as dist
+    if isinstance(tensors, dict):
+        from circuitvision_amd.distributed import packed_tensors
+        tensors = packed_tensors(tensors)
+    s = torch.zeros(2, dtype=torch.float64, device="cuda")
+    for i, t in enumerate(tensors):
+        v = t.double()
+        s[0] += v.sum() * (1 + (i % 7))
+        s[1] += v.abs().sum()
+    lo, hi = s.clone(), s.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    if not torch.equal(lo, hi) or float(hi[1]) == 0.0:
+        raise SystemExit(f"bench.py: {what} weight replicas differ between ranks after the broadcast ({lo.tolist()} vs {hi.tolist()})")
+
+
 # ---- stages ------------------------------------------------------------------------------------------------------------------
 class YoloStage:
     """YOLO11 forward + decode + NMS on B resident images (one captured graph)."""
@@ -190,16 +213,19 @@ class YoloStage:
         import torch
         from circuitvision_amd import _lib
         from circuitvision_amd.distributed import broadcast_packed
-        from circuitvision_amd.yolo11 import SyntheticParams, Yolo11Plan, Yolo11Weights
+        from circuitvision_amd.yolo11 import BlankParams, SyntheticParams, Yolo11Plan, Yolo11Weights
         from synth import circuit_image
         self.scale, self.B, self.nc = scale, B, 62
         if a.dtype == "bf16":
             raise SystemExit("--dtype bf16 is built for the SAM 2 path (workloads sam2l / sam2l_box); the detector runs fp16 / f32")
         self.dtype = {"f16": _lib.F16, "f32": _lib.F32}[a.dtype]
-        self.params = SyntheticParams(seed=0, nc=self.nc)
+        # only rank 0 "reads the checkpoint" (generates + packs the seeded weights); the other ranks allocate blank buffers of the same
+        # shapes and receive every packed tensor by the one-time RCCL broadcast
+        self.params = SyntheticParams(seed=0, nc=self.nc) if rank == 0 else BlankParams()
         self.wt = Yolo11Weights(scale, self.nc, self.params, self.dtype, device=f"cuda:{local_rank}")
         if world > 1:
             broadcast_packed(self.wt.packed, src=0)            # one-time RCCL broadcast of the packed weights
+            check_replicas(self.wt.packed, "YOLO11")
         self.yp = Yolo11Plan(self.wt, B, 640, 640, stream, keep_scores=False)
         lib = _lib.load()
         self.seeds = [seed0 + b for b in range(B)]
@@ -220,7 +246,8 @@ class YoloStage:
         kth = float(lg.kthvalue(lg.numel() - CAND * B + 1).values)
         for i in range(3):
             self.wt.packed[f"model.23.cv3.{i}.2"].bias[:nc] += (math.log(0.25 / 0.75) - kth + 1e-3)
-            self.params.sd[f"model.23.cv3.{i}.2.bias"] += (math.log(0.25 / 0.75) - kth + 1e-3)       # the CPU leg runs the same head
+            if rank == 0:
+                self.params.sd[f"model.23.cv3.{i}.2.bias"] += (math.log(0.25 / 0.75) - kth + 1e-3)   # the CPU leg runs the same head
         self.plan.capture()
 
     def run(self):
@@ -281,16 +308,18 @@ class SamStage:
         import torch
         from circuitvision_amd import _lib
         from circuitvision_amd.distributed import broadcast_weights
-        from circuitvision_amd.sam2 import HIERA_L, LORA_TARGETS_REFERENCE, Sam2Plan, Sam2Weights, SamSyntheticParams
+        from circuitvision_amd.sam2 import HIERA_L, LORA_TARGETS_REFERENCE, Sam2Plan, Sam2Weights, SamBlankParams, SamSyntheticParams
         from synth import circuit_image
         self.B, self.P = B, prompts
         self.dtype = {"f16": _lib.F16, "f32": _lib.F32, "bf16": _lib.BF16}[a.dtype]
         key = (a.dtype, local_rank)
         if key not in SamStage._weights:                         # two SAM stages of one step share the weights
-            params = SamSyntheticParams(seed=0, lora_targets=LORA_TARGETS_REFERENCE)
+            params = SamSyntheticParams(seed=0, lora_targets=LORA_TARGETS_REFERENCE) if rank == 0 else SamBlankParams()
             wt = Sam2Weights(params, HIERA_L, 1024, self.dtype, device=f"cuda:{local_rank}")
             if world > 1:
-                broadcast_weights(wt, src=0)
+                broadcast_weights(wt, src=0)                     # ranks > 0 hold blank buffers until this arrives
+                from circuitvision_amd.distributed import weight_tensors
+                check_replicas(weight_tensors(wt), "SAM 2.1")
             SamStage._weights[key] = (params, wt)
         self.params, self.wt = SamStage._weights[key]
         self.sp = Sam2Plan(self.wt, B, stream, prompts=prompts)
@@ -311,27 +340,56 @@ class SamStage:
     def run(self):
         self.plan.run()
 
+    # launch kinds whose bound is the matrix pipe (flops / duration vs the dense MFMA peak); everything else is priced against HBM
+    MFMA_KINDS = ("gemm", "mlp_fused", "attn_global", "attn_window", "attention")
+
+    def _traffic(self):
+        """Per-launch HBM bytes of the SAM pass from the committed PMC passes (tools/traffic_sam.py): {kernel: [entries]}."""
+        path = os.path.join(ROOT, "profiles", "sam_traffic_latest.json")
+        if self.P or self.B != 16 or self.dtype != 0 or not os.path.exists(path):      # collected for configs[2]: B = 16, fp16, learned prompts
+            return {}, None
+        try:
+            t = json.load(open(path))
+            return t.get("kernels", {}), f"profiles/sam_traffic_latest.json ({t.get('note', '')}; rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes over an eager pass; a committed measurement, NOT read in this run)"
+        except Exception:
+            return {}, None
+
     def profile(self, reps=2):
-        acc = {}
-        dom = [0.0, 0, 0.0]                                       # the single dominant kernel: stage-3 fc1 (tok_linear, K=576, N=2304, LayerNorm + GELU fused)
+        """Per-launch event pairs over `reps` eager passes.  Launches are grouped into SHAPES = (kernel the library dispatched to, flops,
+        plan bytes); the shape with the largest measured share of the pass is `roofline`, the next ones follow in `top_launches`."""
+        acc, shapes = {}, {}
         self.plan.timed_eager()
         for _ in range(reps):
-            for label, kind, ms, b, f in self.plan.timed_eager():
+            for label, kind, ms, b, f, kn in self.plan.timed_eager(with_kernels=True):
                 k = acc.setdefault(kind, [0.0, 0, 0, 0])
                 k[0] += ms / reps; k[1] += 1; k[2] += b / reps; k[3] += f / reps
-                if label.endswith(".fc1") and f == 2.0 * self.B * 4096 * 576 * 2304:
-                    dom[0] += ms; dom[1] += 1; dom[2] = f
+                if kind == "sync":
+                    continue
+                sh = shapes.setdefault((kn or f"[{kind}] {label.rsplit('.', 1)[-1]}", f, b), {"ms": 0.0, "n": 0, "kind": kind, "labels": []})
+                sh["ms"] += ms; sh["n"] += 1
+                if len(sh["labels"]) < 2 and label not in sh["labels"]:
+                    sh["labels"].append(label)
         total_ms = sum(v[0] for v in acc.values())
-        roofs = {}
-        if dom[1]:
-            us = dom[0] / dom[1] * 1e3
-            ach = dom[2] / (us * 1e-6) / 1e12
-            roofs["sam2l_fc1_tok_linear"] = {
-                "bound": "mfma", "achieved": round(ach, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": None,
-                "kernel": f"tok_linear_kernel<576, LN, GELU> (Hiera stage-3 fc1: {self.B * 4096} rows x K=576 x N=2304, LayerNorm and GELU fused), the launch with the "
-                          f"largest share of the step: {dom[1] // reps} launches per pass, average of HIP event pairs on the engine stream; compare the same kernel's "
-                          "average in profiles/r02_sam2l_b16_kernel_stats.md",
-                "us_per_launch": round(us, 2), "algorithmic_flops_per_launch": int(dom[2])}
+        traffic, tsrc = self._traffic()
+        ranked = sorted(shapes.items(), key=lambda kv: -kv[1]["ms"])
+        roofs, tops = {}, []
+        for (kn, f, b), sh in ranked[:8]:
+            n_pass = sh["n"] // reps
+            us = sh["ms"] / sh["n"] * 1e3
+            tr = next((e["hbm_bytes"] for e in traffic.get(kn, []) if e.get("launches_per_pass") == n_pass), None)
+            mfma = sh["kind"] in self.MFMA_KINDS and f > 0
+            ach = f / (us * 1e-6) / 1e12 if mfma else b / (us * 1e-6) / 1e9
+            peak = MFMA_PEAK_TFLOPS if mfma else HBM_PEAK_GBS
+            tops.append({"bound": "mfma" if mfma else "hbm", "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s" if mfma else "GB/s",
+                         "frac": round(ach / peak, 4), "traffic": tr, "traffic_source": tsrc if tr is not None else None,
+                         "kernel": f"{kn}: {n_pass} launches per B={self.B} pass (e.g. {', '.join(sh['labels'])}), {100 * sh['ms'] / reps / total_ms:.1f} % of the pass's summed "
+                                   "launch time; average of HIP event pairs on the engine stream over un-captured passes",
+                         "us_per_launch": round(us, 2), "launches_per_pass": n_pass, "share_of_pass": round(sh["ms"] / reps / total_ms, 4),
+                         "algorithmic_flops_per_launch": int(f), "plan_bytes_per_launch": int(b),
+                         "plan_bytes_gbs": round(b / (us * 1e-6) / 1e9, 1)})
+        if tops:
+            roofs["sam2l_dominant_launch"] = tops[0]
+            roofs["sam2l_top_launches"] = tops
         if "mlp_fused" in acc:                                    # the fused stage-1 / 2 MLP launches are linear-layer flops too
             g, m = acc.setdefault("gemm", [0.0, 0, 0, 0]), acc["mlp_fused"]
             acc["linear"] = [g[0] + m[0], g[1] + m[1], g[2] + m[2], g[3] + m[3]]
@@ -360,6 +418,52 @@ class SamStage:
         return torch.stack([osam.sam2_transform(circuit_image(768, 1024, seed=s), 1024) for s in self.seeds[:1]])
 
 
+class HostPipeline:
+    """The pipeline as a caller runs it: `CircuitPipeline.run_batch` on u8 HOST images of this rank's shard, sharing the packed weights of
+    the graph-only stages (analysis_pipeline.py:97-115 + :168-225 per image in the reference).  Everything the reference chains between
+    the two models is inside the timed call: H2D, letterbox, detector, D2H of the detections, dicts + round() + uid + stage-2 NMS,
+    channel swap + transform, segmenter, post-process (resize, threshold, u8, extent), D2H of the u8 masks."""
+
+    def __init__(self, a, ystage, sstage, n, seed0):
+        import torch
+        from circuitvision_amd.detector import YOLO
+        from circuitvision_amd.pipeline import CircuitPipeline
+        from circuitvision_amd.sam2 import HIERA_L
+        from circuitvision_amd.sam2_infer import SAM2Model, SAM2Transforms
+        from synth import circuit_image
+        det = YOLO.from_weights(ystage.wt, {i: f"class{i}" for i in range(ystage.nc)}, dtype=a.dtype)     # the stage's (bias-shifted) packed weights
+        seg = SAM2Model(HIERA_L, 1024, dtype=a.dtype, use_refinement=True)
+        seg.weights, seg.params = sstage.wt, sstage.params
+        tr = SAM2Transforms(resolution=1024, mask_threshold=0, max_hole_area=0, max_sprinkle_area=0)
+        self.pipe = CircuitPipeline(det, seg, tr, seg_batch=16)
+        self.images = [circuit_image(640, 640, seed=seed0 + i) for i in range(n)]
+        self.n = n
+        self.torch = torch
+
+    def run(self):
+        res = self.pipe.run_batch(self.images, "learned")
+        t0 = time.perf_counter()
+        masks = [r["mask"].cpu() for _, r in res]                       # the caller's `.detach().cpu()` (circuit_analyzer.py:355)
+        self.pipe.timings["D2H of the u8 masks"] += time.perf_counter() - t0
+        return res, masks
+
+    def measure(self, steps, warmup):
+        for _ in range(warmup):
+            self.run()
+        self.pipe.timings.clear()
+        self.torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            res, masks = self.run()
+        self.torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        nb = sum(len(r["bboxes"]) for _, r in res)
+        return {"images_per_s": round(self.n / dt, 2), "ms_per_step": round(dt * 1e3, 3), "steps": steps,
+                "mean_boxes_after_stage2_nms": round(nb / max(1, len(res)), 1),
+                "phases_ms_per_step": {k: round(v / steps * 1e3, 3) for k, v in self.pipe.timings.items()},
+                "what": "CircuitPipeline.run_batch(images u8 HxWx3 on the host, prompts='learned') + .cpu() of the u8 masks, wall clock around the calls"}
+
+
 # ---- main ---------------------------------------------------------------------------------------------------------------------
 def main():
     a = parse()
@@ -381,6 +485,7 @@ def main():
     stream = torch.cuda.Stream()
     w = a.workload
     scaling = "weak"
+    host_pipe = None
     if w == "circuit":
         by, bs = a.batch or 32, 16
         nsam = by // bs
@@ -411,13 +516,21 @@ def main():
         if a.total_images % world or n % 2:
             raise SystemExit("--total-images must split evenly (and into an even share) over the ranks")
         bs = min(16, n)
+        sam_sizes = [bs] * (n // bs) + ([n % bs] if n % bs else [])          # EVERY image of the shard goes through the segmenter
+        assert sum(sam_sizes) == n
         seed0 = 20250704 + lo
         stages = [("yolo11l", YoloStage(a, "l", n, rank, local_rank, world, stream, seed0))]
-        stages += [(f"sam2l[{j}]", SamStage(a, bs, rank, local_rank, world, stream, seed0 + j * bs)) for j in range(n // bs)]
+        off = 0
+        for j, b_ in enumerate(sam_sizes):
+            stages.append((f"sam2l[{j}]", SamStage(a, b_, rank, local_rank, world, stream, seed0 + off)))
+            off += b_
         images_per_step = n
         scaling = "strong"
+        host_pipe = HostPipeline(a, stages[0][1], stages[1][1], n, seed0)
         name = (f"full pipeline YOLO11-l 640x640 + SAM2.1 Hiera-L 1024x1024, {a.total_images} circuit images per step sharded over {world} GPU(s) "
-                f"({n} per GPU: detector batch {n}, segmenter {n // bs} x batch {bs}), fp16 (BASELINE configs[3])")
+                f"({n} per GPU: detector batch {n}, segmenter batches {sam_sizes}), fp16 (BASELINE configs[3]); `value` = graph replays on "
+                "resident tensors, `host_inclusive` = CircuitPipeline.run_batch on u8 host images (H2D, letterbox, detector, D2H + glue + "
+                "stage-2 NMS, transform, segmenter, post-process, D2H of the u8 masks)")
 
     for _ in range(a.warmup):
         for _, st in stages:
@@ -440,6 +553,17 @@ def main():
         dist.barrier()
     ms_per_step = dt / a.steps * 1e3
     value = world * images_per_step * a.steps / dt
+    host_info = None
+    if host_pipe is not None:                                     # every rank runs its shard through the host-visible path too; MAX over ranks
+        if world > 1:
+            dist.barrier()
+        host_info = host_pipe.measure(max(2, a.steps // 2), 1)
+        if world > 1:
+            t = torch.tensor([host_info["ms_per_step"]], device="cuda", dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            host_info["ms_per_step"] = round(float(t.item()), 3)
+            host_info["images_per_s"] = round(world * images_per_step / float(t.item()) * 1e3, 2)
+        host_info["ratio_vs_graph_only"] = round(host_info["images_per_s"] / value, 4)
 
     # ---- per-stage timing (graph replays alone) + per-launch timing pass (un-captured, event pairs on the engine stream)
     stage_info, rooflines, cpu_parts = {}, {}, {}
@@ -480,7 +604,8 @@ def main():
         # the dominant kernel family by time: Hiera linear GEMMs wherever SAM runs, else the detector's conv stack
         # `roofline` = the single launch shape with the largest share of the step (its average duration can be checked against the rocprofv3
         # summary in profiles/); the family aggregates stay in `rooflines`
-        top = rooflines.get("sam2l_fc1_tok_linear") or rooflines.get("sam2l_linear_gemm") or next(iter(rooflines.values()), None)
+        tops = rooflines.pop("sam2l_top_launches", None)
+        top = rooflines.get("sam2l_dominant_launch") or rooflines.get("sam2l_linear_gemm") or next(iter(rooflines.values()), None)
         cpu = None
         if cpu_parts:
             if len(cpu_parts) == 1:
@@ -496,8 +621,10 @@ def main():
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": a.dtype, "data": "synthetic",
             "config": {"workload": name, "images_per_step": world * images_per_step, "nc": 62, "weights": "seeded random (SAM: LoRA merged)"},
-            "roofline": top, "cpu_baseline": cpu, "rooflines": rooflines, "stages": stage_info,
+            "roofline": top, "cpu_baseline": cpu, "rooflines": rooflines, "top_launches": tops, "stages": stage_info,
         }
+        if host_info is not None:
+            line["host_inclusive"] = host_info
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -70,6 +70,7 @@ _vp, _i, _f = C.c_void_p, C.c_int, C.c_float
 SIGNATURES = {
     "cvmi_version": (_i, []),
     "cvmi_last_error": (C.c_char_p, []),
+    "cvmi_last_kernel": (C.c_char_p, []),
     "cvmi_device_info": (_i, [_i, C.POINTER(_i)]),
     "cvmi_desc_size": (C.c_size_t, [_i]),
     "cvmi_graph_begin": (_i, [_vp]),

@@ -583,6 +583,7 @@ int launch_attn64(const AttnArgs& a, hipStream_t stream) {
   constexpr size_t lds = (size_t)64 * (KROW + VRS);
   const long long blocks = (long long)a.B * a.heads * ((a.qtiles + NW - 1) / NW);
   CVMI_CHECK(blocks > 0 && blocks < (1ll << 31), "attention: bad grid");
+  cvmi_note_kernel("attn64_kernel<%d, %d, %d>", DQKP, DVP, NW);
   hipLaunchKernelGGL((attn64_kernel<DQKP, DVP, NW>), dim3((unsigned)blocks), dim3(NW * 64), lds, stream, a);
   CVMI_LAUNCH_CHECK();
   return 0;
@@ -964,6 +965,7 @@ int launch_res64(const AttnArgs& a, hipStream_t stream) {
   constexpr int lds = 2 * (2 * 64 * 144 + 64);
   const long long blocks = ((long long)a.B * a.heads + 1) / 2;
   CVMI_CHECK(blocks > 0 && blocks < (1ll << 31), "attention: bad grid");
+  cvmi_note_kernel("attn_res64_kernel<%d>", QT);
   hipLaunchKernelGGL(attn_res64_kernel<QT>, dim3((unsigned)blocks), dim3(QT * 128), lds, stream, a);
   CVMI_LAUNCH_CHECK();
   return 0;
@@ -1169,6 +1171,7 @@ int launch_dma72(const AttnArgs& a, hipStream_t stream) {
   constexpr int lds = 4 * 64 * 144 + 256;
   const long long blocks = (long long)a.B * a.heads * ((a.qtiles + NW - 1) / NW);
   CVMI_CHECK(blocks > 0 && blocks < (1ll << 31), "attention: bad grid");
+  cvmi_note_kernel("attn_dma72_kernel<%d>", NW);
   hipLaunchKernelGGL(attn_dma72_kernel<NW>, dim3((unsigned)blocks), dim3(NW * 64), lds, stream, a);
   CVMI_LAUNCH_CHECK();
   return 0;
@@ -1184,6 +1187,7 @@ int launch_res256(const AttnArgs& a, hipStream_t stream) {
   }
   const long long blocks = (long long)a.B * a.heads * ((a.qtiles + NW - 1) / NW);
   CVMI_CHECK(blocks > 0 && blocks < (1ll << 31), "attention: bad grid");
+  cvmi_note_kernel("attn_res256_kernel<%d>", NW);
   hipLaunchKernelGGL(attn_res256_kernel<NW>, dim3((unsigned)blocks), dim3(NW * 64), lds, stream, a);
   CVMI_LAUNCH_CHECK();
   return 0;
@@ -1407,6 +1411,7 @@ int launch_f16(const AttnArgs& a, hipStream_t stream) {
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_done = true;
   }
+  cvmi_note_kernel("attn_f16_kernel<%d, %d, %d>", DQKP, DVP, GS);
   hipLaunchKernelGGL((attn_f16_kernel<DQKP, DVP, GS>), dim3((unsigned)blocks), dim3(256), lds, stream, a);
   CVMI_LAUNCH_CHECK();
   return 0;
@@ -1464,6 +1469,7 @@ extern "C" int CVMI_ENTRY(cvmi_attention)(const cvmi_attn_desc* d, cvmi_stream_t
   if (d->dtype == CVMI_F32) {
     CVMI_CHECK(d->dqk <= 128 && d->dv <= 128, "attention(f32): head dims up to 128");
     const long long rows = (long long)d->B * d->heads * d->Nq;
+    cvmi_note_kernel("attn_f32_kernel");
     hipLaunchKernelGGL(attn_f32_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, a);
     CVMI_LAUNCH_CHECK();
     return 0;
@@ -1482,6 +1488,7 @@ extern "C" int CVMI_ENTRY(cvmi_attention)(const cvmi_attn_desc* d, cvmi_stream_t
       ((uintptr_t)d->o & 15) == 0 && d->o_st % 8 == 0 && d->o_sh % 8 == 0) {
     const long long items = (long long)d->B * d->heads;
     const unsigned blocks = (unsigned)((items + 7) / 8);
+    cvmi_note_kernel("attn_win16_kernel<%d, 9>", d->Nq == 16 ? 16 : 4);
     if (d->Nq == 16) hipLaunchKernelGGL((attn_win16_kernel<16, 9>), dim3(blocks), dim3(128), 0, stream, a);
     else hipLaunchKernelGGL((attn_win16_kernel<4, 9>), dim3(blocks), dim3(128), 0, stream, a);
     CVMI_LAUNCH_CHECK();

@@ -31,6 +31,11 @@ typedef _Float16 f16;
 #endif
 #define CVMI_IS16(dt) ((dt) == CVMI_F16 || (dt) == CVMI_BF16)
 typedef f16 f16x8 __attribute__((ext_vector_type(8)));
+#ifdef CVMI_OPERAND_BF16
+#define CVMI_F16NAME "__bf16"
+#else
+#define CVMI_F16NAME "_Float16"
+#endif
 typedef f16 f16x2 __attribute__((ext_vector_type(2)));
 typedef f16 f16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -40,6 +45,12 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
 // ---- error plumbing ----------------------------------------------------------------------------
 void cvmi_set_error(const char* fmt, ...);
+// name of the kernel a dispatcher is about to launch (thread-local; read back by cvmi_last_kernel(): bench.py labels its per-launch
+// timings with it, so a roofline entry names the kernel rocprofv3 lists, not a guess of the host side)
+void cvmi_note_kernel(const char* fmt, ...);
+// template-argument spellings as llvm-cxxfilt prints them, so that a tag equals the demangled rocprofv3 kernel name up to blanks
+template <typename T> inline const char* cvmi_tyname() { return sizeof(T) == 4 ? "float" : "?"; }
+#define CVMI_BOOLNAME(b) ((b) ? "true" : "false")
 #define CVMI_FAIL(...)            \
   do {                            \
     cvmi_set_error(__VA_ARGS__);  \

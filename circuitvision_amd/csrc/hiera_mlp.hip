@@ -200,6 +200,7 @@ int launch_mlp(float* x, int x_ld, const float* gamma, const float* beta, float 
   static hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&hiera_mlp_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
   CVMI_HIP(attr);
   const long long per = (long long)Cfg::NW * 32;
+  cvmi_note_kernel("hiera_mlp_kernel<%d>", C);
   hipLaunchKernelGGL((hiera_mlp_kernel<C>), dim3((unsigned)((rows + per - 1) / per)), dim3(Cfg::NW * 64), Cfg::LDS, s, x, x_ld, gamma, beta, eps,
                      (const char*)wp, b2, rows, stats_out, stats_eps);
   CVMI_LAUNCH_CHECK();

@@ -620,6 +620,7 @@ int launch_glds(ConvKArgs& a, hipStream_t stream) {
   a.nb_n = cdiv(a.N, BN);
   const long long blocks = (long long)cdiv(a.M, BM) * a.nb_n;
   CVMI_CHECK(blocks > 0 && blocks < (1ll << 31), "conv2d: bad grid %lld", blocks);
+  cvmi_note_kernel("gemm_glds_kernel<%s, %s, %d, %d, %d, %d>", sizeof(T) == 2 ? CVMI_F16NAME : "float", sizeof(TO) == 2 ? CVMI_F16NAME : "float", BM, BN, WM, WN);
   hipLaunchKernelGGL((gemm_glds_kernel<T, TO, BM, BN, WM, WN>), dim3((unsigned)blocks), dim3(WM * WN * 64), lds, stream, a);
   CVMI_LAUNCH_CHECK();
   return 0;
@@ -1108,6 +1109,7 @@ int launch_g256p(ConvKArgs& a, hipStream_t stream) {
   const long long tiles = (long long)cdiv(a.M, 256) * a.nb_n;
   CVMI_CHECK(tiles >= 8 && tiles < (1ll << 31), "conv2d: bad grid %lld", tiles);
   const unsigned grid = tiles >= 256 ? 256u : (unsigned)(tiles / 8 * 8);
+  cvmi_note_kernel("gemm256p_kernel");
   hipLaunchKernelGGL(gemm256p_kernel, dim3(grid), dim3(512), bytes, stream, a, (int)tiles);
   CVMI_LAUNCH_CHECK();
   return 0;
@@ -1384,6 +1386,7 @@ int launch_g256x192(ConvKArgs& a, hipStream_t stream) {
   a.nb_n = cdiv(a.N, 192);
   const long long blocks = (long long)cdiv(a.M, 256) * a.nb_n;
   CVMI_CHECK(blocks > 0 && blocks < (1ll << 31), "conv2d: bad grid %lld", blocks);
+  cvmi_note_kernel("gemm256x192_kernel<%s>", sizeof(TO) == 2 ? CVMI_F16NAME : "float");
   hipLaunchKernelGGL((gemm256x192_kernel<TO>), dim3((unsigned)blocks), dim3(512), bytes, stream, a);
   CVMI_LAUNCH_CHECK();
   return 0;
@@ -1403,6 +1406,7 @@ int launch_g256(ConvKArgs& a, hipStream_t stream, int stagger) {
   a.nb_n = cdiv(a.N, 256);
   const long long blocks = (long long)cdiv(a.M, 256) * a.nb_n;
   CVMI_CHECK(blocks > 0 && blocks < (1ll << 31), "conv2d: bad grid %lld", blocks);
+  cvmi_note_kernel("gemm256_kernel<%s, %s>", sizeof(TO) == 2 ? CVMI_F16NAME : "float", CVMI_BOOLNAME(stagger));
   if (stagger) hipLaunchKernelGGL((gemm256_kernel<TO, true>), dim3((unsigned)blocks), dim3(512), bytes, stream, a);
   else hipLaunchKernelGGL((gemm256_kernel<TO, false>), dim3((unsigned)blocks), dim3(512), bytes, stream, a);
   CVMI_LAUNCH_CHECK();
@@ -1429,6 +1433,7 @@ int launch_cfg2(ConvKArgs& a, hipStream_t stream) {
   a.nb_n = cdiv(a.N, BN);
   const long long blocks = (long long)cdiv(a.M, BM) * a.nb_n;
   CVMI_CHECK(blocks > 0 && blocks < (1ll << 31), "conv2d: bad grid %lld", blocks);
+  cvmi_note_kernel("igemm_kernel<%s, %s, %d, %d, %d, %d, %d, %s, %d>", sizeof(T) == 2 ? CVMI_F16NAME : "float", sizeof(TO) == 2 ? CVMI_F16NAME : "float", BM, BN, WM, WN, BKB, CVMI_BOOLNAME(PLAIN), KS);
   hipLaunchKernelGGL((igemm_kernel<T, TO, BM, BN, WM, WN, BKB, PLAIN, KS>), dim3((unsigned)blocks), dim3(WM * WN * 64 * KS), lds, stream, a);
   CVMI_LAUNCH_CHECK();
   return 0;

@@ -12,6 +12,22 @@ void cvmi_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
+static thread_local char g_kernel[160] = "";
+
+void cvmi_note_kernel(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_kernel, sizeof(g_kernel), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" const char* cvmi_last_kernel(void) {      // read-and-clear, so a call that dispatches no tagged kernel reads as ""
+  static thread_local char out[sizeof(g_kernel)];
+  memcpy(out, g_kernel, sizeof(out));
+  g_kernel[0] = 0;
+  return out;
+}
+
 extern "C" int cvmi_version(void) { return CVMI_VERSION; }
 extern "C" const char* cvmi_last_error(void) { return g_err; }
 

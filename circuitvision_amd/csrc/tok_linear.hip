@@ -420,6 +420,7 @@ int launch_tl1(const void* in, int in_ld, const float* gamma, const float* beta,
   using Cfg = TlCfg<K>;
   static hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&tok_linear_kernel<K, LN, RES, GELU, TSTORE, STAMP, PP, POOL>), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
   CVMI_HIP(attr);
+  cvmi_note_kernel("tok_linear_kernel<%d, %d, %s, %s, %s, %s, %s, %s>", K, LN, CVMI_BOOLNAME(RES), CVMI_BOOLNAME(GELU), CVMI_BOOLNAME(TSTORE), CVMI_BOOLNAME(STAMP), CVMI_BOOLNAME(PP), CVMI_BOOLNAME(POOL));
   hipLaunchKernelGGL((tok_linear_kernel<K, LN, RES, GELU, TSTORE, STAMP, PP, POOL>), dim3((unsigned)(rows / 256)), dim3(TL_NW * 64), Cfg::LDS, s, in, in_ld, gamma, beta, eps,
                      (const char*)wp, out, out_ld, rows, N, ex);
   CVMI_LAUNCH_CHECK();

@@ -102,6 +102,23 @@ class YOLO:
         self._lock = threading.Lock()      # one analyzer is shared by all Streamlit sessions (app.py:134)
 
     @classmethod
+    def from_weights(cls, weights, names, dtype="f16", device="cuda", imgsz=640, keep_scores=False):
+        """A detector over already packed `Yolo11Weights` (e.g. the replica a rank received by broadcast: no checkpoint read, no packing)."""
+        require_gpu()
+        self = cls.__new__(cls)
+        self.keep_scores = keep_scores
+        self.dtype = {"f16": F16, "fp16": F16, "f32": F32, "fp32": F32}[dtype] if isinstance(dtype, str) else dtype
+        self.device = device
+        self.imgsz = cls._check_imgsz(imgsz)
+        self.params, self.weights = getattr(weights, "params", None), weights
+        self.names = {int(k): v for k, v in names.items()}
+        self.model = SimpleNamespace(names=self.names, nc=len(self.names), scale=weights.scale, stride=32)
+        self.stream = torch.cuda.Stream(device=device)
+        self._plans = {}
+        self._lock = threading.Lock()
+        return self
+
+    @classmethod
     def _check_imgsz(cls, imgsz):
         imgsz = int(max(imgsz)) if isinstance(imgsz, (list, tuple)) else int(imgsz)
         if imgsz < 32:

@@ -192,9 +192,12 @@ class Plan:
             self.capture()
         _lib.check(_lib.load().cvmi_graph_launch(self.graph, self.sptr), "graph_launch")
 
-    def timed_eager(self):
+    def timed_eager(self, with_kernels=False):
         """One eager pass with an event pair around every launch (on the plan's stream).
-        Returns [(label, kind, ms, bytes, flops)]."""
+        Returns [(label, kind, ms, bytes, flops)]; with_kernels=True appends the kernel the library dispatched to
+        (cvmi_last_kernel: "" for launches whose dispatcher does not tag itself)."""
+        lib = _lib.load()
+        lib.cvmi_last_kernel()
         evs = []
         for label, kind, thunk, b, f in self.ops:
             e0 = torch.cuda.Event(enable_timing=True)
@@ -202,9 +205,11 @@ class Plan:
             e0.record(self.stream)
             thunk()
             e1.record(self.stream)
-            evs.append((label, kind, e0, e1, b, f))
+            evs.append((label, kind, e0, e1, b, f, lib.cvmi_last_kernel().decode()))
         self.stream.synchronize()
-        return [(l, k, e0.elapsed_time(e1), b, f) for l, k, e0, e1, b, f in evs]
+        if with_kernels:
+            return [(l, k, e0.elapsed_time(e1), b, f, kn) for l, k, e0, e1, b, f, kn in evs]
+        return [(l, k, e0.elapsed_time(e1), b, f) for l, k, e0, e1, b, f, _ in evs]
 
     def __del__(self):
         try:

@@ -18,6 +18,9 @@ Images are independent through both models, so a batch shards contiguously over 
 (`shard_range`); every rank returns the results of its own images, `gather_results` collects them on one rank when a single
 caller needs them.  Results do not depend on how the batch is split (tests: sharded == unsharded, bit for bit).
 """
+import time
+from collections import defaultdict
+
 import numpy as np
 import torch
 
@@ -42,11 +45,19 @@ class CircuitPipeline:
     """detector: `circuitvision_amd.detector.YOLO`-like (`predict(list of uint8 HxWx3) -> [Results]`);
     segmenter: `SAM2Model`-like (`infer_masks(x, boxes=None)`, `.image_size`); transforms: `SAM2Transforms`-like."""
 
-    def __init__(self, detector, segmenter, transforms, stage2_iou=0.6, max_prompts=32, crop_fn=None, swap_channels=True):
+    def __init__(self, detector, segmenter, transforms, stage2_iou=0.6, max_prompts=32, crop_fn=None, swap_channels=True, seg_batch=16):
         """swap_channels: segment_with_sam2 applies cv2.COLOR_BGR2RGB to whatever it is given (circuit_analyzer.py:343), and the
-        pipeline hands it RGB (analysis_pipeline.py:199-203) -- i.e. the reference's segmenter sees the channels reversed."""
+        pipeline hands it RGB (analysis_pipeline.py:199-203) -- i.e. the reference's segmenter sees the channels reversed.
+        seg_batch: images per segmenter launch (BASELINE configs[2] runs SAM 2.1-L at 16)."""
         self.det, self.seg, self.tr = detector, segmenter, transforms
         self.stage2_iou, self.max_prompts, self.crop_fn, self.swap = stage2_iou, max_prompts, crop_fn, swap_channels
+        self.seg_batch = max(1, int(seg_batch))
+        self.timings = defaultdict(float)          # wall seconds per phase, accumulated over calls (bench.py prints them per step)
+
+    def _tick(self, name, t0):
+        t1 = time.perf_counter()
+        self.timings[name] += t1 - t0
+        return t1
 
     # ---- stage A: analysis_pipeline.py:97-115
     def detect(self, images):
@@ -56,31 +67,45 @@ class CircuitPipeline:
         for i, im in enumerate(images):
             groups.setdefault(im.shape[:2], []).append(i)
         for idxs in groups.values():                                   # one detector batch per image size
+            t = time.perf_counter()
             res = self.det.predict([images[i] for i in idxs], verbose=False)
+            t = self._tick("detect.predict (H2D + letterbox + YOLO11 + NMS + D2H)", t)
             for i, r in zip(idxs, res):
                 out[i] = non_max_suppression_by_confidence(results_to_bboxes(r), iou_threshold=self.stage2_iou)
+            self._tick("detect.glue (dicts + round + uid + stage-2 NMS)", t)
         return out
 
     # ---- stage B: analysis_pipeline.py:168-225
     def segment(self, images, bboxes, prompts="learned"):
-        R = self.seg.image_size
+        if prompts not in ("learned", "boxes"):
+            raise ValueError("prompts must be 'learned' or 'boxes'")
         crops, boxes_adj = [], []
         for im, bb in zip(images, bboxes):
             if self.crop_fn is not None:
                 im, bb, _ = self.crop_fn(im, [dict(b) for b in bb])
             crops.append(im)
             boxes_adj.append(bb)
+        out = []
+        for c0 in range(0, len(crops), self.seg_batch):                   # one segmenter launch per seg_batch images
+            sl = slice(c0, c0 + self.seg_batch)
+            out += self._segment_chunk(crops[sl], boxes_adj[sl], prompts)
+        return out
+
+    def _segment_chunk(self, crops, boxes_adj, prompts):
+        R = self.seg.image_size
+        t = time.perf_counter()
         seg_in = [np.ascontiguousarray(im[..., ::-1]) if self.swap else im for im in crops]
         x = self.tr.forward_batch(seg_in)
+        t = self._tick("segment.transform (channel swap + H2D + resize / normalise)", t)
         out = []
         if prompts == "learned":
             hi, lo, iou = self.seg.infer_masks(x)
+            t = self._tick("segment.infer_masks (SAM 2.1 forward)", t)
             for b, im in enumerate(crops):
                 u8, ext = self.tr.postprocess_to_mask(hi[b:b + 1], im.shape[:2])
                 out.append({"image": im, "bboxes": boxes_adj[b], "mask": u8[0, 0], "extent": ext[0], "iou": iou[b]})
+            self._tick("segment.postprocess (resize + threshold + u8 + extent + D2H of extents)", t)
             return out
-        if prompts != "boxes":
-            raise ValueError("prompts must be 'learned' or 'boxes'")
         P = self.max_prompts
         bx = torch.zeros(len(crops), P, 4)
         counts = []
@@ -88,13 +113,14 @@ class CircuitPipeline:
             bb = bb[:P]                                                  # already sorted by confidence (stage-2 NMS order)
             counts.append(len(bb))
             if bb:
-                t = torch.tensor([[d["xmin"], d["ymin"], d["xmax"], d["ymax"]] for d in bb], dtype=torch.float32)
-                t = self.tr.transform_boxes(t, normalize=True, orig_hw=im.shape[:2]).reshape(-1, 4)
-                bx[b, :len(bb)] = t
-                bx[b, len(bb):] = t[0]                                   # unused prompt slots repeat the first box (results dropped)
+                t_ = torch.tensor([[d["xmin"], d["ymin"], d["xmax"], d["ymax"]] for d in bb], dtype=torch.float32)
+                t_ = self.tr.transform_boxes(t_, normalize=True, orig_hw=im.shape[:2]).reshape(-1, 4)
+                bx[b, :len(bb)] = t_
+                bx[b, len(bb):] = t_[0]                                  # unused prompt slots repeat the first box (results dropped)
             else:
                 bx[b] = torch.tensor([0.0, 0.0, R, R])
         _, lo, iou = self.seg.infer_masks(x, bx, return_high_res=False)
+        t = self._tick("segment.infer_masks (SAM 2.1 forward)", t)
         for b, im in enumerate(crops):
             k = counts[b]
             if k:
@@ -103,6 +129,7 @@ class CircuitPipeline:
             else:
                 masks, ext = torch.zeros(0, *im.shape[:2], dtype=torch.uint8, device=lo.device), []
             out.append({"image": im, "bboxes": boxes_adj[b][:P], "masks": masks, "extents": ext, "iou": iou[b, :k]})
+        self._tick("segment.postprocess (resize + threshold + u8 + extent + D2H of extents)", t)
         return out
 
     def run_batch(self, images, prompts="learned", rank=0, world=1):

@@ -95,6 +95,23 @@ class SamSyntheticParams:
         return dict(self.sd)
 
 
+class SamBlankParams:
+    """A rank that holds NO checkpoint: every tensor reads as zeros, so `Sam2Weights` allocates the packed buffers at their final shapes
+    (no random generation, no file) and `distributed.broadcast_weights` fills them from the rank that read the checkpoint."""
+
+    def weight(self, mod, shape):
+        return torch.zeros(shape)
+
+    def bias(self, mod, n):
+        return torch.zeros(n)
+
+    def tensor(self, name, shape, kind="w"):
+        return torch.zeros(shape)
+
+    def state_dict(self):
+        return {}
+
+
 class SamStateDictParams:
     """A real checkpoint: flat state_dict (optionally under 'state_dict'), PEFT key names with the
     `sam2_model.base_model.model.` prefix (sam2_infer.py:396), wrapper parameters at the top level."""
@@ -375,6 +392,9 @@ class Sam2Weights:
             self._linear(f"iou.{j}", f"{D}.iou_prediction_head.layers.{j}", co, ci)
         for j, (co, ci) in enumerate(((256, 256), (256, 256), (1, 256))):     # pred_obj_score_head: loaded (strictness), unused by the wrapper
             self.p.weight(f"{D}.pred_obj_score_head.layers.{j}", (co, ci)); self.p.bias(f"{D}.pred_obj_score_head.layers.{j}", co)
+        # host-side intermediates of the constant folding above: no forward pass reads them, and a rank that receives its weights by
+        # broadcast never has them (tests/test_distributed_cpu.py checks that everything left on this object is in the broadcast)
+        del self.key_pe, self.sparse, self._sa_w, self._x_w, self.tokens
 
     def _refinement(self):
         if not self.use_refinement:

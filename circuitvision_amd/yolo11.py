@@ -75,6 +75,16 @@ class SyntheticParams:
         return dict(self.sd)
 
 
+class BlankParams:
+    """A rank that holds NO checkpoint: every tensor reads as zeros (BatchNorm variance one), so the packed buffers get their final
+    shapes and the real values arrive by `distributed.broadcast_packed` from the rank that read the checkpoint."""
+
+    def get(self, name, shape):
+        if name.endswith("num_batches_tracked"):
+            return torch.zeros(shape, dtype=torch.long)
+        return torch.ones(shape) if name.endswith("running_var") else torch.zeros(shape)
+
+
 class StateDictParams:
     def __init__(self, sd):
         self.sd = sd

@@ -41,6 +41,10 @@ enum { CVMI_ACT_NONE = 0, CVMI_ACT_SILU = 1, CVMI_ACT_RELU = 2, CVMI_ACT_GELU = 
 /* ---- library -------------------------------------------------------------------------------- */
 int cvmi_version(void);
 const char* cvmi_last_error(void);
+/* Diagnostic: the kernel (template instance) the calling thread's most recent cvmi_conv2d / cvmi_attention / cvmi_tok_linear* /
+ * cvmi_hiera_mlp* call dispatched to, as rocprofv3 names it up to the spelling of the 16-bit type (e.g. "gemm256x192_kernel<float>").  Read-and-clear: "" when no such
+ * call happened since the last read. */
+const char* cvmi_last_kernel(void);
 /* fills: [0] CU count, [1] wave size, [2] LDS bytes per CU-workgroup, [3] gfx arch number (950) */
 int cvmi_device_info(int device, int* out4);
 /* ABI guard for the descriptor structs below: sizeof(struct) as THIS library was compiled, for kind = CVMI_DESC_CONV / _C3K2 / _DWPW /

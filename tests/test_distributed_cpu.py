@@ -29,12 +29,23 @@ def _worker(rank, world, port, out):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from circuitvision_amd._lib import F32
     from circuitvision_amd.distributed import broadcast_packed, gather_detections, packed_tensors
-    from circuitvision_amd.yolo11 import SyntheticParams, Yolo11Weights
-    # every rank starts from DIFFERENT weights; after the broadcast all must equal rank 0's
-    wt = Yolo11Weights("n", 62, SyntheticParams(seed=100 + rank, nc=62), F32, device="cpu")
+    from circuitvision_amd.yolo11 import BlankParams, SyntheticParams, Yolo11Weights
+    # rank 0 reads the "checkpoint"; rank 1 holds NONE (blank buffers of the right shapes): after the broadcast all must equal rank 0's
+    wt = Yolo11Weights("n", 62, SyntheticParams(seed=100, nc=62) if rank == 0 else BlankParams(), F32, device="cpu")
     ref = Yolo11Weights("n", 62, SyntheticParams(seed=100, nc=62), F32, device="cpu")
     sent = broadcast_packed(wt.packed, src=0, bucket_bytes=1 << 20)
     same = all(torch.equal(a, b) for a, b in zip(packed_tensors(wt.packed), packed_tensors(ref.packed)))
+    # the SAM 2 side: a mini model packed from blank parameters on rank 1 receives everything a forward pass reads
+    from circuitvision_amd.distributed import broadcast_weights, weight_tensors
+    from circuitvision_amd.sam2 import Sam2Weights, SamBlankParams, SamSyntheticParams
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_oracle_sam2_cpu import MINI, mini_targets
+    sp = SamSyntheticParams(seed=3, lora_targets=mini_targets(), std=0.05)
+    sw = Sam2Weights(sp if rank == 0 else SamBlankParams(), MINI, 256, F32, device="cpu")
+    sref = Sam2Weights(sp, MINI, 256, F32, device="cpu")
+    broadcast_weights(sw, src=0, bucket_bytes=1 << 20)
+    a_, b_ = weight_tensors(sw), weight_tensors(sref)
+    same = same and len(a_) == len(b_) > 10 and all(torch.equal(x, y) for x, y in zip(a_, b_))
     det = torch.full((3, 4, 6), float(rank))
     cnt = torch.full((3,), rank, dtype=torch.int32)
     dets, cnts = gather_detections(det, cnt, dst=0)
@@ -44,6 +55,43 @@ def _worker(rank, world, port, out):
     out[rank] = (same, sent > 0, ok_gather)
     dist.barrier()
     dist.destroy_process_group()
+
+
+def _all_tensors(obj, seen=None, depth=0):
+    """Every torch tensor reachable from a prepared-weights object (attributes, dict / list / tuple members), by storage pointer."""
+    seen = {} if seen is None else seen
+    if torch.is_tensor(obj):
+        seen[obj.data_ptr()] = obj
+    elif isinstance(obj, dict):
+        for v in obj.values():
+            _all_tensors(v, seen, depth + 1)
+    elif isinstance(obj, (list, tuple)):
+        for v in obj:
+            _all_tensors(v, seen, depth + 1)
+    elif hasattr(obj, "__dict__") and depth < 4 and type(obj).__module__.startswith("circuitvision_amd"):
+        for k, v in vars(obj).items():
+            if k not in ("p", "params"):                              # the parameter SOURCE (checkpoint side), not the prepared model
+                _all_tensors(v, seen, depth + 1)
+    return seen
+
+
+def test_broadcast_covers_every_tensor_of_the_prepared_models():
+    """a rank without a checkpoint only works if the one-time broadcast carries EVERY device tensor a forward pass
+    reads.  Everything reachable from Yolo11Weights / Sam2Weights must be in the broadcast list."""
+    from circuitvision_amd._lib import F32
+    from circuitvision_amd.distributed import packed_tensors, weight_tensors
+    from circuitvision_amd.sam2 import Sam2Weights, SamSyntheticParams
+    from circuitvision_amd.yolo11 import SyntheticParams, Yolo11Weights
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_oracle_sam2_cpu import MINI, mini_targets
+    yw = Yolo11Weights("n", 62, SyntheticParams(seed=1, nc=62), F32, device="cpu")
+    sent = {t.data_ptr() for t in packed_tensors(yw.packed)}
+    missing = [tuple(t.shape) for p, t in _all_tensors(yw).items() if p not in sent and t.numel() > 0]
+    assert not missing, f"YOLO11 tensors outside the broadcast: {missing}"
+    sw = Sam2Weights(SamSyntheticParams(seed=3, lora_targets=mini_targets(), std=0.05), MINI, 256, F32, device="cpu")
+    sent = {t.data_ptr() for t in weight_tensors(sw)}
+    missing = [tuple(t.shape) for p, t in _all_tensors(sw).items() if p not in sent and t.numel() > 0]
+    assert not missing, f"SAM 2 tensors outside the broadcast: {missing}"
 
 
 def test_weight_broadcast_and_gather_gloo_world2():

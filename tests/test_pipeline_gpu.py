@@ -81,10 +81,12 @@ def test_pipeline_f32_matches_oracle_chain_and_sharding_is_exact(tmp_path):
         assert torch.equal(a["masks"], b["masks"]) and torch.equal(a["iou"], b["iou"]), i
 
 
-def test_pipeline_config3_shapes_yolo11l_sam2l_f16(tmp_path):
-    """BASELINE configs[3] at B = 2: YOLO11-l (fp16) -> SAM 2.1 Hiera-L (fp16 operands) on 640 x 640 circuit images.
-    Detector: >= 0.8 of the fp32 oracle's boxes found again (same class, IoU >= 0.85) and vice versa, reported; segmenter: binary masks IoU >= 0.99 vs the oracle;
-    box mode (configs[4] semantics, up to 32 prompts per image): mask IoU >= 0.98 on the SAME boxes."""
+@pytest.mark.parametrize("sam_dtype,iou_learned,iou_boxes", [("f16", 0.99, 0.98), ("bf16", 0.985, 0.97)])
+def test_pipeline_config3_shapes_yolo11l_sam2l(tmp_path, sam_dtype, iou_learned, iou_boxes):
+    """BASELINE configs[3] at B = 2: YOLO11-l (fp16) -> SAM 2.1 Hiera-L (fp16 operands; bf16 = configs[4]'s operand type) on 640 x 640 circuit
+    images.  Detector: >= 0.8 of the fp32 oracle's boxes found again (same class, IoU >= 0.85) and vice versa, reported; segmenter: binary
+    masks IoU >= 0.99 (bf16: 0.985) vs the oracle; box mode (configs[4] semantics, up to 32 prompts per image): mask IoU >= 0.98 (bf16: 0.97)
+    on the SAME boxes; the measured IoUs are printed."""
     images = [circuit_image(640, 640, seed=800 + i) for i in range(2)]
     x = torch.cat([torch.from_numpy(opre.yolo_preprocess(im)) for im in images])
     yp = calibrated_yolo_params("l", 62, 6, x)
@@ -92,7 +94,7 @@ def test_pipeline_config3_shapes_yolo11l_sam2l_f16(tmp_path):
     yo = YOLO11("l", 62).eval()
     yo.load_state_dict(yp.state_dict(), strict=True)
     sp = SamSyntheticParams(seed=5, lora_targets=LORA_TARGETS_REFERENCE, std=0.05)
-    seg = SAM2Model(HIERA_L, 1024, dtype="f16", use_refinement=True).load_params(sp)
+    seg = SAM2Model(HIERA_L, 1024, dtype=sam_dtype, use_refinement=True).load_params(sp)
     tr = SAM2Transforms(resolution=1024, mask_threshold=0, max_hole_area=0, max_sprinkle_area=0)
     so = osam.SAM2ImageWrapper(osam.SAM2Core(osam.HIERA_L, lora=True)).eval()
     so.load_state_dict({("sam2_model." + k if not (k.startswith("dense_") or k.startswith("sparse_") or k.startswith("refinement_")) else k): v
@@ -110,7 +112,8 @@ def test_pipeline_config3_shapes_yolo11l_sam2l_f16(tmp_path):
             rhi, _, _ = so(xs)
             rmask = osam.postprocess_masks(rhi, im.shape[:2]).squeeze() > 0.0
         g = r["mask"].cpu() > 0
-        assert (g & rmask).sum().item() / max(1, (g | rmask).sum().item()) >= 0.99, i
+        iou_l = (g & rmask).sum().item() / max(1, (g | rmask).sum().item())
+        assert iou_l >= iou_learned, (i, iou_l)
         k = len(rb["bboxes"])
         bx = torch.tensor([[b["xmin"], b["ymin"], b["xmax"], b["ymax"]] for b in rb["bboxes"]], dtype=torch.float32)
         bx = tr.transform_boxes(bx, normalize=True, orig_hw=im.shape[:2]).reshape(1, -1, 4)
@@ -118,6 +121,8 @@ def test_pipeline_config3_shapes_yolo11l_sam2l_f16(tmp_path):
             _, rlo, _ = osam.predict_boxes(so, xs, bx)
             rm = osam.postprocess_masks(rlo[0].unsqueeze(1), im.shape[:2]).squeeze(1) > 0.0
         gm = rb["masks"].cpu() > 0
-        assert k > 0 and (gm & rm).sum().item() / max(1, (gm | rm).sum().item()) >= 0.98, i
+        iou_b = (gm & rm).sum().item() / max(1, (gm | rm).sum().item())
+        print(f"configs[3] {sam_dtype} image {i}: learned-prompt mask IoU {iou_l:.4f}, {k} box prompts mask IoU {iou_b:.4f}")
+        assert k > 0 and iou_b >= iou_boxes, (i, iou_b)
     print("configs[3] B=2 detector, fp16 vs fp32 oracle: (recall of oracle boxes, precision, n, n_oracle) per image =", rates)
     assert all(rc >= 0.8 and pr >= 0.8 for rc, pr, _, _ in rates), rates          # same class, IoU >= 0.85

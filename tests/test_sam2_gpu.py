@@ -633,6 +633,23 @@ def test_sam2_box_prompts_hiera_l_f16_match_oracle():
     torch.testing.assert_close(sp.iou.view(B, P).cpu(), iou, rtol=0, atol=2e-2)
 
 
+def test_sam2_box_prompts_hiera_l_bf16_match_oracle():
+    """BASELINE configs[4] as named -- SAM 2.1 Hiera-L 1024^2, 32 box prompts per image, **bf16** operands -- at B = 1: the bf16 build of the
+    box decoder (layer-0 sharing through the attention batch divisors, cvmi_repeat_images, res_rep broadcast residuals, prompt tokens) vs
+    the fp32 oracle.  Tolerance = the bf16 wrapper test's: mask logits within 0.25 std (max) / 0.05 std (rms), binary-mask IoU over the
+    prompt set >= 0.985 (8 mantissa bits: measured value printed), predicted IoU within 5e-2."""
+    from circuitvision_amd.sam2 import HIERA_L, LORA_TARGETS_REFERENCE
+    B, P = 1, 32
+    sp, (hi, lo, iou) = _run_boxes(HIERA_L, LORA_TARGETS_REFERENCE, _hiera_l_oracle, 1024, BF16, B, P)
+    got = sp.low_res.view(B, P, 256, 256).cpu()
+    _assert_logits("Hiera-L bf16 32 boxes low-res logits", got, lo, 0.25, 0.05)
+    a, b = sp.high_res.view(B, P, 1024, 1024).cpu() > 0, hi > 0
+    inter_, union = (a & b).sum().item(), (a | b).sum().item()
+    print(f"Hiera-L bf16 32 boxes: binary-mask IoU vs the fp32 oracle {inter_ / max(1, union):.4f}")
+    assert union == 0 or inter_ / union >= 0.985
+    torch.testing.assert_close(sp.iou.view(B, P).cpu(), iou, rtol=0, atol=5e-2)
+
+
 def test_wrapper_graph_replay_with_new_images():
     """The captured graph replayed on different images: every per-call state (stability counters) is reset inside the graph."""
     from circuitvision_amd.sam2 import SamSyntheticParams

@@ -3,7 +3,11 @@
 table for profiles/ (kernel, calls, total ms, avg us, %)."""
 import csv
 import glob
+import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from kname import canon
 
 
 def main(src, out, note=""):
@@ -14,7 +18,7 @@ def main(src, out, note=""):
         f.write(f"# rocprofv3 --kernel-trace --stats summary\n\n{note}\n\n")
         f.write("| kernel | calls | total ms | avg us | % |\n|---|---:|---:|---:|---:|\n")
         for r in rows:
-            name = r["Name"].replace("|", "/")
+            name = canon(r["Name"]).replace("|", "/")          # demangled, parameter list cut: the spelling cvmi_last_kernel() / bench.py use
             if len(name) > 110:
                 name = name[:107] + "..."
             f.write(f"| `{name}` | {r['Calls']} | {int(r['TotalDurationNs']) / 1e6:.3f} | {float(r['AverageNs']) / 1e3:.2f} | {float(r['Percentage']):.2f} |\n")
