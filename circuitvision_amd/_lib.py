@@ -93,6 +93,7 @@ SIGNATURES = {
     "cvmi_yolo_nms_workspace": (C.c_size_t, [_i, _i]),
     "cvmi_yolo_nms": (_i, [_vp, _i, _i, _i, _f, _f, _i, _f, _vp, _vp, _vp, _vp, _vp]),
     "cvmi_letterbox": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "cvmi_letterbox_batch": (_i, [_vp, _i, _i, _i, _vp, C.c_longlong, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "cvmi_nchw_to_nhwc": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "cvmi_nhwc_to_nchw_f32": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _i, _vp]),
     "cvmi_layernorm": (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _i, C.c_longlong, _i, _f, _i, _i, _i, _i, _i, _vp]),
@@ -120,6 +121,7 @@ SIGNATURES = {
     "cvmi_mask_postprocess": (_i, [_vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp]),
     "cvmi_upsample_refine": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _vp, C.POINTER(_i), _i, _i, _vp]),
     "cvmi_sam2_transform": (_i, [_vp, _i, _i, _vp, _i, _i, _vp]),
+    "cvmi_sam2_transform_batch": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _i, _vp]),
 }
 
 _lib = None

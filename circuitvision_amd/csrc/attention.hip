@@ -27,6 +27,7 @@ struct AttnArgs {
   int q_bdiv, kv_bdiv;   // batch sharing (no window): q rows of batch entry b come from entry b / q_bdiv, k / v rows from b / kv_bdiv
   int qtiles;      // ceil(Nq / 32)
   int items;       // B * heads * qtiles
+  int xcd;         // 1: XCD-aware workgroup order (xcd_order below); 0: natural order (CVMI_ATTN_XCD=0, A/B runs only)
   FastDiv div_win; // window mode: key -> (row, column) inside the window without a hardware division
 };
 
@@ -36,6 +37,18 @@ struct AttnArgs {
 // see into an asm statement, so an asm v_max3 reading an MFMA result gets no XDL-write -> VALU-read wait states and returns stale
 // accumulators now and then (measured: replays of the same graph differed in the last bits -- tests/*_replay_properties).
 __device__ __forceinline__ float max3f(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
+
+// XCD-aware workgroup order (speed only, bijective for any grid size).  Workgroups are dealt round-robin over the 8 XCDs, each with a
+// private L2.  With the natural order the 8 heads of one window -- whose 144-byte K / V rows share 128-byte lines of the interleaved
+// [token][3 x heads x 72] qkv buffer -- land on 8 different XCDs and every line is fetched twice (PMC, r03: 413 MB read by the 16 x 16
+// window launch against 226 MB of q + k + v), and the query groups that stream the SAME K / V of a global-attention head re-fetch it
+// through 8 L2s.  Here XCD x owns a contiguous run of logical workgroups, walked in dispatch order: the heads of a window and the query
+// groups of a head are neighbours in space (one L2) and in time.
+__device__ __forceinline__ int xcd_order(int wg, int nwg, int on = 1) {
+  if (!on) return wg;
+  const int q = nwg >> 3, r = nwg & 7, xcd = wg & 7, j = wg >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+}
 
 // element offset of token t of batch entry b (window mode: b enumerates windows of an image grid)
 __device__ __forceinline__ long long tok_off(int b, int t, long long sb, long long st, int win, int gh, int gw) {
@@ -350,8 +363,9 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn64_kernel(const 
   const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
   const int lr = lane & 31, lh = lane >> 5;
   const int qgroups = (p.qtiles + NW - 1) / NW;
-  const int item = blockIdx.x / qgroups;                 // (b, h) of the workgroup
-  const int qt = (blockIdx.x - item * qgroups) * NW + wv;
+  const int wgx = xcd_order((int)blockIdx.x, (int)gridDim.x, p.xcd);
+  const int item = wgx / qgroups;                        // (b, h) of the workgroup
+  const int qt = (wgx - item * qgroups) * NW + wv;
   const bool live = qt < p.qtiles;
   const int b = item / p.heads, h = item - b * p.heads;
   const int qwin = p.q_pool ? p.win / 2 : p.win;
@@ -594,6 +608,7 @@ int launch_attn64(const AttnArgs& a, hipStream_t stream) {
 // Q-fragment loads.  Every barrier that publishes DMA'd data is therefore preceded by this explicit wait.
 __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
+
 // ---- head_dim 72 kernels below: which key a score row stands for --------------------------------------------------------
 // K and V live in LDS as unpadded 144-byte rows (what the LDS-DMA writes).  The V^T operand is gathered by ds_read_b64_tr_b16: a
 // 32-lane half reads FOUR key rows x 64 bytes, and with consecutive rows at a 36-dword stride two of the four fall on the same
@@ -624,8 +639,9 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_res256_kernel(const AttnArgs 
   const int tid = threadIdx.x, wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int lr = lane & 31, lh = lane >> 5;
   const int qgroups = (p.qtiles + NW - 1) / NW;
-  const int item = blockIdx.x / qgroups;
-  const int qt = (blockIdx.x - item * qgroups) * NW + wv;
+  const int wgx = xcd_order((int)blockIdx.x, (int)gridDim.x, p.xcd);
+  const int item = wgx / qgroups;
+  const int qt = (wgx - item * qgroups) * NW + wv;
   const bool live = qt < p.qtiles;
   const int b = item / p.heads, h = item - b * p.heads;
   const int qwin = p.q_pool ? p.win / 2 : p.win;
@@ -799,7 +815,7 @@ __global__ __launch_bounds__(QT * 128, 4) void attn_res64_kernel(const AttnArgs 
   char* const Vs = Ks + NK * ROW;
   const int lr = lane & 31, lh = lane >> 5;
   const int nitems = p.B * p.heads;
-  const int item_raw = blockIdx.x * 2 + sub;
+  const int item_raw = xcd_order((int)blockIdx.x, (int)gridDim.x, p.xcd) * 2 + sub;
   const int item = item_raw < nitems ? item_raw : nitems - 1;
   const int qt = wv;
   const bool live = item_raw < nitems && qt < p.qtiles;
@@ -983,8 +999,9 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_dma72_kernel(const AttnArgs p
   const int tid = threadIdx.x, wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int lr = lane & 31, lh = lane >> 5;
   const int qgroups = (p.qtiles + NW - 1) / NW;
-  const int item = blockIdx.x / qgroups;
-  const int qt = (blockIdx.x - item * qgroups) * NW + wv;
+  const int wgx = xcd_order((int)blockIdx.x, (int)gridDim.x, p.xcd);
+  const int item = wgx / qgroups;
+  const int qt = (wgx - item * qgroups) * NW + wv;
   const bool live = qt < p.qtiles;
   const int b = item / p.heads, h = item - b * p.heads;
   const int qwin = p.q_pool ? p.win / 2 : p.win;
@@ -1208,7 +1225,7 @@ __global__ __launch_bounds__(128) void attn_win16_kernel(const AttnArgs p) {
   char* const Kl = lds + wv * 2 * IPW * ITEM_B;
   char* const Vl = Kl + IPW * ITEM_B;
   const int nitems = p.B * p.heads;
-  const int item0 = (blockIdx.x * 2 + wv) * IPW;                   // first item of this wave
+  const int item0 = (xcd_order((int)blockIdx.x, (int)gridDim.x, p.xcd) * 2 + wv) * IPW;   // first item of this wave
   // ---- per-lane item for the compute phase: lane = ti * NQ + tq, ti < IPW
   const int ti = lane / NQ, tq = lane - ti * NQ;
   const bool active = ti < IPW && item0 + ti < nitems;
@@ -1456,6 +1473,8 @@ extern "C" int CVMI_ENTRY(cvmi_attention)(const cvmi_attn_desc* d, cvmi_stream_t
   a.qtiles = (d->Nq + 31) / 32;
   a.div_win.init(d->win > 0 ? (unsigned)d->win : 1u);
   a.items = d->B * d->heads * a.qtiles;
+  static const int use_xcd = getenv("CVMI_ATTN_XCD") ? atoi(getenv("CVMI_ATTN_XCD")) : 1;                 // A/B runs only
+  a.xcd = use_xcd;
   if (d->win > 0) {
     CVMI_CHECK(d->grid_h % d->win == 0 && d->grid_w % d->win == 0, "attention: grid %dx%d not divisible by window %d", d->grid_h, d->grid_w, d->win);
     CVMI_CHECK(d->Nk == d->win * d->win, "attention: window mode needs Nk == win^2");

@@ -503,7 +503,11 @@ __device__ __forceinline__ void aa_axis(int i, float scale, int in, int& xmin, i
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void sam2_transform_kernel(const uint8_t* __restrict__ src, int H, int W, T* __restrict__ dst, int R, float sy, float sx) {
+__global__ __launch_bounds__(256) void sam2_transform_kernel(const uint8_t* __restrict__ src, int H, int W, T* __restrict__ dst, int R, float sy, float sx,
+                                                            int swap_rb) {
+  src += (size_t)blockIdx.y * H * W * 3;                  // blockIdx.y = image of a batch of equally sized sources
+  dst += (size_t)blockIdx.y * R * R * 3;
+  const int c0 = swap_rb ? 2 : 0, c2 = swap_rb ? 0 : 2;   // swap_rb: output channel c reads source channel 2 - c (the caller's cv2.COLOR_BGR2RGB)
   const int total = R * R;
   for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
     const int oy = idx / R, ox = idx - oy * R;
@@ -517,7 +521,7 @@ __global__ __launch_bounds__(256) void sam2_transform_kernel(const uint8_t* __re
       const uint8_t* sp = src + ((size_t)(ymin + j) * W + xmin) * 3;
       for (int i = 0; i < xsize; ++i) {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) row[c] += wx[i] * ((float)sp[i * 3 + c] / 255.0f);
+        for (int c = 0; c < 3; ++c) row[c] += wx[i] * ((float)sp[i * 3 + (c == 0 ? c0 : c == 2 ? c2 : 1)] / 255.0f);
       }
 #pragma unroll
       for (int c = 0; c < 3; ++c) acc[c] += wy[j] * row[c];
@@ -808,20 +812,26 @@ extern "C" int cvmi_upsample_refine(const float* low, int N, int h, int w, float
 #endif
 
 #ifndef CVMI_OPERAND_BF16
-extern "C" int cvmi_sam2_transform_bf16(const uint8_t* src, int H, int W, void* dst, int R, int dst_dtype, cvmi_stream_t stream_);
+extern "C" int cvmi_sam2_transform_batch_bf16(const uint8_t* src, int B, int H, int W, void* dst, int R, int dst_dtype, int swap_rb, cvmi_stream_t stream_);
 #endif
-extern "C" int CVMI_ENTRY(cvmi_sam2_transform)(const uint8_t* src, int H, int W, void* dst, int R, int dst_dtype, cvmi_stream_t stream_) {
+extern "C" int CVMI_ENTRY(cvmi_sam2_transform_batch)(const uint8_t* src, int B, int H, int W, void* dst, int R, int dst_dtype, int swap_rb,
+                                                     cvmi_stream_t stream_) {
 #ifndef CVMI_OPERAND_BF16
-  if (dst_dtype == CVMI_BF16) return cvmi_sam2_transform_bf16(src, H, W, dst, R, dst_dtype, stream_);
+  if (dst_dtype == CVMI_BF16) return cvmi_sam2_transform_batch_bf16(src, B, H, W, dst, R, dst_dtype, swap_rb, stream_);
 #endif
-  CVMI_CHECK(src && dst && H > 0 && W > 0 && R > 0, "sam2_transform: bad arguments");
+  CVMI_CHECK(src && dst && B >= 1 && B <= 65535 && H > 0 && W > 0 && R > 0, "sam2_transform: bad arguments");
   CVMI_CHECK(dst_dtype == CVMI_T16 || dst_dtype == CVMI_F32, "sam2_transform: bad dtype");
   const float sy = (float)H / (float)R, sx = (float)W / (float)R;
   CVMI_CHECK(2.f * (sy > 1.f ? sy : 1.f) + 2.f <= AA_MAXTAPS && 2.f * (sx > 1.f ? sx : 1.f) + 2.f <= AA_MAXTAPS, "sam2_transform: down-scale factor too large");
   hipStream_t s = (hipStream_t)stream_;
-  const dim3 g(grid_for((long long)R * R)), b(256);
-  if (dst_dtype == CVMI_T16) hipLaunchKernelGGL(sam2_transform_kernel<f16>, g, b, 0, s, src, H, W, (f16*)dst, R, sy, sx);
-  else hipLaunchKernelGGL(sam2_transform_kernel<float>, g, b, 0, s, src, H, W, (float*)dst, R, sy, sx);
+  const dim3 g(grid_for((long long)R * R), B), b(256);
+  if (dst_dtype == CVMI_T16) hipLaunchKernelGGL(sam2_transform_kernel<f16>, g, b, 0, s, src, H, W, (f16*)dst, R, sy, sx, swap_rb ? 1 : 0);
+  else hipLaunchKernelGGL(sam2_transform_kernel<float>, g, b, 0, s, src, H, W, (float*)dst, R, sy, sx, swap_rb ? 1 : 0);
   CVMI_LAUNCH_CHECK();
   return 0;
 }
+#ifndef CVMI_OPERAND_BF16
+extern "C" int cvmi_sam2_transform(const uint8_t* src, int H, int W, void* dst, int R, int dst_dtype, cvmi_stream_t stream_) {
+  return cvmi_sam2_transform_batch(src, 1, H, W, dst, R, dst_dtype, 0, stream_);
+}
+#endif

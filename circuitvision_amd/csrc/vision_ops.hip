@@ -321,7 +321,9 @@ __device__ __forceinline__ void lb_axis(int d, int dst, int src, int& s0, int& s
 // stride-1 2x2 conv with 16-byte-aligned channel vectors (see Yolo11Weights.stem).
 template <typename T>
 __global__ __launch_bounds__(256) void letterbox_kernel(const uint8_t* __restrict__ src, int H, int W, T* __restrict__ dst, int out_h,
-                                                       int out_w, int new_h, int new_w, int top, int left, int s2d) {
+                                                       int out_w, int new_h, int new_w, int top, int left, int s2d, long long dst_image_stride) {
+  src += (size_t)blockIdx.y * H * W * 3;                  // blockIdx.y = image of a batch of equally sized sources
+  dst += (size_t)blockIdx.y * dst_image_stride;
   const int total = out_h * out_w;
   for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
     const int ox = idx % out_w, oy = idx / out_w;
@@ -478,17 +480,23 @@ extern "C" int cvmi_detect_decode(const void* const* box, const int* box_ld, con
 #ifndef CVMI_OPERAND_BF16
 extern "C" int cvmi_letterbox(const uint8_t* src, int H, int W, void* dst, int out_h, int out_w, int new_h, int new_w, int top, int left,
                               int dtype, int s2d, cvmi_stream_t stream_) {
+  return cvmi_letterbox_batch(src, 1, H, W, dst, 0, out_h, out_w, new_h, new_w, top, left, dtype, s2d, stream_);
+}
+
+extern "C" int cvmi_letterbox_batch(const uint8_t* src, int B, int H, int W, void* dst, long long dst_image_stride, int out_h, int out_w, int new_h,
+                                    int new_w, int top, int left, int dtype, int s2d, cvmi_stream_t stream_) {
   CVMI_CHECK(!s2d || (out_h % 2 == 0 && out_w % 2 == 0), "letterbox: space-to-depth output needs even out_h, out_w");
   CVMI_CHECK(src && dst, "letterbox: null pointer");
+  CVMI_CHECK(B >= 1 && B <= 65535 && (B == 1 || dst_image_stride >= (long long)out_h * out_w * (s2d ? 4 : 3)), "letterbox: bad batch / image stride");
   CVMI_CHECK(H > 0 && W > 0 && out_h > 0 && out_w > 0 && new_h > 0 && new_w > 0 && top >= 0 && left >= 0 && top + new_h <= out_h &&
                  left + new_w <= out_w, "letterbox: bad geometry");
   CVMI_CHECK(dtype == CVMI_F16 || dtype == CVMI_F32, "letterbox: bad dtype");
   hipStream_t stream = (hipStream_t)stream_;
   const long long total = (long long)out_h * out_w;
   if (dtype == CVMI_F16)
-    hipLaunchKernelGGL(letterbox_kernel<f16>, dim3(grid_for(total)), dim3(256), 0, stream, src, H, W, (f16*)dst, out_h, out_w, new_h, new_w, top, left, s2d);
+    hipLaunchKernelGGL(letterbox_kernel<f16>, dim3(grid_for(total), B), dim3(256), 0, stream, src, H, W, (f16*)dst, out_h, out_w, new_h, new_w, top, left, s2d, dst_image_stride);
   else
-    hipLaunchKernelGGL(letterbox_kernel<float>, dim3(grid_for(total)), dim3(256), 0, stream, src, H, W, (float*)dst, out_h, out_w, new_h, new_w, top, left, s2d);
+    hipLaunchKernelGGL(letterbox_kernel<float>, dim3(grid_for(total), B), dim3(256), 0, stream, src, H, W, (float*)dst, out_h, out_w, new_h, new_w, top, left, s2d, dst_image_stride);
   CVMI_LAUNCH_CHECK();
   return 0;
 }

@@ -37,7 +37,7 @@ def letterbox_geometry(h, w, new_shape=640, stride=32, auto=True):
 
 class Boxes:
     def __init__(self, det):
-        self.data = det                      # [n, 6] x1,y1,x2,y2,conf,cls (device tensor)
+        self.data = det                      # [n, 6] x1,y1,x2,y2,conf,cls (host tensor: one D2H copy per batch brought it over)
 
     xyxy = property(lambda s: s.data[:, :4])
     conf = property(lambda s: s.data[:, 4])
@@ -98,7 +98,7 @@ class YOLO:
         self.model = SimpleNamespace(names=names, nc=nc, scale=scale, stride=32)
         self.names = names
         self.stream = torch.cuda.Stream(device=device)
-        self._plans = {}
+        self._plans, self._staging = {}, {}
         self._lock = threading.Lock()      # one analyzer is shared by all Streamlit sessions (app.py:134)
 
     @classmethod
@@ -114,7 +114,7 @@ class YOLO:
         self.names = {int(k): v for k, v in names.items()}
         self.model = SimpleNamespace(names=self.names, nc=len(self.names), scale=weights.scale, stride=32)
         self.stream = torch.cuda.Stream(device=device)
-        self._plans = {}
+        self._plans, self._staging = {}, {}
         self._lock = threading.Lock()
         return self
 
@@ -138,9 +138,25 @@ class YOLO:
 
     # ---- reference entry point -----------------------------------------------------------------
     def predict(self, image, verbose=True, conf=0.25, iou=0.7, max_det=300, imgsz=None, **_):
-        """image: uint8 HxWx3 numpy array (or a list of same-shaped ones).  Returns [Results]."""
+        """image: uint8 HxWx3 numpy array (or a list of same-shaped ones).  Returns [Results] (host tensors: the reference reads them
+        through `.cpu().numpy().tolist()`, circuit_analyzer.py:270-273)."""
+        out = self.predict_async(image, conf=conf, iou=iou, max_det=max_det, imgsz=imgsz).result()
+        if verbose:
+            H, W = out[0].letterboxed_shape if out else (0, 0)
+            print(f"cvmi355 YOLO11{self.model.scale}: {H}x{W} {', '.join(str(len(r)) + ' boxes' for r in out)}")
+        return out
+
+    __call__ = predict
+
+    def predict_async(self, image, conf=0.25, iou=0.7, max_det=300, imgsz=None):
+        """Batch-shaped, stream-ordered form of `predict`: ONE pinned staging buffer and ONE H2D copy for the batch, ONE letterbox launch,
+        the captured graph, ONE D2H copy of (detections, anchor indices, counts) -- all enqueued on the detector's stream -- and nothing
+        waits.  Returns a handle; `.result()` waits for the copy and builds the `Results` on the host (scale_boxes + clip there: ultralytics'
+        own CPU arithmetic on <= 300 boxes).  The caller may do other work -- or enqueue the segmenter -- in between."""
         imgsz = self.imgsz if imgsz is None else self._check_imgsz(imgsz)
         images = image if isinstance(image, (list, tuple)) else [image]
+        if not images:
+            raise ValueError("predict needs at least one image")
         for im in images:
             if not (isinstance(im, np.ndarray) and im.ndim == 3 and im.shape[2] == 3 and im.dtype == np.uint8):
                 raise TypeError("predict expects uint8 HxWx3 numpy images")
@@ -150,29 +166,56 @@ class YOLO:
         nw, nh, top, bottom, left, right = letterbox_geometry(h0, w0, imgsz)
         H, W = nh + top + bottom, nw + left + right
         lib = _lib.load()
+        B = len(images)
         with self._lock, torch.cuda.device(self.device):
-            p = self.plan(len(images), H, W, conf, iou, max_det)
+            p = self.plan(B, H, W, conf, iou, max_det)
+            st = self._staging.get((B, h0, w0))
+            if st is None:                                              # pinned once per (batch, source size); reused by later calls
+                st = self._staging[(B, h0, w0)] = [torch.empty(B, h0, w0, 3, dtype=torch.uint8, pin_memory=True), None]
+            if st[1] is not None:
+                st[1].synchronize()                                     # the previous call's H2D copy has left this buffer
+            host = st[0].numpy()
+            for b, im in enumerate(images):
+                host[b] = im                                            # the one host pass over the pixels
+            det_h = torch.empty(B, p.max_det, 6, dtype=torch.float32, pin_memory=True)
+            idx_h = torch.empty(B, p.max_det, dtype=torch.int32, pin_memory=True)
+            cnt_h = torch.empty(B, dtype=torch.int32, pin_memory=True)
             sp = self.stream.cuda_stream
-            srcs = []
             with torch.cuda.stream(self.stream):
-                for b, im in enumerate(images):
-                    src = torch.from_numpy(np.ascontiguousarray(im)).to(self.device, non_blocking=False)
-                    srcs.append(src)
-                    dst = p.x_in.t[b]
-                    _lib.check(lib.cvmi_letterbox(src.data_ptr(), h0, w0, dst.data_ptr(), H, W, nh, nw, top, left, self.dtype, 1, sp), "letterbox")
+                src = st[0].to(self.device, non_blocking=True)
+                st[1] = torch.cuda.Event()
+                st[1].record(self.stream)
+                _lib.check(lib.cvmi_letterbox_batch(src.data_ptr(), B, h0, w0, p.x_in.t.data_ptr(), p.x_in.t[0].numel(), H, W, nh, nw, top, left,
+                                                    self.dtype, 1, sp), "letterbox")
                 p.plan.run()
-                self.stream.synchronize()
-                counts = p.det_count.cpu().tolist()
-                out = []
-                for b, n in enumerate(counts):
-                    det = p.det[b, :n].clone()
-                    det[:, :4] = scale_boxes((H, W), det[:, :4], (h0, w0))
-                    out.append(Results(det, self.names, (h0, w0), p.det_idx[b, :n].clone()))
-        if verbose:
-            print(f"cvmi355 YOLO11{self.model.scale}: {H}x{W} {', '.join(str(len(r)) + ' boxes' for r in out)}")
-        return out
+                det_h.copy_(p.det, non_blocking=True)
+                idx_h.copy_(p.det_idx, non_blocking=True)
+                cnt_h.copy_(p.det_count, non_blocking=True)
+                done = torch.cuda.Event()
+                done.record(self.stream)
+        return PendingDetections(done, det_h, idx_h, cnt_h, (H, W), (h0, w0), self.names, src)
 
-    __call__ = predict
+
+class PendingDetections:
+    """Detections in flight (YOLO.predict_async).  `.result()` -> [Results], one per image."""
+
+    def __init__(self, done, det, idx, cnt, lb_shape, orig_shape, names, keep):
+        self.done, self.det, self.idx, self.cnt, self.lb_shape, self.orig_shape, self.names, self._keep = done, det, idx, cnt, lb_shape, orig_shape, names, keep
+        self._out = None
+
+    def result(self):
+        if self._out is None:
+            self.done.synchronize()
+            self._keep = None
+            out = []
+            for b, n in enumerate(self.cnt.tolist()):
+                det = self.det[b, :n].clone()
+                det[:, :4] = scale_boxes(self.lb_shape, det[:, :4], self.orig_shape)
+                r = Results(det, self.names, self.orig_shape, self.idx[b, :n].clone())
+                r.letterboxed_shape = self.lb_shape
+                out.append(r)
+            self._out = out
+        return self._out
 
 
 def scale_boxes(img1_shape, boxes, img0_shape):

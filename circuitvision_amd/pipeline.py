@@ -91,11 +91,20 @@ class CircuitPipeline:
             out += self._segment_chunk(crops[sl], boxes_adj[sl], prompts)
         return out
 
+    def _product_objects(self):
+        """True when detector / segmenter / transforms are this package's own classes (the stream-ordered fast paths use their internals);
+        duck-typed stand-ins (tests, other back ends) take the generic path."""
+        from .detector import YOLO
+        from .sam2_infer import SAM2Model, SAM2Transforms
+        return isinstance(self.det, YOLO) and isinstance(self.seg, SAM2Model) and isinstance(self.tr, SAM2Transforms)
+
     def _segment_chunk(self, crops, boxes_adj, prompts):
         R = self.seg.image_size
         t = time.perf_counter()
-        seg_in = [np.ascontiguousarray(im[..., ::-1]) if self.swap else im for im in crops]
-        x = self.tr.forward_batch(seg_in)
+        if self._product_objects():
+            x = self.tr.forward_batch(crops, swap_rb=self.swap)           # the BGR2RGB of circuit_analyzer.py:343 as a channel index on the device
+        else:
+            x = self.tr.forward_batch([np.ascontiguousarray(im[..., ::-1]) if self.swap else im for im in crops])
         t = self._tick("segment.transform (channel swap + H2D + resize / normalise)", t)
         out = []
         if prompts == "learned":
@@ -139,9 +148,86 @@ class CircuitPipeline:
         mine = list(images[lo:hi])
         if not mine:
             return []
-        bboxes = self.detect(mine)
-        res = self.segment(mine, bboxes, prompts)
+        if prompts == "learned" and self.crop_fn is None and self._product_objects():
+            res = self._run_overlapped(mine)
+        else:
+            bboxes = self.detect(mine)
+            res = self.segment(mine, bboxes, prompts)
         return [(lo + i, r) for i, r in enumerate(res)]
+
+    # ---- learned prompts, no crop: the segmenter does not depend on the detector's boxes (analysis_pipeline.py:168-225 passes the
+    #      image, not the boxes, to segment_with_sam2), so the whole batch is ENQUEUED -- segmenter chunks on the segmenter's stream, the
+    #      detector on its own -- and the host-side glue (D2H lists, round(), uid strings, stage-2 NMS) runs while the GPU works.
+    def _run_overlapped(self, images):
+        t = time.perf_counter()
+        chunks = [images[c0:c0 + self.seg_batch] for c0 in range(0, len(images), self.seg_batch)]
+        pend = [self._enqueue_learned(chunks[0])]
+        t = self._tick("enqueue: segmenter chunk 0 (stage u8 + H2D + transform + SAM 2.1 graph + post-process launches)", t)
+        groups = {}
+        for i, im in enumerate(images):
+            groups.setdefault(im.shape[:2], []).append(i)
+        handles = [(idxs, self.det.predict_async([images[i] for i in idxs])) for idxs in groups.values()]
+        t = self._tick("enqueue: detector (stage u8 + H2D + letterbox + YOLO11 graph + NMS + D2H launches)", t)
+        pend += [self._enqueue_learned(ch) for ch in chunks[1:]]
+        t = self._tick("enqueue: segmenter chunks 1.. (same, while the GPU runs chunk 0)", t)
+        bboxes = [None] * len(images)
+        for idxs, h in handles:
+            res = h.result()
+            t = self._tick("wait: detector results on the host", t)
+            for i, r in zip(idxs, res):
+                bboxes[i] = non_max_suppression_by_confidence(results_to_bboxes(r), iou_threshold=self.stage2_iou)
+            t = self._tick("detect.glue (dicts + round + uid + stage-2 NMS), overlapped with the segmenter", t)
+        out, k = [], 0
+        for ch, pd in zip(chunks, pend):
+            u8s, exts, iou = pd()
+            for b, im in enumerate(ch):
+                out.append({"image": im, "bboxes": bboxes[k], "mask": u8s[b], "extent": exts[b], "iou": iou[b]})
+                k += 1
+        self._tick("wait: segmenter (GPU time not hidden behind host work) + extents to the host", t)
+        return out
+
+    def _enqueue_learned(self, imgs):
+        """transform -> SAM 2.1 (learned prompts) -> resize / threshold / u8 / extent for one chunk, enqueued on the segmenter's stream.
+        Returns a closure that waits for it: -> (u8 masks [H,W] per image, extent tuples, iou [B,1])."""
+        from . import _lib
+        seg, tr = self.seg, self.tr
+        lib = _lib.load()
+        B, R = len(imgs), seg.image_size
+        sizes = [tuple(im.shape[:2]) for im in imgs]
+        same = all(sz == sizes[0] for sz in sizes)
+        with seg._lock, torch.cuda.device(seg.dev):
+            p = seg.plan(B)
+            # outputs come from the CALLER's allocator pool; the segmenter's stream is ordered behind the caller's before it writes them
+            iou = torch.empty_like(p.iou)
+            ext = torch.empty(B, 4, dtype=torch.int32, device=seg.dev)
+            ext_h = torch.empty(B, 4, dtype=torch.int32, pin_memory=True)
+            if same:
+                u8 = torch.empty(B, sizes[0][0], sizes[0][1], dtype=torch.uint8, device=seg.dev)
+                u8s = [u8[b] for b in range(B)]
+            else:
+                u8s = [torch.empty(h, w, dtype=torch.uint8, device=seg.dev) for h, w in sizes]
+            seg.stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(seg.stream):
+                sp = seg.stream.cuda_stream
+                tr.forward_batch(imgs, swap_rb=self.swap, out=p.x_in.t, out_dtype=seg.dtype)
+                p.plan.run()
+                iou.copy_(p.iou, non_blocking=True)
+                hi = p.high_res                                             # f32 [B,1,R,R]
+                if same:
+                    _lib.check(lib.cvmi_mask_postprocess(hi.data_ptr(), B, R, R, sizes[0][0], sizes[0][1], float(tr.mask_threshold), u8.data_ptr(),
+                                                         ext.data_ptr(), sp), "mask_postprocess")
+                else:
+                    for b, (h, w) in enumerate(sizes):
+                        _lib.check(lib.cvmi_mask_postprocess(hi[b].data_ptr(), 1, R, R, h, w, float(tr.mask_threshold), u8s[b].data_ptr(),
+                                                             ext[b].data_ptr(), sp), "mask_postprocess")
+                ext_h.copy_(ext, non_blocking=True)
+                done = torch.cuda.Event()
+                done.record(seg.stream)
+
+        def finish():
+            done.synchronize()
+            return u8s, [None if x1 < 0 else (x0, y0, x1 + 1, y1 + 1) for x0, y0, x1, y1 in ext_h.tolist()], iou
+        return finish
 
 
 def gather_results(results, key="mask", dst=0):

@@ -82,14 +82,14 @@ class SAM2Model:
         return self._plans[key]
 
     def _stage_images(self, p, images):
-        """Checked copy of a [B,3,R,R] tensor into the plan's NHWC input buffer (on the model's stream)."""
+        """Checked copy of a [B,3,R,R] tensor into the plan's NHWC input buffer.  Runs inside `torch.cuda.stream(self.stream)`; the caller's
+        stream has been made a predecessor (`wait_stream`), so device inputs produced there are complete when the copy reads them."""
         lib = _lib.load()
         B = images.shape[0]
         x = images.to(self.dev)
         if x.dtype not in (torch.float32, torch.float16, torch.bfloat16) or (x.dtype == torch.float16) != (self.dtype == F16) and x.dtype != torch.float32:
             x = x.float()                                     # (a 16-bit input of the OTHER 16-bit type goes through f32)
         src_dt = {torch.float32: F32, torch.float16: F16, torch.bfloat16: BF16}[x.dtype]
-        torch.cuda.current_stream().synchronize()
         sp = self.stream.cuda_stream
         if x.permute(0, 2, 3, 1).is_contiguous():            # already channels-last memory (SAM2Transforms output)
             _lib.check(lib.cvmi_cast(x.data_ptr(), 3, src_dt, p.x_in.t.data_ptr(), 3, self.dtype, B * self.image_size ** 2, 3, sp), "cast")
@@ -97,6 +97,22 @@ class SAM2Model:
             x = x.contiguous()
             _lib.check(lib.cvmi_nchw_to_nhwc(x.data_ptr(), src_dt, p.x_in.t.data_ptr(), self.dtype, 3, B, 3, self.image_size, self.image_size, sp), "nchw_to_nhwc")
         return x                                              # keep alive until the stream has consumed it
+
+    def _run(self, p, images, outs, before=None):
+        """Stage -> replay the plan -> copy `outs` = [(plan tensor, fresh tensor)] -- all on the model's stream, which first waits for the
+        caller's current stream and is synchronised before returning (the reference's call is synchronous).  The output copies are
+        part of the stream's order, so the next caller's replay (another session thread, app.py:134) cannot overwrite the plan's
+        buffers under them."""
+        self.stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self.stream):
+            if before is not None:
+                before()
+            keep = self._stage_images(p, images)
+            p.plan.run()
+            for src, dst in outs:
+                dst.copy_(src, non_blocking=True)
+        self.stream.synchronize()
+        del keep
 
     def _check_images(self, images):
         if not (torch.is_tensor(images) and images.dim() == 4 and images.shape[1] == 3 and images.shape[2] == images.shape[3] == self.image_size):
@@ -108,11 +124,9 @@ class SAM2Model:
             raise NotImplementedError("the wrapper always runs multimask_output=False (sam2_infer.py:257)")
         with self._lock, torch.cuda.device(self.dev):
             p = self.plan(images.shape[0])
-            keep = self._stage_images(p, images)
-            p.plan.run()
-            self.stream.synchronize()
-            del keep
-            return p.high_res.clone(), p.low_res.clone(), p.iou.clone()
+            out = [torch.empty_like(t) for t in (p.high_res, p.low_res, p.iou)]       # the caller's tensors (its allocator pool, not the model stream's)
+            self._run(p, images, list(zip((p.high_res, p.low_res, p.iou), out)))
+            return tuple(out)
 
     forward = __call__
 
@@ -159,14 +173,14 @@ class SAM2Model:
             if pts is not None:
                 coords[:, nb:nb + nk] = pts.reshape(B * P, nk, 2)
                 labels[:, nb:nb + nk] = lab.reshape(B * P, nk)
-            p.coords.copy_(coords, non_blocking=False)
-            p.labels.copy_(labels, non_blocking=False)
-            keep = self._stage_images(p, images)
-            p.plan.run()
-            self.stream.synchronize()
-            del keep
-            hi = p.high_res.view(B, P, R, R).clone() if return_high_res else None
-            return hi, p.low_res.view(B, P, f0, f0).clone(), p.iou.view(B, P).clone()
+            def prompts_in():                                          # on the model's stream, in front of the replay that reads them
+                p.coords.copy_(coords, non_blocking=False)
+                p.labels.copy_(labels, non_blocking=False)
+            lo, iou = torch.empty(B, P, f0, f0, dtype=torch.float32, device=self.dev), torch.empty(B, P, dtype=torch.float32, device=self.dev)
+            hi = torch.empty(B, P, R, R, dtype=torch.float32, device=self.dev) if return_high_res else None
+            outs = [(p.low_res.view(B, P, f0, f0), lo), (p.iou.view(B, P), iou)] + ([(p.high_res.view(B, P, R, R), hi)] if return_high_res else [])
+            self._run(p, images, outs, before=prompts_in)
+            return hi, lo, iou
 
 
 def get_modified_sam2(model_cfg_path, checkpoint_path, device="cuda", use_high_res_features=True, use_peft=True, lora_rank=12,
@@ -207,37 +221,45 @@ class SAM2Transforms:
             raise NotImplementedError("hole / sprinkle filtering (connected components) is disabled in the reference (circuit_analyzer.py:245-250)")
         self.mean, self.std = [0.485, 0.456, 0.406], [0.229, 0.224, 0.225]
 
-    def __call__(self, x):
-        require_gpu()
+    # Every method below behaves like a torch op: kernels are enqueued on the caller's CURRENT stream and nothing synchronises the device
+    # (the first use of a result on another stream, or `.cpu()`, orders itself the usual way).  One object is shared by all session
+    # threads (app.py:134): there is no shared state to protect.
+    @staticmethod
+    def _check_u8(x):
         img = np.ascontiguousarray(np.asarray(x))
         if img.ndim != 3 or img.shape[2] != 3 or img.dtype != np.uint8:
             raise TypeError("SAM2Transforms expects an RGB uint8 image (PIL or HxWx3 array)")
-        lib = _lib.load()
-        R = self.resolution
-        src = torch.from_numpy(img).cuda()
-        out = torch.empty(R, R, 3, dtype=torch.float32, device="cuda")
-        torch.cuda.current_stream().synchronize()
-        _lib.check(lib.cvmi_sam2_transform(src.data_ptr(), img.shape[0], img.shape[1], out.data_ptr(), R, F32, None), "sam2_transform")
-        torch.cuda.synchronize()
-        return out.permute(2, 0, 1)
+        return img
 
-    def forward_batch(self, img_list):
-        """sam2_infer.py:53-56.  -> f32 [B,3,R,R] (channels-last memory); one device synchronisation for the whole batch."""
+    def __call__(self, x):
+        return self.forward_batch([x])[0]
+
+    def forward_batch(self, img_list, swap_rb=False, out=None, out_dtype=F32):
+        """sam2_infer.py:53-56.  -> f32 [B,3,R,R] (channels-last memory).  Equally sized images go through ONE pinned staging buffer,
+        ONE H2D copy and ONE launch; ragged sizes take one launch each.  swap_rb: read the channels reversed (the caller's BGR2RGB,
+        circuit_analyzer.py:343) instead of a host pass over every image.  out / out_dtype: write into an existing [B,R,R,3] device
+        tensor of that CVMI dtype (the segmenter's input buffer) instead of a fresh f32 one."""
         require_gpu()
         lib = _lib.load()
         R = self.resolution
-        out = torch.empty(len(img_list), R, R, 3, dtype=torch.float32, device="cuda")
-        srcs = []
-        for img in img_list:
-            img = np.ascontiguousarray(np.asarray(img))
-            if img.ndim != 3 or img.shape[2] != 3 or img.dtype != np.uint8:
-                raise TypeError("SAM2Transforms expects RGB uint8 images (PIL or HxWx3 arrays)")
-            srcs.append(torch.from_numpy(img).cuda())
-        torch.cuda.current_stream().synchronize()
-        for b, src in enumerate(srcs):
-            _lib.check(lib.cvmi_sam2_transform(src.data_ptr(), src.shape[0], src.shape[1], out[b].data_ptr(), R, F32, None), "sam2_transform")
-        torch.cuda.synchronize()
-        return out.permute(0, 3, 1, 2)
+        imgs = [self._check_u8(im) for im in img_list]
+        B = len(imgs)
+        res = torch.empty(B, R, R, 3, dtype=torch.float32, device="cuda") if out is None else out
+        sp = torch.cuda.current_stream().cuda_stream
+        if B > 1 and all(im.shape == imgs[0].shape for im in imgs):
+            h, w = imgs[0].shape[:2]
+            host = torch.empty(B, h, w, 3, dtype=torch.uint8, pin_memory=True)
+            hv = host.numpy()
+            for b, im in enumerate(imgs):
+                hv[b] = im
+            src = host.to("cuda", non_blocking=True)
+            _lib.check(lib.cvmi_sam2_transform_batch(src.data_ptr(), B, h, w, res.data_ptr(), R, out_dtype, 1 if swap_rb else 0, sp), "sam2_transform")
+        else:
+            for b, im in enumerate(imgs):
+                src = torch.from_numpy(im).cuda()
+                _lib.check(lib.cvmi_sam2_transform_batch(src.data_ptr(), 1, im.shape[0], im.shape[1], res[b].data_ptr(), R, out_dtype, 1 if swap_rb else 0, sp),
+                           "sam2_transform")
+        return res.permute(0, 3, 1, 2) if out is None else res
 
     def mask_extent(self, mask_u8):
         """Bounding boxes of binary masks [N,H,W] / [B,C,H,W] (u8 on the device): list of (x0, y0, x1, y1) or None per
@@ -248,9 +270,12 @@ class SAM2Transforms:
         H, W = m.shape[-2:]
         N = m.numel() // (H * W)
         ext = torch.empty(N, 4, dtype=torch.int32, device=m.device)
-        torch.cuda.current_stream().synchronize()
-        _lib.check(lib.cvmi_mask_extent(m.data_ptr(), N, H, W, ext.data_ptr(), None), "mask_extent")
-        torch.cuda.synchronize()
+        _lib.check(lib.cvmi_mask_extent(m.data_ptr(), N, H, W, ext.data_ptr(), torch.cuda.current_stream().cuda_stream), "mask_extent")
+        return self.extents_to_boxes(ext)
+
+    @staticmethod
+    def extents_to_boxes(ext):
+        """int32 [N,4] {min x, min y, max x, max y} (or {W, H, -1, -1}) -> the reference's sam_extent_bbox tuples / None."""
         return [None if x1 < 0 else (x0, y0, x1 + 1, y1 + 1) for x0, y0, x1, y1 in ext.cpu().tolist()]
 
     # sam2_infer.py:58-86 -- what a caller needs to feed detector boxes (original pixels) to `infer_masks`
@@ -280,16 +305,13 @@ class SAM2Transforms:
         H, W = int(orig_hw[0]), int(orig_hw[1])
         out = torch.empty(B, C, H, W, dtype=torch.float32, device=m.device)
         u8 = torch.empty(B, C, H, W, dtype=torch.uint8, device=m.device) if return_u8 else None
-        torch.cuda.current_stream().synchronize()
         _lib.check(lib.cvmi_bilinear_f32(m.data_ptr(), B * C, h, w, out.data_ptr(), H, W, u8.data_ptr() if return_u8 else None,
-                                         float(self.mask_threshold), None), "bilinear")
-        torch.cuda.synchronize()
+                                         float(self.mask_threshold), torch.cuda.current_stream().cuda_stream), "bilinear")
         return (out, u8) if return_u8 else out
 
-    def postprocess_to_mask(self, masks, orig_hw):
-        """circuit_analyzer.py:354-370 in one pass on the device: bilinear resize to orig_hw -> `> mask_threshold` -> u8 {0, 255}
-        -> bounding rectangle.  The f32 [B,C,H,W] map is never written; only the u8 masks and four ints per mask exist afterwards.
-        Returns (mask_u8 [B,C,H,W] on the device, [(x0, y0, x1, y1) | None] per mask, the reference's `sam_extent_bbox`)."""
+    def postprocess_to_mask_async(self, masks, orig_hw):
+        """The device half of postprocess_to_mask: -> (mask_u8 [B,C,H,W], extent int32 [B*C,4]) enqueued on the current stream, nothing
+        copied to the host (extents_to_boxes(extent) does that, later, for a whole batch at once)."""
         require_gpu()
         lib = _lib.load()
         m = masks.float().contiguous()
@@ -299,8 +321,13 @@ class SAM2Transforms:
         H, W = int(orig_hw[0]), int(orig_hw[1])
         u8 = torch.empty(B, C, H, W, dtype=torch.uint8, device=m.device)
         ext = torch.empty(B * C, 4, dtype=torch.int32, device=m.device)
-        torch.cuda.current_stream().synchronize()
-        _lib.check(lib.cvmi_mask_postprocess(m.data_ptr(), B * C, h, w, H, W, float(self.mask_threshold), u8.data_ptr(), ext.data_ptr(), None),
-                   "mask_postprocess")
-        torch.cuda.synchronize()
-        return u8, [None if x1 < 0 else (x0, y0, x1 + 1, y1 + 1) for x0, y0, x1, y1 in ext.cpu().tolist()]
+        _lib.check(lib.cvmi_mask_postprocess(m.data_ptr(), B * C, h, w, H, W, float(self.mask_threshold), u8.data_ptr(), ext.data_ptr(),
+                                             torch.cuda.current_stream().cuda_stream), "mask_postprocess")
+        return u8, ext
+
+    def postprocess_to_mask(self, masks, orig_hw):
+        """circuit_analyzer.py:354-370 in one pass on the device: bilinear resize to orig_hw -> `> mask_threshold` -> u8 {0, 255}
+        -> bounding rectangle.  The f32 [B,C,H,W] map is never written; only the u8 masks and four ints per mask exist afterwards.
+        Returns (mask_u8 [B,C,H,W] on the device, [(x0, y0, x1, y1) | None] per mask, the reference's `sam_extent_bbox`)."""
+        u8, ext = self.postprocess_to_mask_async(masks, orig_hw)
+        return u8, self.extents_to_boxes(ext)

@@ -211,6 +211,10 @@ int cvmi_yolo_nms_best(const float* pred, const float* best_score, const int* be
  * channel ((y&1)*2 + (x&1))*3 + c, channels 12..15 zero -- the layout the YOLO stem conv reads. */
 int cvmi_letterbox(const uint8_t* src, int H, int W, void* dst, int out_h, int out_w, int new_h,
                    int new_w, int top, int left, int dtype, int s2d, cvmi_stream_t stream);
+/* The same for B equally sized sources in ONE launch: src u8 [B,H,W,3] contiguous (e.g. one pinned staging buffer copied by one
+ * hipMemcpyAsync), image b written at dst + b * dst_image_stride elements (the detector's batched `predict([img, ...])`). */
+int cvmi_letterbox_batch(const uint8_t* src, int B, int H, int W, void* dst, long long dst_image_stride, int out_h, int out_w,
+                         int new_h, int new_w, int top, int left, int dtype, int s2d, cvmi_stream_t stream);
 
 /* ---- dtype conversion / layout helpers -------------------------------------------------------- */
 /* NCHW (f32 or f16) -> NHWC dtype */
@@ -368,6 +372,11 @@ int cvmi_upsample_refine(const float* low, int N, int h, int w, float* high, int
  * R x R -> ImageNet normalise; written NHWC with 3 channels in dst_dtype. */
 int cvmi_sam2_transform(const uint8_t* src, int H, int W, void* dst, int R, int dst_dtype,
                         cvmi_stream_t stream);
+/* The same for B equally sized sources in ONE launch (SAM2Transforms.forward_batch, sam2_infer.py:53-56): src u8 [B,H,W,3] contiguous,
+ * dst [B,R,R,3].  swap_rb = 1 reads the source channels reversed: circuit_analyzer.py:343 applies cv2.COLOR_BGR2RGB to the image it
+ * is handed, which on the device is an index, not a pass over the image. */
+int cvmi_sam2_transform_batch(const uint8_t* src, int B, int H, int W, void* dst, int R, int dst_dtype, int swap_rb,
+                              cvmi_stream_t stream);
 
 #ifdef __cplusplus
 }
