@@ -64,6 +64,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=None, help="images per GPU per stage launch (default 32 YOLO / 16 SAM)")
     ap.add_argument("--total-images", type=int, default=64, help="pipeline workload: images in the whole job")
     ap.add_argument("--dtype", default="f16", choices=["f16", "f32", "bf16"], help="operand storage type (bf16: SAM 2 workloads, BASELINE configs[4])")
+    ap.add_argument("--attn", default="16", choices=["16", "fp8"], help="fp8: the AV products of Hiera's 256-key windows / global blocks on the block-scaled fp8 MFMA (BASELINE configs[4])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile-pass", action="store_true")
     a = ap.parse_args()
@@ -322,7 +323,7 @@ class SamStage:
                 check_replicas(weight_tensors(wt), "SAM 2.1")
             SamStage._weights[key] = (params, wt)
         self.params, self.wt = SamStage._weights[key]
-        self.sp = Sam2Plan(self.wt, B, stream, prompts=prompts)
+        self.sp = Sam2Plan(self.wt, B, stream, prompts=prompts, attn=a.attn)
         self.boxes = None
         if prompts:
             self.boxes = synthetic_boxes(B, prompts, seed=rank)

@@ -349,6 +349,14 @@ __global__ __launch_bounds__(256) void attn_f16_kernel(const AttnArgs p) {
 // column-major), which removes the 8 scalar 2-byte LDS stores per staged chunk the transposed image needed.
 // V row stride: a 32-lane half reads 4 consecutive key rows x 64 bytes, conflict-free when (stride mod 256) is 64 or 192.
 typedef short s16x4 __attribute__((__vector_size__(4 * sizeof(short))));
+typedef int v8i32 __attribute__((ext_vector_type(8)));
+// four floats -> four OCP e4m3 bytes (a = byte 0).  v_cvt_pk_fp8_f32 returns NaN, not the largest value, on overflow: callers bound their inputs.
+__device__ __forceinline__ unsigned pack4_e4m3(float a, float b, float c, float d) {
+  int w = 0;
+  w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, w, false);
+  w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
+  return (unsigned)w;
+}
 template <int DQKP, int DVP, int NW>
 __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn64_kernel(const AttnArgs p) {
   constexpr int NTH = NW * 64;                            // NW = 8: one K / V tile serves 256 queries
@@ -630,7 +638,17 @@ __device__ __forceinline__ int key_perm72(int i) {            // i = 4 a + b  ->
 // back with no further synchronisation.  Row reads that run past column 72 (5th k-step, third 32-wide d tile) fetch the
 // next row's finite data against zero Q columns / unstored output rows.  4 waves = 128 queries per workgroup; 72 KiB of
 // LDS, two workgroups per CU.
-template <int NW>
+// AV8 = true (cvmi_attn_desc.av_fp8, BASELINE configs[4] "fp8 MFMA attention"): the O^T += V^T P^T contraction -- whose K axis is the KEY axis,
+// a whole multiple of 64 here -- runs on the block-scaled v_mfma_scale_f32_32x32x64_f8f6f4 (2 x the bf16 rate per clock): one instruction
+// per (64-key tile, 32-wide d tile) instead of four.  V is quantised ONCE per workgroup: after the window has landed, every thread builds
+// three 16-byte pieces of the e4m3 V^T operand image from the fp16 rows (the same transposing reads the 16-bit path feeds its MFMAs with,
+// f32 clamp to +-448 because the conversion returns NaN, not the maximum, on overflow), a barrier, and the pieces overwrite the 16-bit V
+// image in place, lane-linear (conflict-free ds_read_b128 of whole operands).  P is quantised from the fp32 softmax as e4m3 of p * 2^8
+// (p <= 1: the row maximum is exactly 256, no overflow) with the block scale 2^-8 in the MFMA's scale operand; row sums stay fp32 sums of
+// the unquantised p.  Operand maps measured on gfx950 (tools/probe/fp8_probe.hip, fp8_scale_probe.hip): lane (r = l & 31, h = l >> 5) holds
+// A[row r] / B[col r] bytes j = 0..31 which pair with the SAME (h, j) of the other operand; scale byte 0 of lane (r, h) scales that row's
+// bytes 16 h .. 16 h + 15 of both lane halves; C / D as every 32 x 32 MFMA.
+template <int NW, bool AV8 = false>
 __global__ __launch_bounds__(NW * 64, 2) void attn_res256_kernel(const AttnArgs p) {
   constexpr int ROW = 144, NK = 256, QS = 5, DT = 3, CH = 9;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -720,6 +738,37 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_res256_kernel(const AttnArgs 
   dma_wait();                                               // every wave waits for its OWN LDS-DMA pieces ...
   __syncthreads();                                          // ... and the barrier publishes the window
 
+  if constexpr (AV8) {
+    static_assert(NW == 8, "the e4m3 V image is built by 8 waves x 3 pieces");
+    // piece pc = wv + 8 i of 24: (key tile kt, d tile t, operand half u) = (pc / 6, (pc % 6) / 2, pc % 2); this lane's 16 bytes are
+    // V[key(u, jj)][32 t + lr] for jj = 0..15 in the k order of the P operand (the two k-steps s = jj >> 3 of the 16-bit path)
+    u32x4 piece[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int pc = wv + 8 * i, kt = pc / 6, t = (pc - 6 * kt) >> 1, u = pc & 1;
+      unsigned w[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+      for (int sgrp = 0; sgrp < 2; ++sgrp) {
+        const char* a0 = vt + (kt * 64 + u * 32 + sgrp * 16) * ROW + t * 64;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0 + 2 * ROW));
+        const f16x4 l4 = __builtin_bit_cast(f16x4, lo), h4 = __builtin_bit_cast(f16x4, hi);
+        float f[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { f[e] = (float)l4[e]; f[4 + e] = (float)h4[e]; }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] = __builtin_amdgcn_fmed3f(f[e], -448.f, 448.f);
+        w[2 * sgrp] = pack4_e4m3(f[0], f[1], f[2], f[3]);
+        w[2 * sgrp + 1] = pack4_e4m3(f[4], f[5], f[6], f[7]);
+      }
+      piece[i] = (u32x4){w[0], w[1], w[2], w[3]};
+    }
+    __syncthreads();                                        // every transposing read of the 16-bit V image is done ...
+#pragma unroll
+    for (int i = 0; i < 3; ++i) *reinterpret_cast<u32x4*>(Vs + (wv + 8 * i) * 1024 + lane * 16) = piece[i];
+    __syncthreads();                                        // ... before the e4m3 image replaces it
+  }
+
 #pragma unroll 1
   for (int kc = 0; kc < NK / 64; ++kc) {
     f32x16 sacc[2];
@@ -743,14 +792,32 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_res256_kernel(const AttnArgs 
     const float alpha = __builtin_amdgcn_exp2f(fmaf(m_run, c, -mc));
     float psum = 0.f;
     f16x8 pf[2][2];
+    u32x4 p8[2];                                            // AV8: this lane's 32 e4m3 bytes of P^T (tile u -> bytes 16 u .. 16 u + 15)
+    if constexpr (AV8) {
+      const float mc8 = mc - 8.f;                           // p * 2^8 through the exponent
 #pragma unroll
-    for (int u = 0; u < 2; ++u)
+      for (int u = 0; u < 2; ++u) {
+        unsigned w[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float pv = __builtin_amdgcn_exp2f(fmaf(sacc[u][r], c, -mc));
-        psum += pv;
-        pf[u][r >> 3][r & 7] = (f16)pv;
+        for (int r = 0; r < 16; r += 4) {
+          float e[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) { e[i] = __builtin_amdgcn_exp2f(fmaf(sacc[u][r + i], c, -mc8)); psum += e[i]; }
+          w[r >> 2] = pack4_e4m3(e[0], e[1], e[2], e[3]);
+        }
+        p8[u] = (u32x4){w[0], w[1], w[2], w[3]};
       }
+      psum *= 0.00390625f;                                  // back to the scale of l_run (exact: a power of two)
+    } else {
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float pv = __builtin_amdgcn_exp2f(fmaf(sacc[u][r], c, -mc));
+          psum += pv;
+          pf[u][r >> 3][r & 7] = (f16)pv;
+        }
+    }
     psum += __shfl_xor(psum, 32);
     l_run = l_run * alpha + psum;
     const float m_prev = m_run;
@@ -761,19 +828,30 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_res256_kernel(const AttnArgs 
 #pragma unroll
         for (int r = 0; r < 16; ++r) oacc[t][r] *= alpha;
     }
+    if constexpr (AV8) {
+      const v8i32 pb = {(int)p8[0][0], (int)p8[0][1], (int)p8[0][2], (int)p8[0][3], (int)p8[1][0], (int)p8[1][1], (int)p8[1][2], (int)p8[1][3]};
 #pragma unroll
-    for (int u = 0; u < 2; ++u)
+      for (int t = 0; t < DT; ++t) {
+        const char* va = Vs + ((kc * 3 + t) * 2) * 1024 + lane * 16;
+        const u32x4 a_lo = *reinterpret_cast<const u32x4*>(va), a_hi = *reinterpret_cast<const u32x4*>(va + 1024);
+        const v8i32 av = {(int)a_lo[0], (int)a_lo[1], (int)a_lo[2], (int)a_lo[3], (int)a_hi[0], (int)a_hi[1], (int)a_hi[2], (int)a_hi[3]};
+        oacc[t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av, pb, oacc[t], 0, 0, 0, 127, 0, 119);      // e4m3 x e4m3, scales 2^0 / 2^-8
+      }
+    } else {
 #pragma unroll
-      for (int s = 0; s < 2; ++s)
+      for (int u = 0; u < 2; ++u)
 #pragma unroll
-        for (int t = 0; t < DT; ++t) {
-          const char* a0 = vt + (kc * 64 + u * 32 + s * 16) * ROW + t * 64;
-          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0));
-          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0 + 2 * ROW));
-          const u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
-          const u32x4 vv = {l2[0], l2[1], h2[0], h2[1]};
-          oacc[t] = CVMI_MFMA_32X32X16(__builtin_bit_cast(f16x8, vv), pf[u][s], oacc[t], 0, 0, 0);
-        }
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+          for (int t = 0; t < DT; ++t) {
+            const char* a0 = vt + (kc * 64 + u * 32 + s * 16) * ROW + t * 64;
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0));
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0 + 2 * ROW));
+            const u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
+            const u32x4 vv = {l2[0], l2[1], h2[0], h2[1]};
+            oacc[t] = CVMI_MFMA_32X32X16(__builtin_bit_cast(f16x8, vv), pf[u][s], oacc[t], 0, 0, 0);
+          }
+    }
   }
   if (q_ok) {
     const float inv = 1.f / l_run;
@@ -990,7 +1068,10 @@ int launch_res64(const AttnArgs& a, hipStream_t stream) {
 // ---- long sequences of head_dim 72 (Hiera global attention): the same inner loop, K / V streamed through two 64-key
 //      LDS buffers by DMA (no staging registers: 4 waves per SIMD); one barrier per tile publishes tile t + 1 while it
 //      drains, issued a full tile of MFMAs earlier.  Rows past Nk re-read the last key (finite; their scores are masked).
-template <int NW>
+// AV8: as in attn_res256_kernel -- the AV product on the block-scaled fp8 MFMA.  Per 64-key tile, waves 0..5 build one 1-KiB piece each of
+// the tile's e4m3 V^T operand image (d tile t = wave / 2, operand half u = wave & 1) from the 16-bit tile in front of the QK^T products; a
+// second barrier per tile (LDS writes only: the next tile's DMA stays in flight across it) publishes the image before the three MFMAs.
+template <int NW, bool AV8 = false>
 __global__ __launch_bounds__(NW * 64, 2) void attn_dma72_kernel(const AttnArgs p) {
   constexpr int ROW = 144, TK = 64, QS = 5, DT = 3, CH = 9;
   constexpr int TILE_B = TK * ROW;                          // 9216 B per matrix per buffer
@@ -1094,6 +1175,28 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_dma72_kernel(const AttnArgs p
     const char* const vt = smem + (kt & 1) * 2 * TILE_B + vt_off;
     if (kt + 1 < nkt) issue(kt + 1, (kt + 1) & 1);          // the other buffer was last read in iteration kt - 1 (barrier below)
     constexpr int kc = 0;
+    if constexpr (AV8) {
+      static_assert(NW == 8, "six of eight waves build the e4m3 V image");
+      if (wv < 6) {                                         // wave-uniform
+        const int t = wv >> 1, u = wv & 1;
+        unsigned w[4];
+#pragma unroll
+        for (int sgrp = 0; sgrp < 2; ++sgrp) {
+          const char* a0 = vt + (u * 32 + sgrp * 16) * ROW + t * 64;
+          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0));
+          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0 + 2 * ROW));
+          const f16x4 l4 = __builtin_bit_cast(f16x4, lo), h4 = __builtin_bit_cast(f16x4, hi);
+          float f[8];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { f[e] = (float)l4[e]; f[4 + e] = (float)h4[e]; }
+#pragma unroll
+          for (int e = 0; e < 8; ++e) f[e] = __builtin_amdgcn_fmed3f(f[e], -448.f, 448.f);
+          w[2 * sgrp] = pack4_e4m3(f[0], f[1], f[2], f[3]);
+          w[2 * sgrp + 1] = pack4_e4m3(f[4], f[5], f[6], f[7]);
+        }
+        *reinterpret_cast<u32x4*>(smem + 4 * TILE_B + wv * 1024 + lane * 16) = (u32x4){w[0], w[1], w[2], w[3]};     // last read before the barrier that ended iteration kt - 1
+      }
+    }
     f32x16 sacc[2];
 #pragma unroll
     for (int u = 0; u < 2; ++u)
@@ -1124,14 +1227,32 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_dma72_kernel(const AttnArgs p
     const float alpha = __builtin_amdgcn_exp2f(fmaf(m_run, c, -mc));
     float psum = 0.f;
     f16x8 pf[2][2];
+    u32x4 p8[2];
+    if constexpr (AV8) {
+      const float mc8 = mc - 8.f;                           // p * 2^8 through the exponent
 #pragma unroll
-    for (int u = 0; u < 2; ++u)
+      for (int u = 0; u < 2; ++u) {
+        unsigned w[4];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float pv = __builtin_amdgcn_exp2f(fmaf(sacc[u][r], c, -mc));
-        psum += pv;
-        pf[u][r >> 3][r & 7] = (f16)pv;
+        for (int r = 0; r < 16; r += 4) {
+          float e[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) { e[i] = __builtin_amdgcn_exp2f(fmaf(sacc[u][r + i], c, -mc8)); psum += e[i]; }
+          w[r >> 2] = pack4_e4m3(e[0], e[1], e[2], e[3]);
+        }
+        p8[u] = (u32x4){w[0], w[1], w[2], w[3]};
       }
+      psum *= 0.00390625f;
+    } else {
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float pv = __builtin_amdgcn_exp2f(fmaf(sacc[u][r], c, -mc));
+          psum += pv;
+          pf[u][r >> 3][r & 7] = (f16)pv;
+        }
+    }
     psum += __shfl_xor(psum, 32);
     l_run = l_run * alpha + psum;
     const float m_prev = m_run;
@@ -1142,19 +1263,32 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_dma72_kernel(const AttnArgs p
 #pragma unroll
         for (int r = 0; r < 16; ++r) oacc[t][r] *= alpha;
     }
+    if constexpr (AV8) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's piece of the e4m3 image is written ...
+      __builtin_amdgcn_s_barrier();                         // ... and published (no vmcnt wait: tile kt + 1's DMA keeps flying)
+      const v8i32 pb = {(int)p8[0][0], (int)p8[0][1], (int)p8[0][2], (int)p8[0][3], (int)p8[1][0], (int)p8[1][1], (int)p8[1][2], (int)p8[1][3]};
 #pragma unroll
-    for (int u = 0; u < 2; ++u)
+      for (int t = 0; t < DT; ++t) {
+        const char* va = smem + 4 * TILE_B + (2 * t) * 1024 + lane * 16;
+        const u32x4 a_lo = *reinterpret_cast<const u32x4*>(va), a_hi = *reinterpret_cast<const u32x4*>(va + 1024);
+        const v8i32 av = {(int)a_lo[0], (int)a_lo[1], (int)a_lo[2], (int)a_lo[3], (int)a_hi[0], (int)a_hi[1], (int)a_hi[2], (int)a_hi[3]};
+        oacc[t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av, pb, oacc[t], 0, 0, 0, 127, 0, 119);
+      }
+    } else {
 #pragma unroll
-      for (int s = 0; s < 2; ++s)
+      for (int u = 0; u < 2; ++u)
 #pragma unroll
-        for (int t = 0; t < DT; ++t) {
-          const char* a0 = vt + (kc * 64 + u * 32 + s * 16) * ROW + t * 64;
-          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0));
-          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0 + 2 * ROW));
-          const u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
-          const u32x4 vv = {l2[0], l2[1], h2[0], h2[1]};
-          oacc[t] = CVMI_MFMA_32X32X16(__builtin_bit_cast(f16x8, vv), pf[u][s], oacc[t], 0, 0, 0);
-        }
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+          for (int t = 0; t < DT; ++t) {
+            const char* a0 = vt + (kc * 64 + u * 32 + s * 16) * ROW + t * 64;
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0));
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0 + 2 * ROW));
+            const u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
+            const u32x4 vv = {l2[0], l2[1], h2[0], h2[1]};
+            oacc[t] = CVMI_MFMA_32X32X16(__builtin_bit_cast(f16x8, vv), pf[u][s], oacc[t], 0, 0, 0);
+          }
+    }
     dma_wait();                                             // this wave's pieces of tile kt + 1 (issued a whole tile of MFMAs ago)
     __syncthreads();                                        // tile kt fully read; tile kt + 1 landed in every wave
   }
@@ -1183,29 +1317,29 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_dma72_kernel(const AttnArgs p
   }
 }
 
-template <int NW>
+template <int NW, bool AV8 = false>
 int launch_dma72(const AttnArgs& a, hipStream_t stream) {
-  constexpr int lds = 4 * 64 * 144 + 256;
+  constexpr int lds = 4 * 64 * 144 + (AV8 ? 6 * 1024 : 0) + 256;          // AV8: + the tile's e4m3 V^T image
   const long long blocks = (long long)a.B * a.heads * ((a.qtiles + NW - 1) / NW);
   CVMI_CHECK(blocks > 0 && blocks < (1ll << 31), "attention: bad grid");
-  cvmi_note_kernel("attn_dma72_kernel<%d>", NW);
-  hipLaunchKernelGGL(attn_dma72_kernel<NW>, dim3((unsigned)blocks), dim3(NW * 64), lds, stream, a);
+  cvmi_note_kernel(AV8 ? "attn_dma72_kernel<%d, true>" : "attn_dma72_kernel<%d, false>", NW);
+  hipLaunchKernelGGL((attn_dma72_kernel<NW, AV8>), dim3((unsigned)blocks), dim3(NW * 64), lds, stream, a);
   CVMI_LAUNCH_CHECK();
   return 0;
 }
 
-template <int NW>
+template <int NW, bool AV8 = false>
 int launch_res256(const AttnArgs& a, hipStream_t stream) {
   constexpr int lds = 2 * 256 * 144 + 256;                 // + slack: the last rows' over-reads stay inside the allocation
   static bool attr_done = false;
   if (!attr_done) {
-    CVMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_res256_kernel<NW>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    CVMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_res256_kernel<NW, AV8>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     attr_done = true;
   }
   const long long blocks = (long long)a.B * a.heads * ((a.qtiles + NW - 1) / NW);
   CVMI_CHECK(blocks > 0 && blocks < (1ll << 31), "attention: bad grid");
-  cvmi_note_kernel("attn_res256_kernel<%d>", NW);
-  hipLaunchKernelGGL(attn_res256_kernel<NW>, dim3((unsigned)blocks), dim3(NW * 64), lds, stream, a);
+  cvmi_note_kernel(AV8 ? "attn_res256_kernel<%d, true>" : "attn_res256_kernel<%d, false>", NW);
+  hipLaunchKernelGGL((attn_res256_kernel<NW, AV8>), dim3((unsigned)blocks), dim3(NW * 64), lds, stream, a);
   CVMI_LAUNCH_CHECK();
   return 0;
 }
@@ -1514,14 +1648,16 @@ extern "C" int CVMI_ENTRY(cvmi_attention)(const cvmi_attn_desc* d, cvmi_stream_t
     return 0;
   }
   static const int use_res256 = getenv("CVMI_ATTN_RES256") ? atoi(getenv("CVMI_ATTN_RES256")) : 2;      // tuning experiments only: 0 off, 1 four waves, 2 eight waves (4 per SIMD at 125 VGPRs)
-  if (use_res256 && d->Nk == 256 && d->dqk == 72 && d->dv == 72 && d->k_st % 8 == 0 && d->v_st % 8 == 0)
+  if (use_res256 && d->Nk == 256 && d->dqk == 72 && d->dv == 72 && d->k_st % 8 == 0 && d->v_st % 8 == 0) {
+    if (d->av_fp8 && a.qtiles >= 8) return launch_res256<8, true>(a, stream);          // block-scaled fp8 AV product (configs[4])
     return (use_res256 == 2 && a.qtiles >= 8) ? launch_res256<8>(a, stream) : launch_res256<4>(a, stream);
+  }
   static const int use_res64 = getenv("CVMI_ATTN_RES64") ? atoi(getenv("CVMI_ATTN_RES64")) : 1;          // tuning experiments only
   if (use_res64 && d->Nk == 64 && d->dqk == 72 && d->dv == 72 && d->k_st % 8 == 0 && d->v_st % 8 == 0 && (a.qtiles == 1 || a.qtiles == 2))
     return a.qtiles == 2 ? launch_res64<2>(a, stream) : launch_res64<1>(a, stream);
   static const int use_dma72 = getenv("CVMI_ATTN_DMA72") ? atoi(getenv("CVMI_ATTN_DMA72")) : 1;          // tuning experiments only
   if (use_dma72 && d->Nk >= 512 && a.qtiles >= 8 && d->dqk == 72 && d->dv == 72 && d->k_st % 8 == 0 && d->v_st % 8 == 0 && !d->q_pool)
-    return launch_dma72<8>(a, stream);
+    return d->av_fp8 ? launch_dma72<8, true>(a, stream) : launch_dma72<8>(a, stream);
   if (d->dqk <= 32 && d->dv <= 32) return launch_f16_gs<32, 32>(a, stream);
   if (d->dqk <= 32 && d->dv <= 64) return launch_f16_gs<32, 64>(a, stream);
   if (d->dqk <= 64 && d->dv <= 64) return launch_f16_gs<64, 64>(a, stream);

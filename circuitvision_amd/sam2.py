@@ -417,8 +417,13 @@ class Sam2Plan:
     padding point); the caller fills `coords` [B*P, points, 2] / `labels` [B*P, points] before each run and the decoder
     runs on B*P (image, prompt) pairs, image-major (MaskDecoder repeat_image=True); outputs are [B*P, 1, ...]."""
 
-    def __init__(self, wt, B, stream, dynamic_multimask_via_stability=True, prompts=0, points=3, high_res=True):
+    def __init__(self, wt, B, stream, dynamic_multimask_via_stability=True, prompts=0, points=3, high_res=True, attn="16"):
+        """attn = "fp8" (16-bit plans only; BASELINE configs[4]): the AV contraction of Hiera's 256-key windows and global blocks runs on the
+        block-scaled fp8 MFMA (cvmi_attn_desc.av_fp8); "16": operands in the plan's 16-bit type (default)."""
         self.wt, self.B, self.dt, self.dev = wt, B, wt.dtype, wt.device
+        if attn not in ("16", "fp8") or (attn == "fp8" and not is16(wt.dtype)):
+            raise ValueError("attn must be '16' or 'fp8' (fp8 needs an fp16 / bf16 plan)")
+        self.av_fp8 = 1 if attn == "fp8" else 0
         self._ln1_stats, self._ln1_parts = None, 0                    # LayerNorm statistics handed from a block's MLP to the next block's norm1
         self.P, self.K, self.want_high_res = prompts, points, high_res
         if prompts and not wt.prompt_ok:
@@ -525,14 +530,14 @@ class Sam2Plan:
             desc = make_attn_desc(q=base, k=base + dout * es, v=base + 2 * dout * es, o=ao.t.data_ptr(),
                                   q_sb=0, q_sh=hd, q_st=C3, k_sb=0, k_sh=hd, k_st=C3, v_sb=0, v_sh=hd, v_st=C3,
                                   o_sb=0, o_sh=hd, o_st=dout, B=nwin, heads=heads, Nq=nq, Nk=ws * ws, dqk=hd, dv=hd,
-                                  scale=hd ** -0.5, dtype=self.dt, win=ws, grid_h=Hp, grid_w=Wp, q_pool=1 if blk["q_pool"] else 0)
+                                  scale=hd ** -0.5, dtype=self.dt, win=ws, grid_h=Hp, grid_w=Wp, q_pool=1 if blk["q_pool"] else 0, av_fp8=self.av_fp8)
             fl = 4 * nwin * heads * nq * ws * ws * hd
         else:
             N = H * W
             desc = make_attn_desc(q=base, k=base + dout * es, v=base + 2 * dout * es, o=ao.t.data_ptr(),
                                   q_sb=N * C3, q_sh=hd, q_st=C3, k_sb=N * C3, k_sh=hd, k_st=C3, v_sb=N * C3, v_sh=hd, v_st=C3,
                                   o_sb=N * dout, o_sh=hd, o_st=dout, B=B, heads=heads, Nq=N, Nk=N, dqk=hd, dv=hd,
-                                  scale=hd ** -0.5, dtype=self.dt, win=0, grid_h=0, grid_w=0, q_pool=0)
+                                  scale=hd ** -0.5, dtype=self.dt, win=0, grid_h=0, grid_w=0, q_pool=0, av_fp8=self.av_fp8)
             fl = 4 * B * heads * N * N * hd
         op_attention(self.plan, f"b{i}.attn", desc, (qkv, ao), bytes_=qkv.nbytes + ao.nbytes, flops=fl)
         self.plan.ops[-1] = (self.plan.ops[-1][0], "attn_global" if ws == 0 else "attn_window") + self.plan.ops[-1][2:]

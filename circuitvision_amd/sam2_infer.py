@@ -35,8 +35,11 @@ class SAM2Model:
     `__call__(x) -> (high_res, low_res, iou)` (sam2_infer.py:220-275), plus `infer_masks`."""
 
     def __init__(self, hiera=HIERA_L, image_size=1024, dtype="f16", dev="cuda", use_refinement=True, refinement_kernels=(3, 5, 7, 11),
-                 embedding_r=4, lora_rank=4, lora_alpha=16, dynamic_multimask_via_stability=True):
+                 embedding_r=4, lora_rank=4, lora_alpha=16, dynamic_multimask_via_stability=True, attn="16"):
+        """attn="fp8": the softmax(QK^T) V products of Hiera's 256-key windows and global blocks on the block-scaled fp8 MFMA (BASELINE configs[4];
+        off by default: it is slower than the 16-bit product on this path -- DESIGN.md section 5 -- and costs ~3 mantissa bits on V)."""
         require_gpu()
+        self.attn = attn
         self.hiera, self.image_size = hiera, image_size
         self.dtype = {"f16": F16, "fp16": F16, "f32": F32, "fp32": F32, "bf16": BF16}[dtype] if isinstance(dtype, str) else dtype
         self.dev = dev
@@ -78,7 +81,7 @@ class SAM2Model:
         key = (B, prompts, high_res, points if prompts else 0)
         if key not in self._plans:
             with torch.cuda.device(self.dev):
-                self._plans[key] = Sam2Plan(self.weights, B, self.stream, self.dynamic, prompts=prompts, points=points, high_res=high_res)
+                self._plans[key] = Sam2Plan(self.weights, B, self.stream, self.dynamic, prompts=prompts, points=points, high_res=high_res, attn=self.attn)
         return self._plans[key]
 
     def _stage_images(self, p, images):
@@ -185,7 +188,7 @@ class SAM2Model:
 
 def get_modified_sam2(model_cfg_path, checkpoint_path, device="cuda", use_high_res_features=True, use_peft=True, lora_rank=12,
                       lora_alpha=16, lora_dropout=0.2, lora_target_modules=None, use_wrapper=True, trainable_embedding_r=4,
-                      use_refinement_layer=False, refinement_kernels=(3, 5, 7, 11), kernel_channels=4, dtype="f16", **_loss_and_optimizer_kwargs):
+                      use_refinement_layer=False, refinement_kernels=(3, 5, 7, 11), kernel_channels=4, dtype="f16", attn="16", **_loss_and_optimizer_kwargs):
     """Same signature as sam2_infer.py:277-305 (loss / optimizer kwargs accepted and ignored).  `checkpoint_path`
     may be 'synthetic[:seed]' for seeded random weights; a real base checkpoint ({'model': state_dict}) is accepted
     but every tensor is expected to come from the fine-tuned state dict loaded afterwards (circuit_analyzer.py:227-233)."""
@@ -197,7 +200,7 @@ def get_modified_sam2(model_cfg_path, checkpoint_path, device="cuda", use_high_r
     elif isinstance(model_cfg_path, str) and os.path.exists(model_cfg_path.lstrip("/")):
         hiera, image_size = _hiera_from_yaml(model_cfg_path.lstrip("/"))          # the reference prepends "/" for Hydra (circuit_analyzer.py:204)
     model = SAM2Model(hiera, image_size, dtype=dtype, dev=str(device), use_refinement=use_refinement_layer, refinement_kernels=refinement_kernels,
-                      embedding_r=trainable_embedding_r, lora_rank=lora_rank, lora_alpha=lora_alpha)
+                      embedding_r=trainable_embedding_r, lora_rank=lora_rank, lora_alpha=lora_alpha, attn=attn)
     if isinstance(checkpoint_path, str) and checkpoint_path.startswith("synthetic"):
         seed = int(checkpoint_path.split(":")[1]) if ":" in checkpoint_path else 0
         targets = lora_target_modules if (use_peft and lora_target_modules is not None) else ()

@@ -175,6 +175,10 @@ typedef struct cvmi_attn_desc {
   int q_bdiv, kv_bdiv;       /* > 1 (fp16, no window, head dims <= 64): q rows of batch entry b are read from entry b / q_bdiv,
                                 k / v rows from entry b / kv_bdiv -- the prompts of one image sharing its image-side tensors
                                 (SAM 2 MaskDecoder with repeat_image, first two-way layer); 0 / 1 = off */
+  int av_fp8;                /* 1 (16-bit dtype, head_dim 72; BASELINE configs[4] "fp8 MFMA attention"): the softmax(QK^T) V contraction runs on the
+                                block-scaled fp8 MFMA (v_mfma_scale_f32_32x32x64_f8f6f4): P as e4m3 of p * 2^8 (block scale 2^-8), V as e4m3,
+                                fp32 accumulation, fp32 softmax statistics.  Honoured by the 256-key window kernel and the long-sequence
+                                kernel (Hiera stage-3 windows / global blocks); shapes served by other kernels ignore it.  0 = off (default) */
 } cvmi_attn_desc;
 int cvmi_attention(const cvmi_attn_desc* d, cvmi_stream_t stream);
 

@@ -352,6 +352,111 @@ def test_attention_window_mode(dtype, q_pool, win):
     torch.testing.assert_close(od.float().cpu(), ref, **tol)
 
 
+def _fp8_av_emulation(q, k, v, scale, tile=64):
+    """The arithmetic cvmi_attn_desc.av_fp8 states, tile by tile as the kernels run it: per 64-key tile the running row maximum m, P = e4m3(exp(s - m)
+    * 2^8) / 2^8, V = e4m3(clamp(v, +-448)), O <- O * exp(m_old - m) + P V in fp32, row sums of the UNquantised p.  [.., Nq, d] x [.., Nk, d]."""
+    f8 = lambda t: t.to(torch.float8_e4m3fn).float()
+    s = (q @ k.transpose(-1, -2)) * scale
+    Nk = k.shape[-2]
+    m = torch.full(s.shape[:-1] + (1,), float("-inf"))
+    o = torch.zeros(q.shape[:-1] + (v.shape[-1],))
+    l = torch.zeros_like(m)
+    v8 = f8(v.clamp(-448, 448))
+    for k0 in range(0, Nk, tile):
+        st = s[..., k0:k0 + tile]
+        m_new = torch.maximum(m, st.amax(-1, keepdim=True))
+        alpha = torch.exp(m - m_new)
+        pt = torch.exp(st - m_new)
+        o = o * alpha + (f8(pt * 256.0) / 256.0) @ v8[..., k0:k0 + tile, :]
+        l = l * alpha + pt.sum(-1, keepdim=True)
+        m = m_new
+    return o / l
+
+
+def _check_fp8_av(name, got8, got16, ref, emu, dtype):
+    """(1) vs the emulation of the stated arithmetic: 1e-2 (+ the output's 16-bit rounding) -- a P element on a rounding boundary may flip by one
+    e4m3 step (measured r03: 5.5e-3 windows, 1.2e-3 global); (2) vs the fp32 reference ON THE CLAMPED V: the price of 3 mantissa bits on P and
+    V, bounded at 0.03 rms / 0.15 max for V of std 1.7 (measured: 2.0e-2 rms windows, 3e-3 rms / 3.7e-2 max global; the 16-bit product: 6e-3 max)."""
+    assert torch.isfinite(got8).all()
+    d_emu, d_ref = (got8 - emu).abs(), got8 - ref
+    print(f"{name}: fp8 AV vs emulation max {float(d_emu.max()):.2e}; vs fp32 reference max {float(d_ref.abs().max()):.2e} rms {float(d_ref.pow(2).mean().sqrt()):.2e}; "
+          f"16-bit AV vs fp32 reference max {float((got16 - ref).abs().max()):.2e}")
+    rt = 2.0 ** -10 if dtype == F16 else 2.0 ** -7                # the stored output's own rounding (11 / 8 significant bits), with head-room
+    assert bool((d_emu <= 1e-2 + rt * emu.abs()).all()), float((d_emu - rt * emu.abs()).max())
+    assert float(d_ref.abs().max()) <= 0.15 + rt * float(ref.abs().max()) and float(d_ref.pow(2).mean().sqrt()) <= 0.03
+
+
+@pytest.mark.parametrize("dtype", [F16, BF16])
+def test_attention_window_fp8_av_product(dtype):
+    """cvmi_attn_desc.av_fp8 (BASELINE configs[4] "fp8 MFMA attention") on Hiera's 16 x 16 windows (attn_res256_kernel<8, true>): softmax(QK^T) V
+    with P as e4m3 of p * 2^8 and V as e4m3 on the block-scaled fp8 MFMA, vs the emulation of that arithmetic and vs fp32."""
+    from circuitvision_amd.engine import TORCH_DTYPE
+    td = TORCH_DTYPE[dtype]
+    g = torch.Generator().manual_seed(17)
+    imgs, gh, gw, heads, hd, win = 2, 32, 48, 4, 72, 16
+    C_ = heads * hd
+    qkv = torch.randn(imgs, gh, gw, 3 * C_, generator=g)
+    qkv[..., 2 * C_:] *= 1.7                                      # V off the unit scale
+    qkv[0, 3, 5, 2 * C_ + 7] = 600.0                              # one V element beyond e4m3's 448: clamps (the conversion itself would give NaN)
+    qkv = quant(qkv, dtype)
+
+    def part(t):
+        t = t.view(imgs, gh // win, win, gw // win, win, heads, hd).permute(0, 1, 3, 2, 4, 5, 6)
+        return t.reshape(-1, win * win, heads, hd).transpose(1, 2)            # [nwin, heads, 256, hd]
+    q, k, v = (part(qkv[..., i * C_:(i + 1) * C_]) for i in range(3))
+    scale = hd ** -0.5
+    ref, emu = _attn_ref(q, k, v.clamp(-448, 448), scale), _fp8_av_emulation(q, k, v, scale)     # |v| <= 448 is part of the fp8 product's contract
+    unwin = lambda t: t.transpose(1, 2).reshape(imgs, gh // win, gw // win, win, win, C_).permute(0, 1, 3, 2, 4, 5).reshape(imgs, gh, gw, C_)
+    qkv_d = qkv.to(td).cuda().contiguous()
+    outs = {}
+    lib = _lib.load()
+    for fp8 in (1, 0):
+        od = torch.zeros(imgs, gh, gw, C_, dtype=td, device="cuda")
+        es = qkv_d.element_size()
+        desc = make_attn_desc(q=qkv_d.data_ptr(), k=qkv_d.data_ptr() + C_ * es, v=qkv_d.data_ptr() + 2 * C_ * es, o=od.data_ptr(),
+                              q_sb=0, q_sh=hd, q_st=3 * C_, k_sb=0, k_sh=hd, k_st=3 * C_, v_sb=0, v_sh=hd, v_st=3 * C_,
+                              o_sb=0, o_sh=hd, o_st=C_, B=imgs * (gh // win) * (gw // win), heads=heads, Nq=win * win, Nk=win * win, dqk=hd, dv=hd,
+                              scale=scale, dtype=dtype, win=win, grid_h=gh, grid_w=gw, q_pool=0, av_fp8=fp8)
+        plan = Plan(stream())
+        op_attention(plan, "t", desc, (qkv_d, od))
+        lib.cvmi_last_kernel()
+        run(plan)
+        assert lib.cvmi_last_kernel().decode() == ("attn_res256_kernel<8, true>" if fp8 else "attn_res256_kernel<8, false>")
+        outs[fp8] = od.float().cpu()
+    _check_fp8_av("16 x 16 windows", outs[1], outs[0], unwin(ref), unwin(emu), dtype)
+
+
+@pytest.mark.parametrize("dtype", [F16, BF16])
+@pytest.mark.parametrize("N", [1024, 600])
+def test_attention_global_fp8_av_product(dtype, N):
+    """The same on the long-sequence kernel (attn_dma72_kernel<8, true>: Hiera's global blocks), whole tiles and a ragged last tile."""
+    from circuitvision_amd.engine import TORCH_DTYPE
+    td = TORCH_DTYPE[dtype]
+    B, Hh, hd = 2, 3, 72
+    g = torch.Generator().manual_seed(19)
+    q = quant(torch.randn(B, Hh, N, hd, generator=g), dtype)
+    k = quant(torch.randn(B, Hh, N, hd, generator=g), dtype)
+    v = quant(torch.randn(B, Hh, N, hd, generator=g) * 1.7, dtype)
+    scale = hd ** -0.5
+    ref, emu = _attn_ref(q, k, v, scale), _fp8_av_emulation(q, k, v, scale)
+    qd, kd, vd = (t.permute(0, 2, 1, 3).reshape(B, N, Hh * hd).to(td).cuda().contiguous() for t in (q, k, v))
+    outs = {}
+    lib = _lib.load()
+    for fp8 in (1, 0):
+        od = torch.zeros(B, N, Hh * hd, dtype=td, device="cuda")
+        desc = make_attn_desc(q=qd.data_ptr(), k=kd.data_ptr(), v=vd.data_ptr(), o=od.data_ptr(),
+                              q_sb=N * Hh * hd, q_sh=hd, q_st=Hh * hd, k_sb=N * Hh * hd, k_sh=hd, k_st=Hh * hd,
+                              v_sb=N * Hh * hd, v_sh=hd, v_st=Hh * hd, o_sb=N * Hh * hd, o_sh=hd, o_st=Hh * hd,
+                              B=B, heads=Hh, Nq=N, Nk=N, dqk=hd, dv=hd, scale=scale, dtype=dtype, win=0, grid_h=0, grid_w=0, q_pool=0, av_fp8=fp8)
+        plan = Plan(stream())
+        op_attention(plan, "t", desc, (qd, kd, vd, od))
+        lib.cvmi_last_kernel()
+        run(plan)
+        assert lib.cvmi_last_kernel().decode() == ("attn_dma72_kernel<8, true>" if fp8 else "attn_dma72_kernel<8, false>")
+        outs[fp8] = od.float().cpu().view(B, N, Hh, hd).permute(0, 2, 1, 3)
+    _check_fp8_av(f"global N = {N}", outs[1], outs[0], ref, emu, dtype)
+
+
 def test_graph_capture_replays_identically():
     g = torch.Generator().manual_seed(9)
     x = quant(torch.randn(2, 32, 16, 16, generator=g), F16)

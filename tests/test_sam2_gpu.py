@@ -196,7 +196,7 @@ def test_hyper_masks_and_dynamic_selection():
     torch.testing.assert_close(iou_o.cpu(), i_ref.view(B))
 
 
-def _run_wrapper(hiera, targets, oracle_fn, image_size, dtype, B, seed=5):
+def _run_wrapper(hiera, targets, oracle_fn, image_size, dtype, B, seed=5, attn="16"):
     from circuitvision_amd.sam2 import Sam2Plan, Sam2Weights, SamSyntheticParams
     p = SamSyntheticParams(seed=seed, lora_targets=targets, std=0.05)
     wt = Sam2Weights(p, hiera, image_size, dtype)
@@ -204,7 +204,7 @@ def _run_wrapper(hiera, targets, oracle_fn, image_size, dtype, B, seed=5):
     x = torch.randn(B, 3, image_size, image_size, generator=torch.Generator().manual_seed(0)).to(TORCH_DTYPE[dtype]).float()
     with torch.no_grad():
         hi, lo, iou, inter = oracle(x, return_intermediates=True)
-    sp = Sam2Plan(wt, B, torch.cuda.Stream())
+    sp = Sam2Plan(wt, B, torch.cuda.Stream(), attn=attn)
     sp.x_in.t.copy_(x.permute(0, 2, 3, 1).to(TORCH_DTYPE[dtype]))
     torch.cuda.synchronize()
     sp.plan.run_eager()
@@ -264,6 +264,24 @@ def test_sam2_hiera_l_bf16_matches_oracle():
     a, b = sp.high_res.cpu() > 0, hi > 0
     iou_m = (a & b).sum().item() / max(1, (a | b).sum().item())
     print(f"Hiera-L bf16: binary-mask IoU vs the fp32 oracle {iou_m:.4f}")
+    assert iou_m >= 0.99
+
+
+@pytest.mark.parametrize("dtype", [BF16, F16])
+def test_sam2_hiera_l_fp8_attention_matches_oracle(dtype):
+    """BASELINE configs[4] "bf16 + fp8 MFMA attention" at B = 1: SAM 2.1 Hiera-L with the AV products of its 32 sixteen-by-sixteen-window blocks
+    and 3 global blocks on the block-scaled fp8 MFMA (P e4m3 x 2^8, V e4m3; `attn="fp8"`), everything else in the plan's 16-bit type, vs the
+    fp32 oracle.  Reported: logit error in units of the logits' std and the binary-mask IoU.  Bounds (e4m3 keeps 3 mantissa bits of V in 35 of
+    48 blocks): low-res logits within 0.25 std (max) / 0.05 std (rms) -- the bf16 test's bounds -- and mask IoU >= 0.99.  Measured r03:
+    fp16 + fp8 1.9e-2 / 3.3e-3 std, IoU 0.9996 (fp16 alone 8e-3 / 1.6e-3); bf16 + fp8 4.9e-2 / 1.1e-2 std, IoU 0.9988 (bf16 alone 5.9e-2 / 1.2e-2)."""
+    from circuitvision_amd.sam2 import HIERA_L, LORA_TARGETS_REFERENCE
+    sp, (hi, lo, iou, inter) = _run_wrapper(HIERA_L, LORA_TARGETS_REFERENCE, _hiera_l_oracle, 1024, dtype, B=1, attn="fp8")
+    kinds = [op[0] for op in sp.plan.ops if op[1] in ("attn_window", "attn_global")]
+    assert len(kinds) == 48
+    _assert_logits(f"Hiera-L {'bf16' if dtype == BF16 else 'f16'} + fp8 attention low-res logits", sp.low_res.cpu(), lo, 0.25, 0.05)
+    a, b = sp.high_res.cpu() > 0, hi > 0
+    iou_m = (a & b).sum().item() / max(1, (a | b).sum().item())
+    print(f"Hiera-L {'bf16' if dtype == BF16 else 'f16'} + fp8 attention: binary-mask IoU vs the fp32 oracle {iou_m:.4f}")
     assert iou_m >= 0.99
 
 
