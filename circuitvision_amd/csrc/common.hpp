@@ -15,6 +15,7 @@
 #ifdef CVMI_OPERAND_BF16
 typedef __bf16 f16;
 #define CVMI_MFMA_32X32X16 __builtin_amdgcn_mfma_f32_32x32x16_bf16
+#define CVMI_MFMA_16X16X32 __builtin_amdgcn_mfma_f32_16x16x32_bf16
 #define CVMI_FDOT2 __builtin_amdgcn_fdot2_f32_bf16
 #define CVMI_T16 CVMI_BF16
 #define CVMI_ENTRY(name) name##_bf16
@@ -23,6 +24,7 @@ typedef __bf16 f16;
 #else
 typedef _Float16 f16;
 #define CVMI_MFMA_32X32X16 __builtin_amdgcn_mfma_f32_32x32x16_f16
+#define CVMI_MFMA_16X16X32 __builtin_amdgcn_mfma_f32_16x16x32_f16
 #define CVMI_FDOT2 __builtin_amdgcn_fdot2
 #define CVMI_T16 CVMI_F16
 #define CVMI_ENTRY(name) name
@@ -108,6 +110,27 @@ __device__ __forceinline__ float gelu_fast(float v) {
   const float pl = fmaf(s, fmaf(s, 1.01426788e-03f, -1.06775760e-01f), -2.30112128e+00f);
   return v * fast_rcp(1.0f + __builtin_amdgcn_exp2f(v * pl));
 }
+
+// Two GELUs whose results are stored as a 16-bit pair (the fc1 epilogues of tok_linear / hiera_mlp: 8.8 G evaluations per SAM 2.1-L B = 16 pass,
+// ~3 ms of pure VALU time in the f32 form).  fp16 build: the same sigmoid(x P(x^2)) form evaluated in PACKED fp16 -- v_pk_mul / v_pk_min /
+// 2 x v_pk_fma / v_pk_mul / v_pk_add / v_pk_mul for the pair plus 2 x (v_exp_f16 + v_rcp_f16): 4.5 VALU + 2 transcendental issues per value
+// instead of 7 + 2, and the result is already the packed pair.  The argument of the exponential carries fp16's 2^-11 relative error
+// (|x P| <= 16 where the sigmoid is not yet 0 / 1 to fp16 precision: <= 0.5 % of a value that is itself <= 2^-16 of x there; 1e-3 relative
+// around |x| ~ 1), below the fp16 rounding of the stored result everywhere it matters.  bf16 build: no packed bf16 arithmetic on gfx950 --
+// two f32 evaluations.
+#ifndef CVMI_OPERAND_BF16
+__device__ __forceinline__ f16x2 gelu_fast_pk(float a, float b) {
+  const f16x2 v = {(f16)a, (f16)b};
+  const f16x2 s = __builtin_elementwise_min(v * v, (f16x2){(f16)64.f, (f16)64.f});
+  const f16x2 pl = s * (s * (f16x2){(f16)1.01426788e-03f, (f16)1.01426788e-03f} + (f16x2){(f16)-1.06775760e-01f, (f16)-1.06775760e-01f}) +
+                   (f16x2){(f16)-2.30112128e+00f, (f16)-2.30112128e+00f};
+  const f16x2 arg = v * pl;
+  const f16x2 d = (f16x2){(f16)__builtin_exp2f16(arg[0]), (f16)__builtin_exp2f16(arg[1])} + (f16x2){(f16)1.f, (f16)1.f};
+  return v * (f16x2){(f16)__builtin_amdgcn_rcph(d[0]), (f16)__builtin_amdgcn_rcph(d[1])};
+}
+#else
+__device__ __forceinline__ f16x2 gelu_fast_pk(float a, float b) { return (f16x2){(f16)gelu_fast(a), (f16)gelu_fast(b)}; }
+#endif
 
 // FAST = true: v_exp/v_rcp based (fp16 storage mode); false: precise libm (f32 parity mode)
 template <bool FAST> __device__ __forceinline__ float act_apply(float v, int act) {

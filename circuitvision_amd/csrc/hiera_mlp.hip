@@ -153,7 +153,11 @@ __global__ __launch_bounds__(MlpCfg<C>::NW * 64, MlpCfg<C>::WPS) void hiera_mlp_
       if (f + PF < FR) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(ring[f % PF]) : "v"(lbase), "i"((f + PF) * 1024));
       if (f == KS1 - 1) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) pf[r >> 3][r & 7] = (f16)gelu_fast(hacc[r]);
+        for (int r = 0; r < 16; r += 2) {
+          const f16x2 g2 = gelu_fast_pk(hacc[r], hacc[r + 1]);
+          pf[r >> 3][r & 7] = g2[0];
+          pf[r >> 3][(r & 7) + 1] = g2[1];
+        }
       }
     }
   }

@@ -1123,7 +1123,12 @@ int launch_g256p(ConvKArgs& a, hipStream_t stream) {
 //     phase (t,1): WC2(t+1)      (t,2): X0(t+2), WC0(t+2)      (t,3): X1(t+2), WC1(t+2)
 // and one counted wait per K-tile, vmcnt(6) in phase 3 (all but the six instructions of phases 2 and 3, i.e. all of tile
 // t+1, has landed).  Hazard argument as for gemm256_kernel (reads retired before a phase's first barrier).
-template <typename TO>
+// M16 = true: the same tile, DMA schedule and barriers on v_mfma_f32_16x16x32 (16 per phase instead of 8 of 32x32x16: equal cycles per
+// flop, equal LDS bytes -- every lane still reads 16 bytes per fragment -- but the chip holds a higher clock on this shape under the
+// power limit: MI355X_MICROARCH.md, DVFS give-back item 7).  Fragment (16 rows x 32 k): lane (r16 = lane & 15, g = lane >> 4) reads chunk
+// 4 ks + g of row r16; with the source swizzle slot = chunk ^ ((row >> 1) & 7) a 16-lane ds_read_b128 group still covers the 16 slots of
+// a 256-byte bank period once.  C / D: lane holds channels 4 g .. 4 g + 3 (rows, from the weight operand) of pixel r16.
+template <typename TO, bool M16 = false>
 __global__ __launch_bounds__(512, 1) void gemm256x192_kernel(const ConvKArgs p) {
   using T = f16;
   constexpr int BM = 256, BN = 192, BKB = 128;
@@ -1172,19 +1177,28 @@ __global__ __launch_bounds__(512, 1) void gemm256x192_kernel(const ConvKArgs p) 
 #define G192_X1(stage, kt) do { G192_ISSUE1(2, stage, kt); G192_ISSUE1(3, stage, kt); } while (0)
 #define G192_WC(k, stage, kt) G192_ISSUE1(4 + (k), stage, kt)
 
-  f32x16 acc[3][2];
+  f32x16 acc[3][2];                                       // 32x32x16: [channel block][pixel block]
+  f32x4 acc16[3][2][4];                                   // 16x16x32: [channel block][16-channel half][16-pixel block]
 #pragma unroll
   for (int i = 0; i < 3; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < 2; ++j) {
+      if constexpr (M16) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        for (int q = 0; q < 4; ++q) acc16[i][j][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+      }
+    }
 
-  const int sw = (lr >> 1) & 7;
+  const int r16 = lane & 15, g16 = lane >> 4;
+  const int sw = M16 ? (r16 >> 1) & 7 : (lr >> 1) & 7;
   int ko[4];
 #pragma unroll
-  for (int s2 = 0; s2 < 4; ++s2) ko[s2] = ((2 * s2 + lh) ^ sw) << 4;
-  const int xbase = (wp * 64 + lr) * BKB, wbase = (BM + wh * 96 + lr) * BKB;
+  for (int s2 = 0; s2 < 4; ++s2) ko[s2] = M16 ? (((4 * (s2 & 1) + g16) ^ sw) << 4) + (s2 >> 1) * 16 * BKB      // s2 = ks + 2 * (16-row half)
+                                             : ((2 * s2 + lh) ^ sw) << 4;
+  const int xbase = (wp * 64 + (M16 ? r16 : lr)) * BKB, wbase = (BM + wh * 96 + (M16 ? r16 : lr)) * BKB;
 
   G192_X0(0, 0); G192_WC(0, 0, 0); G192_X1(0, 0); G192_WC(1, 0, 0); G192_WC(2, 0, 0);
   if (nk > 1) {
@@ -1218,13 +1232,24 @@ __global__ __launch_bounds__(512, 1) void gemm256x192_kernel(const ConvKArgs p) 
     __builtin_amdgcn_s_barrier();                                                                                        \
     __builtin_amdgcn_sched_barrier(0);                                                                                   \
   } while (0)
+  // M16: wf[ks + 2 hh] = channels 16 hh .. of block i, k-step ks; xf[j][ks + 2 ph] = pixels 32 j + 16 ph .., k-step ks
 #define G192_MMA(i)                                                                                                      \
   asm volatile("" : "+v"(wf[0]), "+v"(wf[1]), "+v"(wf[2]), "+v"(wf[3]));                                                 \
-  _Pragma("unroll") for (int s2 = 0; s2 < 4; ++s2) {                                                                     \
-    Mma<T>::run(wf[s2], xf[0][s2], acc[i][0]);                                                                           \
-    Mma<T>::run(wf[s2], xf[1][s2], acc[i][1]);                                                                           \
-  }                                                                                                                      \
-  asm volatile("" : "+v"(acc[i][0]), "+v"(acc[i][1]))
+  if constexpr (M16) {                                                                                                   \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                                     \
+    _Pragma("unroll") for (int hh = 0; hh < 2; ++hh)                                                                     \
+    _Pragma("unroll") for (int pq = 0; pq < 4; ++pq)                                                                     \
+      acc16[i][hh][pq] = CVMI_MFMA_16X16X32(__builtin_bit_cast(f16x8, wf[ks + 2 * hh]),                                  \
+                                            __builtin_bit_cast(f16x8, xf[pq >> 1][ks + 2 * (pq & 1)]), acc16[i][hh][pq], 0, 0, 0); \
+    asm volatile("" : "+v"(acc16[i][0][0]), "+v"(acc16[i][0][1]), "+v"(acc16[i][0][2]), "+v"(acc16[i][0][3]),            \
+                      "+v"(acc16[i][1][0]), "+v"(acc16[i][1][1]), "+v"(acc16[i][1][2]), "+v"(acc16[i][1][3]));           \
+  } else {                                                                                                               \
+    _Pragma("unroll") for (int s2 = 0; s2 < 4; ++s2) {                                                                   \
+      Mma<T>::run(wf[s2], xf[0][s2], acc[i][0]);                                                                         \
+      Mma<T>::run(wf[s2], xf[1][s2], acc[i][1]);                                                                         \
+    }                                                                                                                    \
+    asm volatile("" : "+v"(acc[i][0]), "+v"(acc[i][1]));                                                                 \
+  }
 
   for (int kt = 0; kt < nk; ++kt) {
     const int b = kt & 1;
@@ -1236,13 +1261,13 @@ __global__ __launch_bounds__(512, 1) void gemm256x192_kernel(const ConvKArgs p) 
     G192_READ_X(1);
     if (more1) G192_WC(2, b ^ 1, kt + 1);
     G192_SYNC_IN();
-    G192_MMA(0);
+    G192_MMA(0)
     G192_SYNC_OUT();
     // ---- phase 2
     G192_READ_W(1);
     if (more2) { G192_X0(b, kt + 2); G192_WC(0, b, kt + 2); }
     G192_SYNC_IN();
-    G192_MMA(1);
+    G192_MMA(1)
     G192_SYNC_OUT();
     // ---- phase 3
     G192_READ_W(2);
@@ -1253,7 +1278,7 @@ __global__ __launch_bounds__(512, 1) void gemm256x192_kernel(const ConvKArgs p) 
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     G192_SYNC_IN();
-    G192_MMA(2);
+    G192_MMA(2)
     G192_SYNC_OUT();
   }
   if (wh == 0) __builtin_amdgcn_s_barrier();
@@ -1293,6 +1318,32 @@ __global__ __launch_bounds__(512, 1) void gemm256x192_kernel(const ConvKArgs p) 
     if (NPASS == 1 || wh == pass) {
       const int cbase = NPASS == 1 ? wh * 96 : 0;
       with_act<true>(p.act_after_res ? CVMI_ACT_NONE : p.act, [&](auto actf) {
+        if constexpr (M16) {
+#pragma unroll
+          for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+              const int nl = cbase + i * 32 + hh * 16 + 4 * g16;
+              const int n = n0 + pass * CW + nl;
+              f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+              if (n < p.N) bv = *reinterpret_cast<const f32x4*>(p.bias + n);
+#pragma unroll
+              for (int pq = 0; pq < 4; ++pq) {
+                const int ml = wp * 64 + pq * 16 + r16;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = actf(acc16[i][hh][pq][e] + bv[e]);
+                char* d = Ct + ml * CROWB + nl * OES;
+                if constexpr (OES == 2) {
+                  f16x4 hv = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
+                  *reinterpret_cast<f16x4*>(d) = hv;
+                } else {
+                  f32x4 fv = {v[0], v[1], v[2], v[3]};
+                  *reinterpret_cast<f32x4*>(d) = fv;
+                }
+              }
+            }
+        } else
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
 #pragma unroll
@@ -1380,14 +1431,17 @@ int launch_g256x192(ConvKArgs& a, hipStream_t stream) {
   constexpr int bytes = lds > epi ? lds : epi;
   static bool attr_done = false;
   if (!attr_done) {
-    CVMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256x192_kernel<TO>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    CVMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256x192_kernel<TO, false>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    CVMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256x192_kernel<TO, true>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
     attr_done = true;
   }
   a.nb_n = cdiv(a.N, 192);
   const long long blocks = (long long)cdiv(a.M, 256) * a.nb_n;
   CVMI_CHECK(blocks > 0 && blocks < (1ll << 31), "conv2d: bad grid %lld", blocks);
-  cvmi_note_kernel("gemm256x192_kernel<%s>", sizeof(TO) == 2 ? CVMI_F16NAME : "float");
-  hipLaunchKernelGGL((gemm256x192_kernel<TO>), dim3((unsigned)blocks), dim3(512), bytes, stream, a);
+  static const int m16 = getenv("CVMI_G192_M16") ? atoi(getenv("CVMI_G192_M16")) : 1;        // MFMA shape: 1 = 16x16x32, 0 = 32x32x16 (A/B runs)
+  cvmi_note_kernel("gemm256x192_kernel<%s, %s>", sizeof(TO) == 2 ? CVMI_F16NAME : "float", CVMI_BOOLNAME(m16));
+  if (m16) hipLaunchKernelGGL((gemm256x192_kernel<TO, true>), dim3((unsigned)blocks), dim3(512), bytes, stream, a);
+  else hipLaunchKernelGGL((gemm256x192_kernel<TO, false>), dim3((unsigned)blocks), dim3(512), bytes, stream, a);
   CVMI_LAUNCH_CHECK();
   return 0;
 }

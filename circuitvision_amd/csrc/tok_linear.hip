@@ -221,8 +221,13 @@ __global__ __launch_bounds__(TL_NW * 64, 2) void tok_linear_kernel(const void* _
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         f16x4 h4;
+        if constexpr (GELU) {
+          const f16x2 lo2 = gelu_fast_pk(acc[4 * g], acc[4 * g + 1]), hi2 = gelu_fast_pk(acc[4 * g + 2], acc[4 * g + 3]);
+          h4 = (f16x4){lo2[0], lo2[1], hi2[0], hi2[1]};
+        } else {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) h4[e] = (f16)(GELU ? gelu_fast(acc[4 * g + e]) : acc[4 * g + e]);
+          for (int e = 0; e < 4; ++e) h4[e] = (f16)acc[4 * g + e];
+        }
         *reinterpret_cast<f16x4*>(stage + lr * 80 + (8 * g + 4 * lh) * 2) = h4;
       }
       const int sr = lane >> 2, pc = lane & 3;
@@ -237,8 +242,13 @@ __global__ __launch_bounds__(TL_NW * 64, 2) void tok_linear_kernel(const void* _
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         f16x4 h4;
+        if constexpr (GELU) {
+          const f16x2 lo2 = gelu_fast_pk(acc[4 * g], acc[4 * g + 1]), hi2 = gelu_fast_pk(acc[4 * g + 2], acc[4 * g + 3]);
+          h4 = (f16x4){lo2[0], lo2[1], hi2[0], hi2[1]};
+        } else {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) h4[e] = (f16)(GELU ? gelu_fast(acc[4 * g + e]) : acc[4 * g + e]);
+          for (int e = 0; e < 4; ++e) h4[e] = (f16)acc[4 * g + e];
+        }
         if (32 * j + 8 * g + 4 * lh < N) *reinterpret_cast<f16x4*>(o + 8 * g) = h4;
       }
     }

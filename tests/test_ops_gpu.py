@@ -373,7 +373,7 @@ def _fp8_av_emulation(q, k, v, scale, tile=64):
     return o / l
 
 
-def _check_fp8_av(name, got8, got16, ref, emu, dtype):
+def _check_fp8_av(name, got8, got16, ref, emu, dtype, absref):
     """(1) vs the emulation of the stated arithmetic: 1e-2 (+ the output's 16-bit rounding) -- a P element on a rounding boundary may flip by one
     e4m3 step (measured r03: 5.5e-3 windows, 1.2e-3 global); (2) vs the fp32 reference ON THE CLAMPED V: the price of 3 mantissa bits on P and
     V, bounded at 0.03 rms / 0.15 max for V of std 1.7 (measured: 2.0e-2 rms windows, 3e-3 rms / 3.7e-2 max global; the 16-bit product: 6e-3 max)."""
@@ -383,7 +383,11 @@ def _check_fp8_av(name, got8, got16, ref, emu, dtype):
           f"16-bit AV vs fp32 reference max {float((got16 - ref).abs().max()):.2e}")
     rt = 2.0 ** -10 if dtype == F16 else 2.0 ** -7                # the stored output's own rounding (11 / 8 significant bits), with head-room
     assert bool((d_emu <= 1e-2 + rt * emu.abs()).all()), float((d_emu - rt * emu.abs()).max())
-    assert float(d_ref.abs().max()) <= 0.15 + rt * float(ref.abs().max()) and float(d_ref.pow(2).mean().sqrt()) <= 0.03
+    # e4m3 rounds P and V to 3 mantissa bits each (relative step 2^-3, error <= 2^-4 each): |err| <= (2^-4 + 2^-4 + 2^-8) sum_k p |v| in the worst
+    # case, far less on average (rms bound below)
+    bound = 0.13 * absref + 1e-2 + rt * ref.abs()
+    assert bool((d_ref.abs() <= bound).all()), float((d_ref.abs() - bound).max())
+    assert float(d_ref.pow(2).mean().sqrt()) <= 0.03
 
 
 @pytest.mark.parametrize("dtype", [F16, BF16])
@@ -423,7 +427,7 @@ def test_attention_window_fp8_av_product(dtype):
         run(plan)
         assert lib.cvmi_last_kernel().decode() == ("attn_res256_kernel<8, true>" if fp8 else "attn_res256_kernel<8, false>")
         outs[fp8] = od.float().cpu()
-    _check_fp8_av("16 x 16 windows", outs[1], outs[0], unwin(ref), unwin(emu), dtype)
+    _check_fp8_av("16 x 16 windows", outs[1], outs[0], unwin(ref), unwin(emu), dtype, unwin(_attn_ref(q, k, v.clamp(-448, 448).abs(), scale)))
 
 
 @pytest.mark.parametrize("dtype", [F16, BF16])
@@ -454,7 +458,7 @@ def test_attention_global_fp8_av_product(dtype, N):
         run(plan)
         assert lib.cvmi_last_kernel().decode() == ("attn_dma72_kernel<8, true>" if fp8 else "attn_dma72_kernel<8, false>")
         outs[fp8] = od.float().cpu().view(B, N, Hh, hd).permute(0, 2, 1, 3)
-    _check_fp8_av(f"global N = {N}", outs[1], outs[0], ref, emu, dtype)
+    _check_fp8_av(f"global N = {N}", outs[1], outs[0], ref, emu, dtype, _attn_ref(q, k, v.abs(), scale))
 
 
 def test_graph_capture_replays_identically():
