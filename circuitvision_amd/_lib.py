@@ -104,6 +104,7 @@ SIGNATURES = {
     "cvmi_hiera_mlp_stats": (_i, [_vp, _i, _vp, _vp, _f, _vp, _vp, C.c_longlong, _i, _i, _vp, _f, _vp]),
     "cvmi_tok_linear_supported": (_i, [_i]),
     "cvmi_tok_linear_packed_bytes": (C.c_size_t, [_i, _i]),
+    "cvmi_tok_linear_format": (_i, [_i]),
     "cvmi_tok_linear": (_i, [_vp, _i, _i, _vp, _vp, _f, _vp, _vp, _i, _i, C.c_longlong, _i, _i, _i, _i, _vp]),
     "cvmi_tok_linear_stats": (_i, [_vp, _i, _i, _vp, _vp, _f, _vp, _vp, _i, _i, C.c_longlong, _i, _i, _i, _i, _vp, _i, _vp, _f, _vp]),
     "cvmi_tok_linear_pool_stats": (_i, [_vp, _i, _vp, _vp, _f, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),

@@ -68,7 +68,7 @@ extern "C" int cvmi_graph_end(cvmi_stream_t stream, void** graph_exec_out) {
   CVMI_CHECK(graph, "graph_end: capture produced no graph (a captured call failed)");
   hipGraphExec_t exec = nullptr;
   hipError_t e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-  hipGraphDestroy(graph);
+  (void)hipGraphDestroy(graph);
   if (e != hipSuccess) CVMI_FAIL("hipGraphInstantiate failed: %s", hipGetErrorString(e));
   *graph_exec_out = (void*)exec;
   return 0;

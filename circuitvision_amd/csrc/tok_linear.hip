@@ -484,7 +484,18 @@ int dispatch_tl(int ln, bool res, int act, const void* in, int in_ld, const floa
 
 }  // namespace
 
+// K = 576 is served by tok_linear16.hip (16x16x32 MFMA shape, its own packed-weight format) unless CVMI_TOKLIN_M16=0 (A/B runs)
+int CVMI_ENTRY(cvmi_tok_linear16_launch)(int K, int ln, bool res, bool gelu, const void* in, int in_ld, const float* gamma, const float* beta, float eps,
+                                         const void* wp, void* out, int out_ld, long long rows, int N, int pool_w, int pool_hw2, const float* stats_in,
+                                         int stats_parts, float* stats_out, float stats_eps, hipStream_t s);
+static int tl_format(int K) {
+  static const int m16 = getenv("CVMI_TOKLIN_M16") ? atoi(getenv("CVMI_TOKLIN_M16")) : 1;
+  return (m16 && K == 576) ? 16 : 32;
+}
+
 #ifndef CVMI_OPERAND_BF16
+extern "C" int cvmi_tok_linear_format(int K) { return tl_format(K); }
+
 // diagnostic: read and clear the segment sums of the CVMI_TOKLIN_STAMP build.  Ping-pong schedule: [0 .. 8] = wave 0 {b1 wait, MFMAs, vmcnt wait,
 // b2 wait, epilogue, prefetch issue, total, chunks, launches}, [12 .. 20] = wave 4 {b1 wait, epilogue, b2 wait, MFMAs, vmcnt wait, prefetch issue,
 // total, chunks, launches}.  One-barrier schedule (CVMI_TOKLIN_PP=0): [0 .. 6] = {vmcnt wait, barrier, issue, MFMAs, total, chunks, launches}.
@@ -499,6 +510,7 @@ extern "C" int cvmi_tok_linear_supported(int K) { return K == 144 || K == 288 ||
 
 extern "C" size_t cvmi_tok_linear_packed_bytes(int K, int N) {
   if (!cvmi_tok_linear_supported(K) || N <= 0) return 0;
+  if (tl_format(K) == 16) return (size_t)((N + 31) / 32) * (size_t)(K / 16 + 1) * 1024;     // 2 K/32 weight fragments + the bias piece per chunk
   return (size_t)(((N + 31) / 32 + 1) / 2 * 2) * (size_t)(K / 16 + 1) * 1024;        // chunk count padded to even
 }
 extern "C" int cvmi_tok_linear_stats_bf16(const void* in, int in_ld, int in_f32_layernorm, const float* gamma, const float* beta, float eps,
@@ -536,6 +548,9 @@ extern "C" int CVMI_ENTRY(cvmi_tok_linear_stats)(const void* in, int in_ld, int 
   hipStream_t s = (hipStream_t)stream_;
   const int ln = in_f32_layernorm;
   const bool res = out_f32_residual != 0;
+  if (tl_format(K) == 16)
+    return CVMI_ENTRY(cvmi_tok_linear16_launch)(K, ln, res, act == CVMI_ACT_GELU, in, in_ld, gamma, beta, eps, w_packed, out, out_ld, rows, N, 0, 0, ln_stats_in,
+                                                ln_stats_in_parts, ln_stats_out, ln_stats_eps, s);
   const TlExtra ex{0, 0, ln_stats_in, ln_stats_out, ln_stats_eps, ln_stats_in_parts};
   switch (K) {
     case 144: return dispatch_tl<144>(ln, res, act, in, in_ld, gamma, beta, eps, w_packed, out, out_ld, rows, N, s, ex);
@@ -577,6 +592,8 @@ extern "C" int CVMI_ENTRY(cvmi_tok_linear_pool_stats)(const void* in, int in_ld,
              "tok_linear_pool: pointers / ld not aligned (in_ld=%d out_ld=%d N=%d)", in_ld, out_ld, N);
   hipStream_t s = (hipStream_t)stream_;
   const int hw2 = (H / 2) * (W / 2);
+  if (tl_format(K) == 16)
+    return CVMI_ENTRY(cvmi_tok_linear16_launch)(K, 1, false, false, in, in_ld, gamma, beta, eps, w_packed, out, out_ld, rows, N, W, hw2, ln_stats_in, 0, nullptr, 0.f, s);
   switch (K) {
     case 144: return launch_tl1<144, 1, false, false, false, false, true, true>(in, in_ld, gamma, beta, eps, w_packed, out, out_ld, rows, N, s, TlExtra{W, hw2, ln_stats_in, nullptr, 0.f, 0});
     case 288: return launch_tl1<288, 1, false, false, false, false, true, true>(in, in_ld, gamma, beta, eps, w_packed, out, out_ld, rows, N, s, TlExtra{W, hw2, ln_stats_in, nullptr, 0.f, 0});

@@ -570,6 +570,23 @@ class PackedTokLinear:
         N, K = w.shape                                       # float32, LoRA already merged; dtype: F16 or BF16 operands
         td = TORCH_DTYPE[dtype]
         assert K % 16 == 0
+        if _lib.load().cvmi_tok_linear_format(K) == 16:      # 16x16x32 MFMA fragments + an f32 bias piece per chunk (include/cvmi355.h)
+            nch, ks = (N + 31) // 32, K // 32
+            b = b if b is not None else torch.zeros(N)
+            wx = torch.zeros(nch * 32, K)
+            wx[:N] = w
+            frag = wx.view(nch, 2, 16, ks, 4, 8).permute(0, 3, 1, 4, 2, 5).reshape(nch, ks * 2 * 512)      # (j, s, hh, g, r16, e)
+            bias = torch.zeros(nch * 32)
+            bias[:N] = b
+            piece = torch.zeros(nch, 512, dtype=torch.int16)
+            piece[:, :64] = bias.view(nch, 32).contiguous().view(torch.int16)
+            packed = torch.cat((frag.to(td).contiguous().view(torch.int16), piece), 1).contiguous()
+            assert packed.numel() * 2 == _lib.load().cvmi_tok_linear_packed_bytes(K, N)
+            self.w = packed.to(device)
+            self.bias = torch.zeros(4, device=device)
+            self.N, self.K, self.dtype = N, K, dtype
+            self.param_bytes = N * K * 2
+            return
         ks1, nch = K // 16 + 1, ((N + 31) // 32 + 1) // 2 * 2       # chunk count padded to even (the kernel may take two per barrier)
         b = b if b is not None else torch.zeros(N)
         b_hi = b.to(td).float()

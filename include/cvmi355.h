@@ -277,6 +277,11 @@ int cvmi_hiera_mlp_stats(void* x, int x_ld, const float* gamma, const float* bet
  * cvmi_tok_linear_packed_bytes(K, N) = ceil(N/32) * (K/16 + 1) * 1024. */
 int cvmi_tok_linear_supported(int K);
 size_t cvmi_tok_linear_packed_bytes(int K, int N);
+/* Packed-weight format the library expects for this K: 32 = the layout above (32x32x16 MFMA fragments, bias on an extra k-step);
+ * 16 (K = 576) = fragments of the 16x16x32 MFMA shape: ceil(N/32) chunks of 2 K/32 + 1 pieces of 1 KiB, piece (j, 2 s + hh), lane l
+ * (r16 = l & 15, g = l >> 4), element e:  W[32 j + 16 hh + r16][32 s + 8 g + e]  (rows >= N zero);  the chunk's last piece holds its 32 bias
+ * values as f32 in its first 128 bytes (rest zero).  cvmi_tok_linear_packed_bytes follows the format. */
+int cvmi_tok_linear_format(int K);
 int cvmi_tok_linear(const void* in, int in_ld, int in_f32_layernorm, const float* gamma, const float* beta, float eps,
                     const void* w_packed, void* out, int out_ld, int out_f32_residual, long long rows, int K, int N, int act,
                     int dtype /* CVMI_F16 | CVMI_BF16: type of w_packed and of the 16-bit input / output */, cvmi_stream_t stream);
