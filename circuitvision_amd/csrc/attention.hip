@@ -27,6 +27,7 @@ struct AttnArgs {
   int q_bdiv, kv_bdiv;   // batch sharing (no window): q rows of batch entry b come from entry b / q_bdiv, k / v rows from b / kv_bdiv
   int qtiles;      // ceil(Nq / 32)
   int items;       // B * heads * qtiles
+  float defer;     // deferred-rescale threshold in log2 units (DEFER_LOG2; CVMI_ATTN_DEFER=0 restores "rescale on every new maximum" for A/B runs)
   int xcd;         // 1: XCD-aware workgroup order (xcd_order below); 0: natural order (CVMI_ATTN_XCD=0, A/B runs only)
   FastDiv div_win; // window mode: key -> (row, column) inside the window without a hardware division
 };
@@ -37,6 +38,26 @@ struct AttnArgs {
 // see into an asm statement, so an asm v_max3 reading an MFMA result gets no XDL-write -> VALU-read wait states and returns stale
 // accumulators now and then (measured: replays of the same graph differed in the last bits -- tests/*_replay_properties).
 __device__ __forceinline__ float max3f(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
+
+// Values of the two lane halves (lane, lane ^ 32) combined without LDS: __shfl_xor(x, 32) compiles to ds_bpermute_b32 -- an LDS round trip on
+// the softmax's critical path, twice per key tile; v_permlane32_swap exchanges the halves in the VALU (r[0], r[1] = {own, partner} in one
+// order or the other, which max and + do not care about).
+__device__ __forceinline__ float xhalf_max(float x) {
+  const int xi = __builtin_bit_cast(int, x);
+  const auto r = __builtin_amdgcn_permlane32_swap(xi, xi, false, false);
+  return fmaxf(__builtin_bit_cast(float, (int)r[0]), __builtin_bit_cast(float, (int)r[1]));
+}
+__device__ __forceinline__ float xhalf_sum(float x) {
+  const int xi = __builtin_bit_cast(int, x);
+  const auto r = __builtin_amdgcn_permlane32_swap(xi, xi, false, false);
+  return __builtin_bit_cast(float, (int)r[0]) + __builtin_bit_cast(float, (int)r[1]);
+}
+// Deferred rescaling of the online softmax: the running reference m of a row only moves when the tile's maximum exceeds it by more than
+// DEFER_LOG2 in the exponent's (log2) units; until then P = exp2((s - m) c) may reach 2^DEFER_LOG2 -- 256: exact powers of two away from
+// overflow in fp16 / bf16 P and in the fp32 sums -- and the accumulator rescale (48 multiplies per lane, taken whenever ANY of the wave's rows
+// saw a new maximum: almost every tile) becomes rare.  Everything at the old scale is rescaled exactly once when the reference does move:
+// O and l here, and no P is pending (it is exponentiated after the decision).  The e4m3 product keeps DEFER = 0: its P is scaled by 2^8 already.
+constexpr float DEFER_LOG2 = 8.0f;
 
 // XCD-aware workgroup order (speed only, bijective for any grid size).  Workgroups are dealt round-robin over the 8 XCDs, each with a
 // private L2.  With the natural order the 8 heads of one window -- whose 144-byte K / V rows share 128-byte lines of the interleaved
@@ -787,9 +808,11 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_res256_kernel(const AttnArgs 
 #pragma unroll
     for (int r = 2; r < 8; ++r) { mxa = max3f(mxa, sacc[0][r], sacc[1][r]); mxb = max3f(mxb, sacc[0][r + 7], sacc[1][r + 7]); }
     const float mx = max3f(mxa, mxb, max3f(sacc[0][15], sacc[1][15], mxa));
-    const float m_new = max3f(m_run, mx, __shfl_xor(mx, 32));
+    const float m_top = fmaxf(m_run, xhalf_max(mx));
+    const bool grow = (m_top - m_run) * c > (AV8 ? 0.f : p.defer);      // first tile: m_run = -inf -> true
+    const float m_new = grow ? m_top : m_run;
     const float mc = m_new * c;
-    const float alpha = __builtin_amdgcn_exp2f(fmaf(m_run, c, -mc));
+    const float alpha = grow ? __builtin_amdgcn_exp2f(fmaf(m_run, c, -mc)) : 1.0f;
     float psum = 0.f;
     f16x8 pf[2][2];
     u32x4 p8[2];                                            // AV8: this lane's 32 e4m3 bytes of P^T (tile u -> bytes 16 u .. 16 u + 15)
@@ -818,11 +841,12 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_res256_kernel(const AttnArgs 
           pf[u][r >> 3][r & 7] = (f16)pv;
         }
     }
-    psum += __shfl_xor(psum, 32);
+    psum = xhalf_sum(psum);
     l_run = l_run * alpha + psum;
     const float m_prev = m_run;
     m_run = m_new;
-    if (__any(m_new != m_prev)) {
+    if (__any(grow)) {                                      // (a real branch: rare once the first tiles have set the reference)
+      asm volatile("" ::: "memory");
 #pragma unroll
       for (int t = 0; t < DT; ++t)
 #pragma unroll
@@ -992,9 +1016,11 @@ __global__ __launch_bounds__(QT * 128, 4) void attn_res64_kernel(const AttnArgs 
 #pragma unroll
     for (int r = 2; r < 8; ++r) { mxa = max3f(mxa, sacc[0][r], sacc[1][r]); mxb = max3f(mxb, sacc[0][r + 7], sacc[1][r + 7]); }
     const float mx = max3f(mxa, mxb, max3f(sacc[0][15], sacc[1][15], mxa));
-    const float m_new = max3f(m_run, mx, __shfl_xor(mx, 32));
+    const float m_top = fmaxf(m_run, xhalf_max(mx));
+    const bool grow = (m_top - m_run) * c > p.defer;      // first tile: m_run = -inf -> true
+    const float m_new = grow ? m_top : m_run;
     const float mc = m_new * c;
-    const float alpha = __builtin_amdgcn_exp2f(fmaf(m_run, c, -mc));
+    const float alpha = grow ? __builtin_amdgcn_exp2f(fmaf(m_run, c, -mc)) : 1.0f;
     float psum = 0.f;
     f16x8 pf[2][2];
 #pragma unroll
@@ -1005,11 +1031,12 @@ __global__ __launch_bounds__(QT * 128, 4) void attn_res64_kernel(const AttnArgs 
         psum += pv;
         pf[u][r >> 3][r & 7] = (f16)pv;
       }
-    psum += __shfl_xor(psum, 32);
+    psum = xhalf_sum(psum);
     l_run = l_run * alpha + psum;
     const float m_prev = m_run;
     m_run = m_new;
-    if (__any(m_new != m_prev)) {
+    if (__any(grow)) {                                      // (a real branch: rare once the first tiles have set the reference)
+      asm volatile("" ::: "memory");
 #pragma unroll
       for (int t = 0; t < DT; ++t)
 #pragma unroll
@@ -1222,9 +1249,11 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_dma72_kernel(const AttnArgs p
 #pragma unroll
     for (int r = 2; r < 8; ++r) { mxa = max3f(mxa, sacc[0][r], sacc[1][r]); mxb = max3f(mxb, sacc[0][r + 7], sacc[1][r + 7]); }
     const float mx = max3f(mxa, mxb, max3f(sacc[0][15], sacc[1][15], mxa));
-    const float m_new = max3f(m_run, mx, __shfl_xor(mx, 32));
+    const float m_top = fmaxf(m_run, xhalf_max(mx));
+    const bool grow = (m_top - m_run) * c > (AV8 ? 0.f : p.defer);      // first tile: m_run = -inf -> true
+    const float m_new = grow ? m_top : m_run;
     const float mc = m_new * c;
-    const float alpha = __builtin_amdgcn_exp2f(fmaf(m_run, c, -mc));
+    const float alpha = grow ? __builtin_amdgcn_exp2f(fmaf(m_run, c, -mc)) : 1.0f;
     float psum = 0.f;
     f16x8 pf[2][2];
     u32x4 p8[2];
@@ -1253,11 +1282,12 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_dma72_kernel(const AttnArgs p
           pf[u][r >> 3][r & 7] = (f16)pv;
         }
     }
-    psum += __shfl_xor(psum, 32);
+    psum = xhalf_sum(psum);
     l_run = l_run * alpha + psum;
     const float m_prev = m_run;
     m_run = m_new;
-    if (__any(m_new != m_prev)) {
+    if (__any(grow)) {                                      // (a real branch: rare once the first tiles have set the reference)
+      asm volatile("" ::: "memory");
 #pragma unroll
       for (int t = 0; t < DT; ++t)
 #pragma unroll
@@ -1609,6 +1639,8 @@ extern "C" int CVMI_ENTRY(cvmi_attention)(const cvmi_attn_desc* d, cvmi_stream_t
   a.items = d->B * d->heads * a.qtiles;
   static const int use_xcd = getenv("CVMI_ATTN_XCD") ? atoi(getenv("CVMI_ATTN_XCD")) : 1;                 // A/B runs only
   a.xcd = use_xcd;
+  static const float defer = getenv("CVMI_ATTN_DEFER") ? (float)atof(getenv("CVMI_ATTN_DEFER")) : DEFER_LOG2;   // A/B runs only
+  a.defer = defer;
   if (d->win > 0) {
     CVMI_CHECK(d->grid_h % d->win == 0 && d->grid_w % d->win == 0, "attention: grid %dx%d not divisible by window %d", d->grid_h, d->grid_w, d->win);
     CVMI_CHECK(d->Nk == d->win * d->win, "attention: window mode needs Nk == win^2");

@@ -36,7 +36,7 @@ struct ConvKArgs {
   int rows2;                             // 1x1 / s1 / p0 over two concatenated sources with channel counts that are K-tile multiples
   int nb_n;
   int bias_off;                          // igemm_kernel: LDS byte offset of the parked bias row
-  float* stats;                          // gemm256x192 (f32 out): per row and 96-column slice (sum, sum of squares) of the values written, or null
+  float* stats;                          // gemm256x192 (f32 out): per row and 96-column slice (mean, sum of squared deviations from it) of the values written, or null
   FastDiv div_ctot, div_kw;
 };
 
@@ -1292,6 +1292,60 @@ __global__ __launch_bounds__(512, 1) void gemm256x192_kernel(const ConvKArgs p) 
 #undef G192_SYNC_OUT
 #undef G192_MMA
 
+  // ---- M16, f32 output + residual on a full tile (Hiera stage-3 fc2, the dominant launch): NO LDS transposition, no barriers.  In the
+  //      16x16x32 C / D layout a lane holds 4 consecutive channels of a pixel and the four lanes g = 0..3 hold 16 consecutive ones:
+  //      residual loads and stores are 64-byte row pieces as they stand.  Row statistics for the next LayerNorm (p.stats): per pixel and
+  //      96-channel slice (= this wave's channel half) the slice MEAN and the sum of squared deviations from it, two passes over the 24
+  //      values in registers -- no E[x^2] - E[x]^2 cancellation however far the row sits from zero; the consumer combines the
+  //      slices as Chan et al. do (tok_linear16.hip / tok_linear.hip, stats_parts).
+  if constexpr (M16 && sizeof(TO) == 4) {
+    if (p.res && p.act == CVMI_ACT_NONE && !p.act_after_res && p.res_mod == 0 && m0 + BM <= p.M && n0 + BN <= p.N) {      // (uniform)
+      const int slices = p.N / 96;
+      f32x4 bv[3][2];
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) bv[i][hh] = *reinterpret_cast<const f32x4*>(p.bias + n0 + wh * 96 + i * 32 + hh * 16 + 4 * g16);
+#pragma unroll
+      for (int pq = 0; pq < 4; ++pq) {
+        const size_t m = (size_t)m0 + wp * 64 + pq * 16 + r16;
+        const float* rrow = reinterpret_cast<const float*>(p.res) + m * p.res_ld + n0 + wh * 96 + 4 * g16;
+        float* yrow = reinterpret_cast<float*>(p.y) + m * p.y_ld + n0 + wh * 96 + 4 * g16;
+        f32x4 v[3][2];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+          for (int hh = 0; hh < 2; ++hh) v[i][hh] = *reinterpret_cast<const f32x4*>(rrow + i * 32 + hh * 16);
+        float sm = 0.f;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+          for (int hh = 0; hh < 2; ++hh) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[i][hh][e] = (acc16[i][hh][pq][e] + bv[i][hh][e]) + v[i][hh][e];
+            *reinterpret_cast<f32x4*>(yrow + i * 32 + hh * 16) = v[i][hh];
+            sm += (v[i][hh][0] + v[i][hh][1]) + (v[i][hh][2] + v[i][hh][3]);
+          }
+        if (p.stats) {                                          // (uniform)
+          sm += __shfl_xor(sm, 16);
+          sm += __shfl_xor(sm, 32);
+          const float mean = sm * (1.0f / 96.0f);
+          float m2 = 0.f;
+#pragma unroll
+          for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+              for (int e = 0; e < 4; ++e) { const float dv = v[i][hh][e] - mean; m2 = fmaf(dv, dv, m2); }
+          m2 += __shfl_xor(m2, 16);
+          m2 += __shfl_xor(m2, 32);
+          if (g16 == 0) *reinterpret_cast<float2*>(p.stats + (m * slices + (n0 / 96 + wh)) * 2) = make_float2(mean, m2);
+        }
+      }
+      return;
+    }
+  }
+
   // ---- epilogue: bias + act -> LDS tile -> 16-byte stores (+ residual prefetched before the transposition);
   //      f32 output goes in two 96-column passes (one per channel half)
   constexpr int OES = sizeof(TO), OVEC = 16 / OES;
@@ -1400,7 +1454,11 @@ __global__ __launch_bounds__(512, 1) void gemm256x192_kernel(const ConvKArgs p) 
         if constexpr (OES == 4) {
           // row statistics for the NEXT LayerNorm over these rows: this thread's 4 values -> (sum, sum of squares), parked in the chunk slot it
           // has just consumed (no other thread reads that slot), reduced per row below
-          if (p.stats) *reinterpret_cast<float2*>(Ct + row * CROWB + ch * 16) = make_float2((a[0] + a[1]) + (a[2] + a[3]), fmaf(a[0], a[0], fmaf(a[1], a[1], fmaf(a[2], a[2], a[3] * a[3]))));
+          if (p.stats) {                                      // (mean of the 4 values, their squared deviations from it)
+            const float m4 = 0.25f * ((a[0] + a[1]) + (a[2] + a[3]));
+            const float d0 = a[0] - m4, d1 = a[1] - m4, d2 = a[2] - m4, d3 = a[3] - m4;
+            *reinterpret_cast<float2*>(Ct + row * CROWB + ch * 16) = make_float2(m4, fmaf(d0, d0, fmaf(d1, d1, fmaf(d2, d2, d3 * d3))));
+          }
         }
       }
       *reinterpret_cast<u32x4*>(p.y + ((size_t)m * p.y_ld + n) * OES) = cv;
@@ -1409,14 +1467,16 @@ __global__ __launch_bounds__(512, 1) void gemm256x192_kernel(const ConvKArgs p) 
       if (p.stats) {                                        // (uniform; the host admits it only with a residual and whole 96-column slices)
         __syncthreads();
         if (tid < BM && m0 + tid < p.M) {
-          float ps = 0.f, pq = 0.f;
+          float mean_ = 0.f, m2_ = 0.f;
 #pragma unroll
-          for (int ch = 0; ch < NCH; ++ch) {                // fixed order: bit-identical replays
+          for (int ch = 0; ch < NCH; ++ch) {                // fixed order: bit-identical replays; pairwise update of Chan et al. (groups of 4)
             const float2 t = *reinterpret_cast<const float2*>(Ct + tid * CROWB + ch * 16);
-            ps += t.x; pq += t.y;
+            const float dl = t.x - mean_, nn = (float)(4 * ch);
+            mean_ += dl * (4.0f / (nn + 4.0f));
+            m2_ += t.y + dl * dl * (nn * 4.0f / (nn + 4.0f));
           }
-          const int slices = p.N / CW;
-          *reinterpret_cast<float2*>(p.stats + ((size_t)(m0 + tid) * slices + (n0 / CW + pass)) * 2) = make_float2(ps, pq);
+          const int slices = p.N / CW;                      // (slice mean, sum of squared deviations): the format the direct M16 epilogue writes
+          *reinterpret_cast<float2*>(p.stats + ((size_t)(m0 + tid) * slices + (n0 / CW + pass)) * 2) = make_float2(mean_, m2_);
         }
       }
     }

@@ -110,14 +110,20 @@ __global__ __launch_bounds__(TL_NW * 64, 2) void tok_linear_kernel(const void* _
     if (ex.stats_in && ex.stats_parts == 0) {                // forwarded by the producer of these rows: pass 1 disappears
       const float2 st = *reinterpret_cast<const float2*>(ex.stats_in + 2 * row);
       mean = st.x; rstd = st.y;
-    } else if (ex.stats_in) {                                // raw partial sums of a tiled GEMM's column slices, added in a fixed order
-      float ss = 0.f, qq = 0.f;
+    } else if (ex.stats_in) {                                // per column slice (mean, sum of squared deviations) of a tiled GEMM's epilogue, combined
+      float ms = 0.f, m2 = 0.f;                              // as Chan et al. do (equal slice sizes K / P, fixed order): see tok_linear16.hip
       for (int t = 0; t < ex.stats_parts; ++t) {
         const float2 st = *reinterpret_cast<const float2*>(ex.stats_in + (row * ex.stats_parts + t) * 2);
-        ss += st.x; qq += st.y;
+        ms += st.x; m2 += st.y;
       }
-      mean = ss / (float)K;
-      rstd = 1.0f / sqrtf(fmaxf(qq / (float)K - mean * mean, 0.f) + eps);
+      const float inv_p = 1.0f / (float)ex.stats_parts;
+      mean = ms * inv_p;
+      float dev = 0.f;
+      for (int t = 0; t < ex.stats_parts; ++t) {
+        const float d = ex.stats_in[(row * ex.stats_parts + t) * 2] - mean;
+        dev = fmaf(d, d, dev);
+      }
+      rstd = 1.0f / sqrtf(fmaxf((m2 + ((float)K * inv_p) * dev) / (float)K, 0.f) + eps);
     } else {
       const float x0 = xr[0];
       float s = 0.f, q = 0.f;

@@ -89,14 +89,24 @@ __global__ __launch_bounds__(TL_NW * 64, 2) void tok_linear16_kernel(const void*
       if (ex.stats_in && ex.stats_parts == 0) {
         const float2 st = *reinterpret_cast<const float2*>(ex.stats_in + 2 * row[tg]);
         mean[tg] = st.x; rstd[tg] = st.y;
-      } else if (ex.stats_in) {                                // raw (sum, sum of squares) partials of a tiled GEMM's column slices, fixed order
-        float ss = 0.f, qq = 0.f;
+      } else if (ex.stats_in) {                                // per column slice (mean, sum of squared deviations) of a tiled GEMM's epilogue
+        float ms = 0.f, m2 = 0.f;                              // combined as Chan et al.: equal slice sizes n = K / P, fixed order
         for (int t = 0; t < ex.stats_parts; ++t) {
           const float2 st = *reinterpret_cast<const float2*>(ex.stats_in + (row[tg] * ex.stats_parts + t) * 2);
-          ss += st.x; qq += st.y;
+          ms += st.x; m2 += st.y;
         }
-        mean[tg] = ss / (float)K;
-        rstd[tg] = 1.0f / sqrtf(fmaxf(qq / (float)K - mean[tg] * mean[tg], 0.f) + eps);
+        const float inv_p = 1.0f / (float)ex.stats_parts;
+        mean[tg] = ms * inv_p;
+        // sum_t M2_t + n sum_t (mean_t - mean)^2, the second term as n (sum mean_t^2 - P mean^2): slice means differ by O(sigma / sqrt(n)) only
+        // when the row's offset is common to all slices, and then sum mean_t^2 - P mean^2 is a difference of nearly equal numbers of size
+        // mean^2 -- so it is formed from the deviations instead
+        float dev = 0.f;
+        for (int t = 0; t < ex.stats_parts; ++t) {
+          const float d = ex.stats_in[(row[tg] * ex.stats_parts + t) * 2] - mean[tg];
+          dev = fmaf(d, d, dev);
+        }
+        const float var = (m2 + ((float)K * inv_p) * dev) / (float)K;
+        rstd[tg] = 1.0f / sqrtf(fmaxf(var, 0.f) + eps);
       } else {                                                 // own statistics: shifted single pass over this lane's quarter of the row, 4 lanes per row
         const float x0 = xr[tg][0];
         float s = 0.f, q = 0.f;

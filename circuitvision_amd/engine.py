@@ -267,7 +267,7 @@ def op_conv(plan, label, pc, srcs, dst, stride=1, pad=None, act=_lib.ACT_NONE, r
         N=pc.N, Kpad=pc.Kpad, act=act, dtype=pc.dtype, out_f32=out_f32, scalar_gather=1 if scalar_gather else 0,
         res_mod=res_mod, act_after_res=1 if act_after_res else 0, shuffle_cout=shuffle_cout, res_rep=res_rep,
         row_stats=(row_stats.data_ptr() if row_stats is not None else None))
-    if row_stats is not None:       # f32 [rows, N / 96, 2]: (sum, sum of squares) per 96-column slice of every written row (Hiera stage-3 fc2 shape only)
+    if row_stats is not None:       # f32 [rows, N / 96, 2]: (mean, sum of squared deviations) per 96-column slice of every written row (Hiera stage-3 fc2 shape only)
         assert row_stats.dtype == torch.float32 and row_stats.is_contiguous() and row_stats.numel() == v0.B * OH * OW * (pc.N // 96) * 2, label
     plan.keep.append((d, pc, srcs, dst, res, row_stats))
     sp0 = plan.sptr
@@ -607,7 +607,7 @@ def op_tok_linear(plan, label, pt, src, dst, ln=None, act=_lib.ACT_NONE, residua
     dst: fp16 View, or (residual=True) the f32 View updated in place.
     stats_out (residual=True): f32 tensor [rows, 2] that receives each updated row's (mean, rstd) for the NEXT LayerNorm (eps = stats_eps);
     stats_in (ln = (gamma, beta, eps)): such a tensor written by the launch that produced src -- the prologue then reads src once.
-    stats_parts = P > 0: stats_in is instead f32 [rows, P, 2] of raw (sum, sum of squares) partials (op_conv(row_stats=...))."""
+    stats_parts = P > 0: stats_in is instead f32 [rows, P, 2] of per-slice (mean, sum of squared deviations) (op_conv(row_stats=...))."""
     lib = _lib.load()
     src, dst = _as_rows(src), _as_rows(dst)
     assert src.C == pt.K and dst.C == pt.N and src.rows == dst.rows and src.rows % 256 == 0, label

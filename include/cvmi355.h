@@ -96,9 +96,10 @@ typedef struct cvmi_conv_desc {
   int res_rep;                      /* > 1 (with shuffle_cout, or with res_mod == OH * OW): the residual has B / res_rep images, image b
                                        reads residual image b / res_rep (tensors shared by the prompts of an image) */
   float* row_stats;                 /* optional (f32 output + residual, plain 16-bit GEMM with N % 192 == 0 and K >= 1024, i.e. the Hiera stage-3
-                                       fc2 shape): float[rows][N / 96][2] = (sum, sum of squares) of the values written to each row's
-                                       96-column slices -- the statistics of the NEXT LayerNorm over these rows (cvmi_tok_linear_stats with
-                                       ln_stats_in_parts = N / 96); NULL = off */
+                                       fc2 shape): float[rows][N / 96][2] = (mean, sum of squared deviations from that mean) of the values
+                                       written to each row's 96-column slices -- the statistics of the NEXT LayerNorm over these rows, free of
+                                       the E[x^2] - E[x]^2 cancellation (cvmi_tok_linear_stats with ln_stats_in_parts = N / 96 combines the
+                                       slices); NULL = off */
 } cvmi_conv_desc;
 int cvmi_conv2d(const cvmi_conv_desc* d, cvmi_stream_t stream);
 
@@ -290,7 +291,8 @@ int cvmi_tok_linear(const void* in, int in_ld, int in_f32_layernorm, const float
  * (sam2 hieradet MultiScaleBlock: x = shortcut + proj(attn), then mlp.layers[0](norm2(x)); behind sam2_infer.py:226):
  *   ln_stats_out (out_f32_residual = 1, may be NULL): float[2 * rows] = per row (mean, 1 / sqrt(var + ln_stats_eps)) over the N updated values
  *   ln_stats_in  (in_f32_layernorm = 1, may be NULL): the same pairs; the LayerNorm prologue then reads every row once instead of twice.
- *   ln_stats_in_parts = P > 0: ln_stats_in is float[rows][P][2] of raw (sum, sum of squares) partials instead (cvmi_conv_desc.row_stats). */
+ *   ln_stats_in_parts = P > 0: ln_stats_in is float[rows][P][2] of per-slice (mean, sum of squared deviations) instead, P equal column slices
+ *                     of the row (cvmi_conv_desc.row_stats). */
 int cvmi_tok_linear_stats(const void* in, int in_ld, int in_f32_layernorm, const float* gamma, const float* beta, float eps,
                           const void* w_packed, void* out, int out_ld, int out_f32_residual, long long rows, int K, int N, int act,
                           int dtype, const float* ln_stats_in, int ln_stats_in_parts, float* ln_stats_out, float ln_stats_eps,

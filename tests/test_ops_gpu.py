@@ -706,9 +706,10 @@ def test_tok_linear_forwarded_layernorm_statistics(K, N2, dt):
 @pytest.mark.parametrize("dt", [F16, BF16])
 def test_gemm_row_statistics_feed_the_next_layernorm(dt):
     """Hiera stage-3 fc2 shape (65536 x 2304 -> 576, f32 residual stream updated in place): the 256 x 192 GEMM also writes, per row and per
-    96-column slice, (sum, sum of squares) of the values it stores (cvmi_conv_desc.row_stats); the next block's qkv (cvmi_tok_linear_stats with
-    ln_stats_in_parts = 6) adds them up instead of reading the rows twice.  Statistics vs float64 sums of the rows AS WRITTEN; the qkv output
-    with forwarded statistics vs the two-pass prologue on the same rows; replays bit-identical."""
+    96-column slice, (mean, sum of squared deviations) of the values it stores (cvmi_conv_desc.row_stats); the next block's qkv
+    (cvmi_tok_linear_stats with ln_stats_in_parts = 6) combines them instead of reading the rows twice.  Statistics vs float64 moments of the rows
+    AS WRITTEN; the qkv output with forwarded statistics vs the two-pass prologue on the same rows; replays bit-identical.  Rows 0..255 sit 500
+    (>= 300 standard deviations) away from zero: raw (sum, sum of squares) partials would lose the variance there."""
     from circuitvision_amd.engine import TORCH_DTYPE, PackedTokLinear, Rows, op_tok_linear, row_stats_supported
     td = TORCH_DTYPE[dt]
     tol = 1.0 if dt == F16 else 8.0
@@ -719,6 +720,7 @@ def test_gemm_row_statistics_feed_the_next_layernorm(dt):
     w = quant(torch.randn(N, K) / K ** 0.5, dt); b = torch.randn(N) * 0.2
     x0 = torch.randn(M, N, generator=g, device="cuda") * 1.5 + 0.4
     x0[:, 11] += 30.0
+    x0[:256] += 500.0                                            # a common offset of >= 300 sigma
     xb = Buf(1, 1, M, N, F32); xb.t.copy_(x0.view(1, 1, M, N))
     hb = Buf(1, 1, M, K, dt); hb.t.copy_(hid.view(1, 1, M, K))
     parts = torch.zeros(M, N // 96, 2, device="cuda")
@@ -734,8 +736,11 @@ def test_gemm_row_statistics_feed_the_next_layernorm(dt):
     run(plan)
     x1 = xb.t.view(M, N).double()
     sl = x1.view(M, N // 96, 96)
-    exp = torch.stack((sl.sum(2), (sl * sl).sum(2)), 2).float()
+    mu = sl.mean(2, keepdim=True)
+    exp = torch.stack((mu[..., 0], ((sl - mu) ** 2).sum(2)), 2).float()
     torch.testing.assert_close(parts, exp, rtol=2e-5, atol=2e-4)
+    # the offset rows: the forwarded statistics give the same normalised rows as the two-pass prologue (variance not lost to cancellation)
+    torch.testing.assert_close(oa[:256].float(), ob[:256].float(), rtol=2e-3 * tol, atol=2e-3 * tol)
     ref_rows = (x0.double() + hid.double() @ w.double().cuda().t() + b.double().cuda())[:512]
     torch.testing.assert_close(x1[:512], ref_rows, rtol=2e-3 * tol, atol=2e-3 * tol)
     torch.testing.assert_close(oa.float(), ob.float(), rtol=2e-3 * tol, atol=2e-3 * tol)
