@@ -13,14 +13,16 @@ Columns (per launch, averaged over the launches of the pass):
 import collections
 import csv
 import glob
+import os
 import re
 import sys
 
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from kname import canon
+
 
 def clean(name):
-    name = name.replace("(anonymous namespace)::", "").replace("void ", "")
-    name = re.sub(r"\(.*$", "", name)
-    return name[:90]
+    return canon(name)[:90]           # demangled, parameter list cut: the spelling bench.py / cvmi_last_kernel() use
 
 
 def load(d):
