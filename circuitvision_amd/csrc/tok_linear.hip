@@ -464,8 +464,15 @@ int launch_tl(const void* in, int in_ld, const float* gamma, const float* beta, 
       return launch_tl1<K, LN, RES, GELU, true>(in, in_ld, gamma, beta, eps, wp, out, out_ld, rows, N, s, ex);
     }
   }
-  if (pp) return launch_tl1<K, LN, RES, GELU, false, false, true>(in, in_ld, gamma, beta, eps, wp, out, out_ld, rows, N, s, ex);
-  return launch_tl1<K, LN, RES, GELU, false>(in, in_ld, gamma, beta, eps, wp, out, out_ld, rows, N, s, ex);
+  // The one-barrier schedule runs the RES epilogue in the MIDDLE of the MFMA sequence, where hipcc re-loads a kernel argument (s_load:
+  // the same counter as the ring's counted lgkmcnt waits -- tools/check_ring_asm.py found it): the residual form always takes the ping-pong
+  // schedule, whose epilogue sits outside the ring window.
+  if constexpr (RES) {
+    return launch_tl1<K, LN, RES, GELU, false, false, true>(in, in_ld, gamma, beta, eps, wp, out, out_ld, rows, N, s, ex);
+  } else {
+    if (pp) return launch_tl1<K, LN, RES, GELU, false, false, true>(in, in_ld, gamma, beta, eps, wp, out, out_ld, rows, N, s, ex);
+    return launch_tl1<K, LN, RES, GELU, false>(in, in_ld, gamma, beta, eps, wp, out, out_ld, rows, N, s, ex);
+  }
 }
 
 template <int K>

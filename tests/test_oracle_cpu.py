@@ -176,3 +176,21 @@ def test_row_stats_predicate_mirrors_the_gemm_dispatch():
     assert not ok(65536, 1152, 4608)             # stage 4: 1152 = 4.5 x 256, 90 % column use -> the 256 x 256 kernel
     assert not ok(65536, 576, 576)               # K below the 256 x 192 kernel's threshold
     assert not ok(65536, 560, 2304)              # N not a multiple of 192
+
+
+def test_counted_lds_rings_hold_no_scalar_memory_instruction():
+    """the hand-counted `s_waitcnt lgkmcnt(N > 0)` rings of tok_linear16.hip / hiera_mlp.hip / tok_linear.hip are only valid while
+    hipcc emits no scalar-memory instruction (same counter, out-of-order return) between a ring `ds_read_b128` and the MFMA that consumes it.
+    tools/check_ring_asm.py disassembles the device code of both operand builds and fails on any; the checker itself is exercised on a
+    synthetic stream first."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("check_ring_asm", os.path.join(ROOT, "tools", "check_ring_asm.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    fake = "\n".join(["_Zk:", ";;#ASMSTART", "ds_read_b128 v[0:3], v9 offset:0", ";;#ASMEND", "s_load_dwordx2 s[0:1], s[4:5], 0x0", ";;#ASMSTART",
+                      "s_waitcnt lgkmcnt(0)", ";;#ASMEND", "s_load_dword s2, s[4:5], 0x8", ".end_amdhsa_kernel"])
+    k, s, bad = m.check(fake)
+    assert (k, s) == (1, 1) and [b[2] for b in bad] == ["s_load_dwordx2 s[0:1], s[4:5], 0x0"]      # inside the window: flagged; after the drain: not
+    if not os.path.exists(m.HIPCC):
+        pytest.skip("hipcc not available")
+    assert m.main(["tok_linear16.hip", "hiera_mlp.hip", "tok_linear.hip"]) == 0
