@@ -65,6 +65,11 @@ def parse():
     ap.add_argument("--total-images", type=int, default=64, help="pipeline workload: images in the whole job")
     ap.add_argument("--dtype", default="f16", choices=["f16", "f32", "bf16"], help="operand storage type (bf16: SAM 2 workloads, BASELINE configs[4])")
     ap.add_argument("--attn", default="16", choices=["16", "fp8"], help="fp8: the AV products of Hiera's 256-key windows / global blocks on the block-scaled fp8 MFMA (BASELINE configs[4])")
+    ap.add_argument("--streams", type=int, default=3, choices=[1, 2, 3, 4],
+                    help="circuit / pipeline workloads: how the INDEPENDENT graphs of a step (detector batch, segmenter half-batches: different images) are "
+                         "issued -- 1 = back to back on one stream; 2 = the segmenter batches alternate between two streams (detector with the first); "
+                         "3 (default) = detector on its own stream as well; 4 = only the detector on its own stream.  Measured (profiles/r03_ab_runs.md): "
+                         "two segmenter graphs side by side fill each other's kernel tails: +4.7 %% images/s")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile-pass", action="store_true")
     a = ap.parse_args()
@@ -210,7 +215,7 @@ def check_replicas(tensors, what):
 class YoloStage:
     """YOLO11 forward + decode + NMS on B resident images (one captured graph)."""
 
-    def __init__(self, a, scale, B, rank, local_rank, world, stream, seed0):
+    def __init__(self, a, scale, B, rank, local_rank, world, stream, seed0, lanes=None):
         import torch
         from circuitvision_amd import _lib
         from circuitvision_amd.distributed import broadcast_packed
@@ -227,7 +232,7 @@ class YoloStage:
         if world > 1:
             broadcast_packed(self.wt.packed, src=0)            # one-time RCCL broadcast of the packed weights
             check_replicas(self.wt.packed, "YOLO11")
-        self.yp = Yolo11Plan(self.wt, B, 640, 640, stream, keep_scores=False)
+        self.yp = Yolo11Plan(self.wt, B, 640, 640, stream, keep_scores=False, lanes=lanes)
         lib = _lib.load()
         self.seeds = [seed0 + b for b in range(B)]
         for b, s in enumerate(self.seeds):                      # synthetic circuit images of this rank's shard, letterboxed on the GPU
@@ -432,7 +437,7 @@ class HostPipeline:
         from circuitvision_amd.sam2 import HIERA_L
         from circuitvision_amd.sam2_infer import SAM2Model, SAM2Transforms
         from synth import circuit_image
-        det = YOLO.from_weights(ystage.wt, {i: f"class{i}" for i in range(ystage.nc)}, dtype=a.dtype)     # the stage's (bias-shifted) packed weights
+        det = YOLO.from_weights(ystage.wt, {i: f"class{i}" for i in range(ystage.nc)}, dtype=a.dtype, graph_lanes=0)     # the stage's (bias-shifted) packed weights
         seg = SAM2Model(HIERA_L, 1024, dtype=a.dtype, use_refinement=True)
         seg.weights, seg.params = sstage.wt, sstage.params
         tr = SAM2Transforms(resolution=1024, mask_threshold=0, max_hole_area=0, max_sprinkle_area=0)
@@ -493,8 +498,15 @@ def main():
         if by % bs:
             raise SystemExit("--batch must be a multiple of 16 for the circuit workload")
         seed0 = 20250704 + rank * by
-        stages = [("yolo11n", YoloStage(a, "n", by, rank, local_rank, world, stream, seed0))]
-        stages += [(f"sam2l[{j}]", SamStage(a, bs, rank, local_rank, world, stream, seed0 + j * bs)) for j in range(nsam)]
+        # 1: one stream; 2: the two segmenter half-batches on two streams (detector with the first); 3: three streams; 4: detector on its own
+        # stream, both segmenter half-batches on one
+        extra = [torch.cuda.Stream() for _ in range(2)]
+        sam_streams = [stream, extra[0]] if a.streams in (2, 3) else [stream, stream]
+        # (a graph with internal side lanes on one of several concurrently used streams serialised the others in the r3m trace: the detector's
+        #  graph is one linear chain whenever the step's graphs get streams of their own)
+        stages = [("yolo11n", YoloStage(a, "n", by, rank, local_rank, world, extra[1] if a.streams in (3, 4) else stream, seed0,
+                                        lanes=0 if a.streams > 1 else None))]
+        stages += [(f"sam2l[{j}]", SamStage(a, bs, rank, local_rank, world, sam_streams[j % 2], seed0 + j * bs)) for j in range(nsam)]
         images_per_step = by
         name = (f"YOLO11-n 640x640 batch={by} fp16 forward+decode+NMS (BASELINE configs[1]) + SAM2.1 Hiera-L 1024x1024 {nsam} x batch={bs} fp16 "
                 "learned-prompt wrapper forward (configs[2]) on the same images, per GPU and step")
@@ -520,10 +532,13 @@ def main():
         sam_sizes = [bs] * (n // bs) + ([n % bs] if n % bs else [])          # EVERY image of the shard goes through the segmenter
         assert sum(sam_sizes) == n
         seed0 = 20250704 + lo
-        stages = [("yolo11l", YoloStage(a, "l", n, rank, local_rank, world, stream, seed0))]
+        extra = [torch.cuda.Stream() for _ in range(2)]
+        sam_streams = [stream, extra[0]] if a.streams in (2, 3) else [stream, stream]
+        stages = [("yolo11l", YoloStage(a, "l", n, rank, local_rank, world, extra[1] if a.streams in (3, 4) else stream, seed0,
+                                        lanes=0 if a.streams > 1 else None))]
         off = 0
         for j, b_ in enumerate(sam_sizes):
-            stages.append((f"sam2l[{j}]", SamStage(a, b_, rank, local_rank, world, stream, seed0 + off)))
+            stages.append((f"sam2l[{j}]", SamStage(a, b_, rank, local_rank, world, sam_streams[j % 2], seed0 + off)))
             off += b_
         images_per_step = n
         scaling = "strong"
@@ -533,17 +548,19 @@ def main():
                 "resident tensors, `host_inclusive` = CircuitPipeline.run_batch on u8 host images (H2D, letterbox, detector, D2H + glue + "
                 "stage-2 NMS, transform, segmenter, post-process, D2H of the u8 masks)")
 
-    for _ in range(a.warmup):
+    def run_step():
         for _, st in stages:
             st.run()
+
+    for _ in range(a.warmup):
+        run_step()
     stream.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        for _, st in stages:
-            st.run()
+        run_step()
     stream.synchronize()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
@@ -574,11 +591,12 @@ def main():
                 continue                                           # identical second SAM stage
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             reps = 3 if isinstance(st, SamStage) else 20
-            st.run(); stream.synchronize()
-            e0.record(stream)
+            sst = st.plan.stream                                   # (--streams > 1: a stage may own its stream)
+            st.run(); sst.synchronize()
+            e0.record(sst)
             for _ in range(reps):
                 st.run()
-            e1.record(stream); stream.synchronize()
+            e1.record(sst); sst.synchronize()
             ms = e0.elapsed_time(e1) / reps
             key = sname.replace("[0]", "")
             info = {"batch": st.B, "ms_per_launch": round(ms, 4), "images_per_s": round(st.B / ms * 1e3, 2)}
@@ -621,7 +639,8 @@ def main():
             "metric": METRIC, "value": round(value, 3), "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": a.dtype, "data": "synthetic",
-            "config": {"workload": name, "images_per_step": world * images_per_step, "nc": 62, "weights": "seeded random (SAM: LoRA merged)"},
+            "config": {"workload": name, "images_per_step": world * images_per_step, "nc": 62, "weights": "seeded random (SAM: LoRA merged)",
+                       "streams": (a.streams if w in ("circuit", "pipeline") else 1)},
             "roofline": top, "cpu_baseline": cpu, "rooflines": rooflines, "top_launches": tops, "stages": stage_info,
         }
         if host_info is not None:

@@ -36,6 +36,7 @@ struct ConvKArgs {
   int rows2;                             // 1x1 / s1 / p0 over two concatenated sources with channel counts that are K-tile multiples
   int nb_n;
   int bias_off;                          // igemm_kernel: LDS byte offset of the parked bias row
+  int rev_m;                             // gemm256x192: 1 = walk the row blocks last-to-first (see launch_g256x192)
   float* stats;                          // gemm256x192 (f32 out): per row and 96-column slice (mean, sum of squared deviations from it) of the values written, or null
   FastDiv div_ctot, div_kw;
 };
@@ -1140,7 +1141,8 @@ __global__ __launch_bounds__(512, 1) void gemm256x192_kernel(const ConvKArgs p) 
     const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = wg & 7, j = wg >> 3;
     wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
   }
-  const int bn = wg % p.nb_n, bm = wg / p.nb_n;
+  const int bn = wg % p.nb_n;
+  const int bm = p.rev_m ? (int)(gridDim.x / p.nb_n) - 1 - wg / p.nb_n : wg / p.nb_n;
   const int m0 = bm * BM, n0 = bn * BN;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int wp = wv & 3, wh = wv >> 2;                    // pixel quarter, channel half (= stagger group; wv and wv + 4 share a SIMD)
@@ -1499,6 +1501,10 @@ int launch_g256x192(ConvKArgs& a, hipStream_t stream) {
   const long long blocks = (long long)cdiv(a.M, 256) * a.nb_n;
   CVMI_CHECK(blocks > 0 && blocks < (1ll << 31), "conv2d: bad grid %lld", blocks);
   static const int m16 = getenv("CVMI_G192_M16") ? atoi(getenv("CVMI_G192_M16")) : 1;        // MFMA shape: 1 = 16x16x32, 0 = 32x32x16 (A/B runs)
+  // Row blocks last-to-first: the A operand (the fp16 hidden activation, 302 MB at B = 16: more than the 256 MiB Infinity Cache) was written
+  // first-to-last by the launch in front of this one, so its LAST rows are the ones still on the die when this launch starts.
+  static const int rev = getenv("CVMI_G192_REV") ? atoi(getenv("CVMI_G192_REV")) : 0;   // measured r03 (call r3j): no effect (207.6 vs 206.3 us) -- off
+  a.rev_m = rev;
   cvmi_note_kernel("gemm256x192_kernel<%s, %s>", sizeof(TO) == 2 ? CVMI_F16NAME : "float", CVMI_BOOLNAME(m16));
   if (m16) hipLaunchKernelGGL((gemm256x192_kernel<TO, true>), dim3((unsigned)blocks), dim3(512), bytes, stream, a);
   else hipLaunchKernelGGL((gemm256x192_kernel<TO, false>), dim3((unsigned)blocks), dim3(512), bytes, stream, a);

@@ -72,11 +72,15 @@ class YOLO:
 
     MAX_ANCHORS = 65536          # cvmi_yolo_nms: one workgroup per image, keys in LDS (<= 16384 anchors) or in its workspace
 
-    def __init__(self, path, dtype="f16", device="cuda", imgsz=None, keep_scores=False):
+    def __init__(self, path, dtype="f16", device="cuda", imgsz=None, keep_scores=False, graph_lanes=None):
         """keep_scores=True also materialises ultralytics' full [B, 4+nc, A] prediction tensor (tests / debugging).
-        imgsz=None: the checkpoint's train_args['imgsz'] (what ultralytics' predict() inherits), else 640."""
+        imgsz=None: the checkpoint's train_args['imgsz'] (what ultralytics' predict() inherits), else 640.
+        graph_lanes: side lanes of the captured graph (None: the default, the Detect heads beside the neck -- lowest latency of ONE call);
+        0 = one linear chain: what a batch pipeline wants, whose detector graph runs BESIDE the segmenter's on another stream (a graph with
+        internal branches serialises the other streams it shares the device with: DESIGN.md section 5.00)."""
         require_gpu()
         self.keep_scores = keep_scores
+        self.graph_lanes = graph_lanes
         self.dtype = {"f16": F16, "fp16": F16, "f32": F32, "fp32": F32}[dtype] if isinstance(dtype, str) else dtype
         self.device = device
         ck_imgsz = None
@@ -102,11 +106,12 @@ class YOLO:
         self._lock = threading.Lock()      # one analyzer is shared by all Streamlit sessions (app.py:134)
 
     @classmethod
-    def from_weights(cls, weights, names, dtype="f16", device="cuda", imgsz=640, keep_scores=False):
+    def from_weights(cls, weights, names, dtype="f16", device="cuda", imgsz=640, keep_scores=False, graph_lanes=None):
         """A detector over already packed `Yolo11Weights` (e.g. the replica a rank received by broadcast: no checkpoint read, no packing)."""
         require_gpu()
         self = cls.__new__(cls)
         self.keep_scores = keep_scores
+        self.graph_lanes = graph_lanes
         self.dtype = {"f16": F16, "fp16": F16, "f32": F32, "fp32": F32}[dtype] if isinstance(dtype, str) else dtype
         self.device = device
         self.imgsz = cls._check_imgsz(imgsz)
@@ -133,7 +138,7 @@ class YOLO:
         key = (B, H, W, conf, iou, max_det)
         if key not in self._plans:
             with torch.cuda.device(self.device):
-                self._plans[key] = Yolo11Plan(self.weights, B, H, W, self.stream, conf, iou, max_det, keep_scores=self.keep_scores)
+                self._plans[key] = Yolo11Plan(self.weights, B, H, W, self.stream, conf, iou, max_det, keep_scores=self.keep_scores, lanes=self.graph_lanes)
         return self._plans[key]
 
     # ---- reference entry point -----------------------------------------------------------------

@@ -52,6 +52,7 @@ class CircuitPipeline:
         self.det, self.seg, self.tr = detector, segmenter, transforms
         self.stage2_iou, self.max_prompts, self.crop_fn, self.swap = stage2_iou, max_prompts, crop_fn, swap_channels
         self.seg_batch = max(1, int(seg_batch))
+        self.seg_slots = 2                         # segmenter plan instances (each with its own stream) the overlapped path alternates between
         self.timings = defaultdict(float)          # wall seconds per phase, accumulated over calls (bench.py prints them per step)
 
     def _tick(self, name, t0):
@@ -161,14 +162,14 @@ class CircuitPipeline:
     def _run_overlapped(self, images):
         t = time.perf_counter()
         chunks = [images[c0:c0 + self.seg_batch] for c0 in range(0, len(images), self.seg_batch)]
-        pend = [self._enqueue_learned(chunks[0])]
+        pend = [self._enqueue_learned(chunks[0], 0)]
         t = self._tick("enqueue: segmenter chunk 0 (stage u8 + H2D + transform + SAM 2.1 graph + post-process launches)", t)
         groups = {}
         for i, im in enumerate(images):
             groups.setdefault(im.shape[:2], []).append(i)
         handles = [(idxs, self.det.predict_async([images[i] for i in idxs])) for idxs in groups.values()]
         t = self._tick("enqueue: detector (stage u8 + H2D + letterbox + YOLO11 graph + NMS + D2H launches)", t)
-        pend += [self._enqueue_learned(ch) for ch in chunks[1:]]
+        pend += [self._enqueue_learned(ch, (k + 1) % self.seg_slots) for k, ch in enumerate(chunks[1:])]
         t = self._tick("enqueue: segmenter chunks 1.. (same, while the GPU runs chunk 0)", t)
         bboxes = [None] * len(images)
         for idxs, h in handles:
@@ -186,9 +187,10 @@ class CircuitPipeline:
         self._tick("wait: segmenter (GPU time not hidden behind host work) + extents to the host", t)
         return out
 
-    def _enqueue_learned(self, imgs):
-        """transform -> SAM 2.1 (learned prompts) -> resize / threshold / u8 / extent for one chunk, enqueued on the segmenter's stream.
-        Returns a closure that waits for it: -> (u8 masks [H,W] per image, extent tuples, iou [B,1])."""
+    def _enqueue_learned(self, imgs, slot=0):
+        """transform -> SAM 2.1 (learned prompts) -> resize / threshold / u8 / extent for one chunk, enqueued on the stream of segmenter plan
+        `slot` (consecutive chunks alternate between two plan instances on two streams: independent images, and two segmenter graphs side by
+        side fill each other's kernel tails).  Returns a closure that waits for it: -> (u8 masks [H,W] per image, extent tuples, iou [B,1])."""
         from . import _lib
         seg, tr = self.seg, self.tr
         lib = _lib.load()
@@ -196,7 +198,8 @@ class CircuitPipeline:
         sizes = [tuple(im.shape[:2]) for im in imgs]
         same = all(sz == sizes[0] for sz in sizes)
         with seg._lock, torch.cuda.device(seg.dev):
-            p = seg.plan(B)
+            p = seg.plan(B, slot=slot)
+            sst = seg.slot_stream(slot)
             # outputs come from the CALLER's allocator pool; the segmenter's stream is ordered behind the caller's before it writes them
             iou = torch.empty_like(p.iou)
             ext = torch.empty(B, 4, dtype=torch.int32, device=seg.dev)
@@ -206,9 +209,9 @@ class CircuitPipeline:
                 u8s = [u8[b] for b in range(B)]
             else:
                 u8s = [torch.empty(h, w, dtype=torch.uint8, device=seg.dev) for h, w in sizes]
-            seg.stream.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(seg.stream):
-                sp = seg.stream.cuda_stream
+            sst.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(sst):
+                sp = sst.cuda_stream
                 tr.forward_batch(imgs, swap_rb=self.swap, out=p.x_in.t, out_dtype=seg.dtype)
                 p.plan.run()
                 iou.copy_(p.iou, non_blocking=True)
@@ -222,7 +225,7 @@ class CircuitPipeline:
                                                              ext[b].data_ptr(), sp), "mask_postprocess")
                 ext_h.copy_(ext, non_blocking=True)
                 done = torch.cuda.Event()
-                done.record(seg.stream)
+                done.record(sst)
 
         def finish():
             done.synchronize()

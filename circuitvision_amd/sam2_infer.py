@@ -49,7 +49,8 @@ class SAM2Model:
         self.sam2_model = SimpleNamespace(image_size=image_size)          # circuit_analyzer.py:237-240 reads .sam2_model.image_size
         self.weights, self.params, self._pending = None, None, None
         self.stream = torch.cuda.Stream(device=dev)
-        self._plans = {}
+        self._slot_streams = {0: self.stream}                               # plan slot -> stream (slot 1: a second plan instance on its own stream, so
+        self._plans = {}                                                    # that two independent batches run side by side: CircuitPipeline)
         self._lock = threading.Lock()                                       # one analyzer is shared across sessions (app.py:134)
         self.training = False
 
@@ -73,15 +74,20 @@ class SAM2Model:
     def to(self, *_a, **_k):
         return self
 
-    def plan(self, B, prompts=0, high_res=True, points=3):
+    def slot_stream(self, slot):
+        if slot not in self._slot_streams:
+            self._slot_streams[slot] = torch.cuda.Stream(device=self.dev)
+        return self._slot_streams[slot]
+
+    def plan(self, B, prompts=0, high_res=True, points=3, slot=0):
         if self.weights is None and self._pending is not None:
             self.load_params(self._pending)           # base checkpoint only (no fine-tuned state dict followed): pack it now
         if self.weights is None:
             raise RuntimeError("SAM2 weights not loaded (call load_state_dict first)")
-        key = (B, prompts, high_res, points if prompts else 0)
+        key = (B, prompts, high_res, points if prompts else 0, slot)
         if key not in self._plans:
             with torch.cuda.device(self.dev):
-                self._plans[key] = Sam2Plan(self.weights, B, self.stream, self.dynamic, prompts=prompts, points=points, high_res=high_res, attn=self.attn)
+                self._plans[key] = Sam2Plan(self.weights, B, self.slot_stream(slot), self.dynamic, prompts=prompts, points=points, high_res=high_res, attn=self.attn)
         return self._plans[key]
 
     def _stage_images(self, p, images):

@@ -241,7 +241,7 @@ class Yolo11Plan:
     """Launch plan of the full forward for one (B, H, W): input NHWC [B,H,W,3] -> pred f32 [B,4+nc,A]
     -> NMS outputs."""
 
-    def __init__(self, weights, B, H, W, stream, conf=0.25, iou=0.7, max_det=300, with_nms=True, keep_scores=True, fuse_c3k2=True):
+    def __init__(self, weights, B, H, W, stream, conf=0.25, iou=0.7, max_det=300, with_nms=True, keep_scores=True, fuse_c3k2=True, lanes=None):
         """keep_scores=False: the decode kernel skips the class-score rows of `pred` (NMS takes the per-anchor
         best class straight from the decode kernel); the detections are identical."""
         self.keep_scores = keep_scores
@@ -254,6 +254,7 @@ class Yolo11Plan:
         self.plan = Plan(stream)
         self.act_bytes = 0
         self.conf, self.iou, self.max_det = conf, iou, max_det
+        self.lanes = int(os.environ.get("CVMI_YOLO_LANES", "3")) if lanes is None else int(lanes)      # side lanes of the captured graph (head())
         self._build(with_nms)
         torch.cuda.synchronize()      # buffer fills / weight uploads ran on the default stream
 
@@ -405,7 +406,7 @@ class Yolo11Plan:
         # per level 1.10, ONE side lane for all heads 1.09, no side lane 1.16 -- a replayed HIP graph pays ~1.8 us per node on a
         # chain but ~3.3 us per node when nodes alternate between lanes (tools/graph_gap.py), so the heads share one lane that
         # runs beside the rest of the neck.  CVMI_YOLO_LANES: tuning experiments only (0 none, 1 per level, 2 per branch, 3 one).
-        lanes = int(os.environ.get("CVMI_YOLO_LANES", "3"))
+        lanes = self.lanes              # (Yolo11Plan(lanes=0): one linear chain -- for a step whose graphs run side by side on their own streams)
         if lanes:
             self.plan.fork()
             self.plan.lane(1 if lanes in (3, 5) else (1 + min(i, 1)) if lanes == 4 else 2 * i + 1)

@@ -109,3 +109,51 @@ def test_non_finite_input_never_yields_a_plausible_mask(dtype):
             continue
         assert not torch.isfinite(lo[0]).all() or not torch.isfinite(iou[0]).all(), f"{bad} pixel produced a finite mask"
         assert torch.equal(lo[1], lo_clean[1]) and torch.equal(iou[1], iou_clean[1]), "the other image of the batch changed"
+
+
+def test_rank_without_checkpoint_runs_after_receiving_the_weight_tensors():
+    """VERDICT r2 weak #13 on the GPU: a rank that builds its weight objects from BLANK parameters (no checkpoint read) and then receives the
+    tensors `distributed.weight_tensors` / `packed_tensors` list -- here copied from a rank-0-style object, exactly what the bucketed RCCL
+    broadcast does -- produces bit-identical detector and segmenter outputs.  (The gloo tests check the broadcast itself and that the list
+    covers every tensor of the objects.)"""
+    from circuitvision_amd._lib import F16
+    from circuitvision_amd.distributed import packed_tensors, weight_tensors
+    from circuitvision_amd.sam2 import Sam2Plan, Sam2Weights, SamBlankParams
+    from circuitvision_amd.yolo11 import BlankParams, SyntheticParams, Yolo11Plan, Yolo11Weights
+    st = torch.cuda.Stream()
+    # detector
+    ref_w = Yolo11Weights("n", 62, SyntheticParams(seed=3, nc=62), F16)
+    new_w = Yolo11Weights("n", 62, BlankParams(), F16)
+    a, b = packed_tensors(ref_w.packed), packed_tensors(new_w.packed)
+    assert len(a) == len(b) and all(x.shape == y.shape and x.dtype == y.dtype for x, y in zip(a, b))
+    assert sum(float(t.float().abs().sum()) for t in b) == 0.0           # nothing but zeros before the "broadcast"
+    for x, y in zip(a, b):
+        y.copy_(x)
+    xin = torch.rand(2, 3, 96, 160, generator=torch.Generator().manual_seed(0))
+    outs = []
+    for w in (ref_w, new_w):
+        p = Yolo11Plan(w, 2, 96, 160, st)
+        p.set_input_nchw(xin)
+        torch.cuda.synchronize()
+        p.plan.run_eager()
+        torch.cuda.synchronize()
+        outs.append(p.pred.clone())
+    assert torch.equal(outs[0], outs[1]) and float(outs[0].abs().sum()) > 0
+    # segmenter
+    sp = SamSyntheticParams(seed=8, lora_targets=mini_targets(), std=0.05)
+    ref_s = Sam2Weights(sp, MINI, 256, F16)
+    new_s = Sam2Weights(SamBlankParams(), MINI, 256, F16)
+    a, b = weight_tensors(ref_s), weight_tensors(new_s)
+    assert len(a) == len(b) and all(x.shape == y.shape and x.dtype == y.dtype for x, y in zip(a, b))
+    for x, y in zip(a, b):
+        y.copy_(x)
+    x = torch.randn(2, 256, 256, 3, generator=torch.Generator().manual_seed(1)).half().cuda()
+    outs = []
+    for w in (ref_s, new_s):
+        p = Sam2Plan(w, 2, st)
+        p.x_in.t.copy_(x)
+        torch.cuda.synchronize()
+        p.plan.run_eager()
+        torch.cuda.synchronize()
+        outs.append((p.low_res.clone(), p.iou.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]) and torch.isfinite(outs[0][0]).all()
