@@ -27,6 +27,8 @@ struct AttnArgs {
   int q_bdiv, kv_bdiv;   // batch sharing (no window): q rows of batch entry b come from entry b / q_bdiv, k / v rows from b / kv_bdiv
   int qtiles;      // ceil(Nq / 32)
   int items;       // B * heads * qtiles
+  int ostage;      // 1: head_dim-72 kernels store O through an LDS stage as 144-byte row pieces (needs 16-byte aligned o / strides); 0: direct 8-byte stores
+  int diag;        // CVMI_ATTN_DIAG, timing experiments ONLY (results are wrong): bit 0 = attn_res256 skips its key-tile loop, bit 1 = skips its K / V DMA
   float defer;     // deferred-rescale threshold in log2 units (DEFER_LOG2; CVMI_ATTN_DEFER=0 restores "rescale on every new maximum" for A/B runs)
   int xcd;         // 1: XCD-aware workgroup order (xcd_order below); 0: natural order (CVMI_ATTN_XCD=0, A/B runs only)
   FastDiv div_win; // window mode: key -> (row, column) inside the window without a hardware division
@@ -58,6 +60,37 @@ __device__ __forceinline__ float xhalf_sum(float x) {
 // saw a new maximum: almost every tile) becomes rare.  Everything at the old scale is rescaled exactly once when the reference does move:
 // O and l here, and no P is pending (it is exponentiated after the decision).  The e4m3 product keeps DEFER = 0: its P is scaled by 2^8 already.
 constexpr float DEFER_LOG2 = 8.0f;
+
+// Epilogue of the head_dim-72 kernels.  The accumulator has the query on the lane: stored directly, a wave writes 8-byte pieces of 64
+// different rows per instruction (576 of them for a 32 x 72 tile) -- with the Q loads that was 50 of the 16 x 16-window launch's 91 us
+// (CVMI_ATTN_DIAG=3, r03).  Here the wave's tile goes through a wave-private 32 x 144-byte LDS stage (the K / V region, dead after the
+// key loop: callers put a barrier in front) and leaves as 16-byte pieces, nine lanes per 144-byte row.  row_off(r) = element offset of
+// query row r of the wave's tile in `o`, or -1 for a row that does not exist.
+template <typename RowOff>
+__device__ __forceinline__ void store_o72_staged(const f32x16 (&oacc)[3], float inv, char* stage, int lane, char* o, RowOff row_off) {
+  const int lr = lane & 31, lh = lane >> 5;
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int d0 = t * 32 + 8 * g + 4 * lh;
+      if (d0 < 72) {
+        f16x4 ov;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ov[e] = (f16)(oacc[t][4 * g + e] * inv);
+        *reinterpret_cast<f16x4*>(stage + lr * 144 + d0 * 2) = ov;
+      }
+    }
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    const int id = lane + 64 * i;
+    if (id < 288) {
+      const int r = id / 9, ch = id - r * 9;
+      const long long off = row_off(r);
+      if (off >= 0) *reinterpret_cast<u32x4*>(o + (off + ch * 8) * 2) = *reinterpret_cast<const u32x4*>(stage + r * 144 + ch * 16);
+    }
+  }
+}
 
 // XCD-aware workgroup order (speed only, bijective for any grid size).  Workgroups are dealt round-robin over the 8 XCDs, each with a
 // private L2.  With the natural order the 8 heads of one window -- whose 144-byte K / V rows share 128-byte lines of the interleaved
@@ -698,7 +731,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_res256_kernel(const AttnArgs 
     const char* vbase = p.v + (vorg + (long long)h * p.v_sh) * 2;
 #pragma unroll
     for (int j = 0; j < (36 + NW - 1) / NW; ++j) {
-      if (j * NW + wv >= 36) break;                           // 36 wave-instructions per matrix (wave-uniform)
+      if (j * NW + wv >= 36 || (p.diag & 2)) break;           // 36 wave-instructions per matrix (wave-uniform)
       const int L = (j * NW + wv) * 64 + lane;
       const int row = L / CH, ch = L - row * CH;
       int pix = row;
@@ -791,7 +824,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_res256_kernel(const AttnArgs 
   }
 
 #pragma unroll 1
-  for (int kc = 0; kc < NK / 64; ++kc) {
+  for (int kc = 0; kc < ((p.diag & 1) ? 0 : NK / 64); ++kc) {
     f32x16 sacc[2];
 #pragma unroll
     for (int u = 0; u < 2; ++u)
@@ -876,6 +909,19 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_res256_kernel(const AttnArgs 
             oacc[t] = CVMI_MFMA_32X32X16(__builtin_bit_cast(f16x8, vv), pf[u][s], oacc[t], 0, 0, 0);
           }
     }
+  }
+  if (p.ostage) {                                           // (uniform)
+    __syncthreads();                                        // every wave is done with the window's K (and V): the stage reuses the K region
+    const float inv = 1.f / l_run;                          // (rows that do not exist: l_run of garbage, never stored)
+    const int ow_ = p.q_pool ? p.win / 2 : p.win, ogh_ = p.q_pool ? p.grid_h / 2 : p.grid_h, ogw_ = p.q_pool ? p.grid_w / 2 : p.grid_w;
+    if (live)
+      store_o72_staged(oacc, inv, Ks + wv * 4608, lane, p.o, [&](int r) -> long long {
+        const int q = qt * 32 + r;
+        if (q >= p.Nq) return -1;
+        const long long ob = p.win > 0 ? tok_off(b, q, p.o_sb, p.o_st, ow_, ogh_, ogw_) : (long long)b * p.o_sb + (long long)q * p.o_st;
+        return ob + (long long)h * p.o_sh;
+      });
+    return;
   }
   if (q_ok) {
     const float inv = 1.f / l_run;
@@ -1055,6 +1101,19 @@ __global__ __launch_bounds__(QT * 128, 4) void attn_res64_kernel(const AttnArgs 
           const u32x4 vv = {l2[0], l2[1], h2[0], h2[1]};
           oacc[t] = CVMI_MFMA_32X32X16(__builtin_bit_cast(f16x8, vv), pf[u][s], oacc[t], 0, 0, 0);
         }
+  }
+  if (p.ostage) {                                           // (uniform)
+    __syncthreads();                                        // both items' waves are done with their K / V
+    const float inv = 1.f / l_run;                          // (rows that do not exist: l_run of garbage, never stored)
+    const int ow_ = p.q_pool ? p.win / 2 : p.win, ogh_ = p.q_pool ? p.grid_h / 2 : p.grid_h, ogw_ = p.q_pool ? p.grid_w / 2 : p.grid_w;
+    if (live)
+      store_o72_staged(oacc, inv, Ks + wv * 4608, lane, p.o, [&](int r) -> long long {
+        const int q = qt * 32 + r;
+        if (q >= p.Nq) return -1;
+        const long long ob = p.win > 0 ? tok_off(b, q, p.o_sb, p.o_st, ow_, ogh_, ogw_) : (long long)b * p.o_sb + (long long)q * p.o_st;
+        return ob + (long long)h * p.o_sh;
+      });
+    return;
   }
   if (q_ok) {
     const float inv = 1.f / l_run;
@@ -1321,6 +1380,18 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_dma72_kernel(const AttnArgs p
     }
     dma_wait();                                             // this wave's pieces of tile kt + 1 (issued a whole tile of MFMAs ago)
     __syncthreads();                                        // tile kt fully read; tile kt + 1 landed in every wave
+  }
+  if (p.ostage) {                                           // (uniform)
+    const float inv = 1.f / l_run;                          // (rows that do not exist: l_run of garbage, never stored)
+    const int ow_ = p.q_pool ? p.win / 2 : p.win, ogh_ = p.q_pool ? p.grid_h / 2 : p.grid_h, ogw_ = p.q_pool ? p.grid_w / 2 : p.grid_w;
+    if (live)
+      store_o72_staged(oacc, inv, smem + wv * 4608, lane, p.o, [&](int r) -> long long {
+        const int q = qt * 32 + r;
+        if (q >= p.Nq) return -1;
+        const long long ob = p.win > 0 ? tok_off(b, q, p.o_sb, p.o_st, ow_, ogh_, ogw_) : (long long)b * p.o_sb + (long long)q * p.o_st;
+        return ob + (long long)h * p.o_sh;
+      });
+    return;
   }
   if (q_ok) {
     const float inv = 1.f / l_run;
@@ -1641,6 +1712,10 @@ extern "C" int CVMI_ENTRY(cvmi_attention)(const cvmi_attn_desc* d, cvmi_stream_t
   a.xcd = use_xcd;
   static const float defer = getenv("CVMI_ATTN_DEFER") ? (float)atof(getenv("CVMI_ATTN_DEFER")) : DEFER_LOG2;   // A/B runs only
   a.defer = defer;
+  static const int diag = getenv("CVMI_ATTN_DIAG") ? atoi(getenv("CVMI_ATTN_DIAG")) : 0;
+  a.diag = diag;
+  static const int ost = getenv("CVMI_ATTN_OSTAGE") ? atoi(getenv("CVMI_ATTN_OSTAGE")) : 1;                // A/B runs only
+  a.ostage = ost && ((uintptr_t)d->o & 15) == 0 && d->o_st % 8 == 0 && d->o_sh % 8 == 0 && d->o_sb % 8 == 0 && d->dv == 72;
   if (d->win > 0) {
     CVMI_CHECK(d->grid_h % d->win == 0 && d->grid_w % d->win == 0, "attention: grid %dx%d not divisible by window %d", d->grid_h, d->grid_w, d->win);
     CVMI_CHECK(d->Nk == d->win * d->win, "attention: window mode needs Nk == win^2");

@@ -37,6 +37,7 @@ struct ConvKArgs {
   int nb_n;
   int bias_off;                          // igemm_kernel: LDS byte offset of the parked bias row
   int rev_m;                             // gemm256x192: 1 = walk the row blocks last-to-first (see launch_g256x192)
+  int per_xcd;                           // gemm256x192r: tiles per XCD
   float* stats;                          // gemm256x192 (f32 out): per row and 96-column slice (mean, sum of squared deviations from it) of the values written, or null
   FastDiv div_ctot, div_kw;
 };
@@ -1486,6 +1487,239 @@ __global__ __launch_bounds__(512, 1) void gemm256x192_kernel(const ConvKArgs p) 
   }
 }
 
+// ---- Row-block-persistent form of gemm256x192_kernel<float, true> for the launch it is dominant in (Hiera-L stage-3 fc2: M = 65536,
+//      N = 576 = 3 tiles, K = 2304, f32 output + f32 residual + row statistics).  Measured on the one-tile-per-workgroup kernel (r03): a
+//      round of 256 tiles is ~43 us of K-loop at the matrix pipe's limit followed by ~20 us in which every CU reads its 196 KB of residual
+//      and writes its 196 KB of output at the same moment -- the launch pays its MFMA bound and its HBM bound in series.  Here a persistent
+//      workgroup per CU walks its three tiles as ONE software pipeline of 3 x 36 K-tiles (the DMA of the next tile's first two K-tiles is
+//      issued under the current tile's last two; which tiles: see tile0 below -- a first form that gave a workgroup the three column tiles
+//      of ONE row block re-read A from HBM twice, 37 MB of A rows per XCD do not live in a 4 MB L2: 290 us), and the residual is folded
+//      INTO THE ACCUMULATOR while the K-loop runs: a tile's K-loop is four unrolled segments, segment s loads the 6 x 16 bytes per lane of
+//      16-pixel block s (inline-asm loads the compiler's waitcnt pass does not see; the counted vmcnt of the K-tile after next retires
+//      them, loads return in order) and adds them to acc16[..][..][s] in the segment's last K-tile.  The K-tile in which a workgroup issues its loads
+//      is staggered by blockIdx (the CUs run in lock step; 256 x 49 KB at one instant would queue behind each other).  What is left
+//      between two tiles is + bias, the statistics and 24 stores per lane; stores and DMA loads share vmcnt on gfx9, and because loads
+//      retire in order among themselves a counted wait after the stores is conservative, never early.
+//      Summation order: (residual + sum of products) + bias instead of (sum + bias) + residual -- f32 either way.
+__global__ __launch_bounds__(512, 1) void gemm256x192r_kernel(const ConvKArgs p) {
+  constexpr int BM = 256, BKB = 128;
+  constexpr int STAGE = (BM + 192) * BKB;                 // 56 KiB
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  // Tiles of this workgroup: the order the hardware would dispatch the one-tile kernel's grid in.  Workgroup i runs on XCD i % 8; XCD x owns
+  // tiles [x T / 8, (x + 1) T / 8) (row block = tile / nb_n: the column siblings of a row block are neighbours), and in round r its 32
+  // workgroups take 32 consecutive ones -- the three siblings stream the same A rows through that XCD's L2 at the same time, as before.
+  const int wgx = (int)gridDim.x >> 3, per_xcd = p.per_xcd;                 // workgroups per XCD, tiles per XCD (host: T % gridDim == 0)
+  const int tile0 = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
+  const int ntile = per_xcd / wgx;
+  const long long xrow = (long long)p.x0_ld * 2 * BM, wrow = (long long)p.Kpad * 2 * 192;      // bytes per row block of X / per column tile of W
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int wp = wv & 3, wh = wv >> 2;
+  const int r16 = lane & 15, g16 = lane >> 4;
+  const int nk = p.K >> 6, nseg = nk >> 2;                // host: K % 256 == 0, K / 256 >= 9
+  const int ng = nk * ntile;
+  const int ji = (int)(blockIdx.x % 7u);                  // K-tile of a segment in which this workgroup issues its residual loads
+
+  const char* src[7];
+  int dst[7];
+#pragma unroll
+  for (int u = 0; u < 7; ++u) {
+    int row0;
+    if (u < 4) row0 = (u >> 1) * 128 + (wv * 2 + (u & 1)) * 8;
+    else row0 = BM + (wv >> 2) * 96 + (u - 4) * 32 + (wv & 3) * 8;
+    const int row = row0 + (lane >> 3);
+    const int slot = (lane & 7) ^ ((row >> 1) & 7);
+    if (row < BM) src[u] = p.x0 + ((size_t)row * p.x0_ld + slot * 8) * 2;
+    else src[u] = p.w + ((size_t)(row - BM) * p.Kpad + slot * 8) * 2;
+    dst[u] = row0 * BKB;
+  }
+#define R192_ISSUE1(u, stage, off)                                                                                       \
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[u] + (off)),                      \
+                                   (__attribute__((address_space(3))) void*)(smem + (stage) * STAGE + dst[u]), 16, 0, 0)
+#define R192_X0(stage, xo) do { R192_ISSUE1(0, stage, xo); R192_ISSUE1(1, stage, xo); } while (0)
+#define R192_X1(stage, xo) do { R192_ISSUE1(2, stage, xo); R192_ISSUE1(3, stage, xo); } while (0)
+#define R192_WC(k, stage, wo) R192_ISSUE1(4 + (k), stage, wo)
+
+  f32x4 acc16[3][2][4];                                   // [32-channel block][16-channel half][16-pixel block]
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc16[i][hh][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  f32x4 rv[6];                                            // the residual batch in flight
+#pragma unroll
+  for (int k = 0; k < 6; ++k) rv[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int sw = (r16 >> 1) & 7;
+  int ko[4];
+#pragma unroll
+  for (int s2 = 0; s2 < 4; ++s2) ko[s2] = (((4 * (s2 & 1) + g16) ^ sw) << 4) + (s2 >> 1) * 16 * BKB;
+  const int xbase = (wp * 64 + r16) * BKB, wbase = (BM + wh * 96 + r16) * BKB;
+
+  // stream offsets (bytes) of K-tiles g + 1 and g + 2 of the ntile x nk stream
+  const long long xo0 = (long long)(tile0 / p.nb_n) * xrow, wo0 = (long long)(tile0 % p.nb_n) * wrow;
+  long long xo1 = xo0 + BKB, wo1 = wo0 + BKB, xo2 = xo0 + 2 * BKB, wo2 = wo0 + 2 * BKB;
+  int kt2 = 2, tl2 = tile0;                               // (g + 2) % nk and the tile K-tile g + 2 belongs to
+  R192_X0(0, xo0); R192_WC(0, 0, wo0); R192_X1(0, xo0); R192_WC(1, 0, wo0); R192_WC(2, 0, wo0);
+  R192_X0(1, xo1); R192_WC(0, 1, wo1); R192_X1(1, xo1); R192_WC(1, 1, wo1);
+  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  if (wh == 1) __builtin_amdgcn_s_barrier();
+
+  u32x4 xf[2][4], wf[4];
+#define R192_READ_X(j)                                                                                                   \
+  _Pragma("unroll") for (int s2 = 0; s2 < 4; ++s2)                                                                       \
+      xf[j][s2] = *reinterpret_cast<const u32x4*>(st + xbase + (j) * 32 * BKB + ko[s2])
+#define R192_READ_W(i)                                                                                                   \
+  _Pragma("unroll") for (int s2 = 0; s2 < 4; ++s2)                                                                       \
+      wf[s2] = *reinterpret_cast<const u32x4*>(st + wbase + (i) * 32 * BKB + ko[s2])
+#define R192_SYNC_IN()                                                                                                   \
+  do {                                                                                                                   \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                   \
+    __builtin_amdgcn_sched_barrier(0);                                                                                   \
+    __builtin_amdgcn_s_barrier();                                                                                        \
+    __builtin_amdgcn_sched_barrier(0);                                                                                   \
+    __builtin_amdgcn_s_setprio(1);                                                                                       \
+  } while (0)
+#define R192_SYNC_OUT()                                                                                                  \
+  do {                                                                                                                   \
+    __builtin_amdgcn_s_setprio(0);                                                                                       \
+    __builtin_amdgcn_sched_barrier(0);                                                                                   \
+    __builtin_amdgcn_s_barrier();                                                                                        \
+    __builtin_amdgcn_sched_barrier(0);                                                                                   \
+  } while (0)
+#define R192_MMA(i)                                                                                                      \
+  asm volatile("" : "+v"(wf[0]), "+v"(wf[1]), "+v"(wf[2]), "+v"(wf[3]));                                                 \
+  _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                                       \
+  _Pragma("unroll") for (int hh = 0; hh < 2; ++hh)                                                                       \
+  _Pragma("unroll") for (int pq = 0; pq < 4; ++pq)                                                                       \
+    acc16[i][hh][pq] = CVMI_MFMA_16X16X32(__builtin_bit_cast(f16x8, wf[ks + 2 * hh]),                                    \
+                                          __builtin_bit_cast(f16x8, xf[pq >> 1][ks + 2 * (pq & 1)]), acc16[i][hh][pq], 0, 0, 0); \
+  asm volatile("" : "+v"(acc16[i][0][0]), "+v"(acc16[i][0][1]), "+v"(acc16[i][0][2]), "+v"(acc16[i][0][3]),              \
+                    "+v"(acc16[i][1][0]), "+v"(acc16[i][1][1]), "+v"(acc16[i][1][2]), "+v"(acc16[i][1][3]));
+#define R192_RLOAD(k, off)                                                                                               \
+  asm volatile("global_load_dwordx4 %0, %1, off offset:" #off : "+v"(rv[k]) : "v"(rptr) : "memory")
+
+  int g = 0;
+#pragma unroll 1
+  for (int tl = 0; tl < ntile; ++tl) {
+    const int tile = tile0 + tl * wgx, bm = tile / p.nb_n, bn = tile - bm * p.nb_n;
+    const size_t mrow = (size_t)bm * BM + wp * 64 + r16;  // this lane's pixel of 16-pixel block 0
+    const int ncol = bn * 192 + wh * 96 + 4 * g16;        // this lane's first channel of the tile
+    // the tile's bias: loaded here, used behind the K-loop, and by inline asm like the residual -- hipcc's waitcnt pass would drain vmcnt
+    // (the DMA in flight) in front of the first use of a load it can see.  K-tile 0's counted wait retires them.
+    f32x4 bv[3][2];
+    {
+      const float* bptr = p.bias + ncol;
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(bv[0][0]) : "v"(bptr) : "memory");
+      asm volatile("global_load_dwordx4 %0, %1, off offset:64" : "=v"(bv[0][1]) : "v"(bptr) : "memory");
+      asm volatile("global_load_dwordx4 %0, %1, off offset:128" : "=v"(bv[1][0]) : "v"(bptr) : "memory");
+      asm volatile("global_load_dwordx4 %0, %1, off offset:192" : "=v"(bv[1][1]) : "v"(bptr) : "memory");
+      asm volatile("global_load_dwordx4 %0, %1, off offset:256" : "=v"(bv[2][0]) : "v"(bptr) : "memory");
+      asm volatile("global_load_dwordx4 %0, %1, off offset:320" : "=v"(bv[2][1]) : "v"(bptr) : "memory");
+    }
+#pragma unroll
+    for (int seg = 0; seg < 4; ++seg) {
+      const float* rptr = reinterpret_cast<const float*>(p.res) + (mrow + seg * 16) * p.res_ld + ncol;
+#pragma unroll 1
+      for (int j = 0; j < nseg; ++j, ++g) {
+        const int b = g & 1;
+        const char* st = smem + b * STAGE;
+        const bool more1 = g + 1 < ng, more2 = g + 2 < ng;
+        if (j == nseg - 1) {                                // the same K-tile in EVERY workgroup (the rounding sequence of a row must not depend on where its image sits in the batch); the batch was retired by the counted wait of K-tile ji + 1 <= nseg - 2
+#pragma unroll
+          for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) acc16[i][hh][seg] += rv[2 * i + hh];
+        }
+        // ---- phase 1
+        R192_READ_W(0);
+        R192_READ_X(0);
+        R192_READ_X(1);
+        if (more1) R192_WC(2, b ^ 1, wo1);
+        R192_SYNC_IN();
+        R192_MMA(0)
+        R192_SYNC_OUT();
+        // ---- phase 2
+        R192_READ_W(1);
+        if (more2) { R192_X0(b, xo2); R192_WC(0, b, wo2); }
+        R192_SYNC_IN();
+        R192_MMA(1)
+        R192_SYNC_OUT();
+        // ---- phase 3
+        R192_READ_W(2);
+        if (more2) { R192_X1(b, xo2); R192_WC(1, b, wo2); }
+        if (j == ji) {                                      // (uniform) six more loads in flight behind the DMA: one counted wait covers both
+          R192_RLOAD(0, 0); R192_RLOAD(1, 64); R192_RLOAD(2, 128); R192_RLOAD(3, 192); R192_RLOAD(4, 256); R192_RLOAD(5, 320);
+          if (more2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+          else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");          // (cannot happen for ji + 2 < nseg; kept exact anyway)
+        } else {
+          if (more2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+          else if (more1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        R192_SYNC_IN();
+        R192_MMA(2)
+        R192_SYNC_OUT();
+        xo1 = xo2; wo1 = wo2;
+        if (++kt2 == nk) {
+          kt2 = 0; tl2 += wgx;
+          const int bm2 = tl2 / p.nb_n;
+          xo2 = (long long)bm2 * xrow; wo2 = (long long)(tl2 - bm2 * p.nb_n) * wrow;
+        } else { xo2 += BKB; wo2 += BKB; }
+      }
+    }
+    // ---- between two tiles: + bias, row statistics, 24 stores per lane; no LDS, no barrier (the next tile's first K-tiles are landing)
+    {
+      const int slices = p.N / 96;
+#pragma unroll
+      for (int pq = 0; pq < 4; ++pq) {
+        const size_t m = mrow + pq * 16;
+        float* yrow = reinterpret_cast<float*>(p.y) + m * p.y_ld + ncol;
+        f32x4 v[3][2];
+        float sm = 0.f;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+          for (int hh = 0; hh < 2; ++hh) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[i][hh][e] = acc16[i][hh][pq][e] + bv[i][hh][e];
+            *reinterpret_cast<f32x4*>(yrow + i * 32 + hh * 16) = v[i][hh];
+            sm += (v[i][hh][0] + v[i][hh][1]) + (v[i][hh][2] + v[i][hh][3]);
+            acc16[i][hh][pq] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          }
+        if (p.stats) {                                          // (uniform)
+          sm += __shfl_xor(sm, 16);
+          sm += __shfl_xor(sm, 32);
+          const float mean = sm * (1.0f / 96.0f);
+          float m2 = 0.f;
+#pragma unroll
+          for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+              for (int e = 0; e < 4; ++e) { const float dv = v[i][hh][e] - mean; m2 = fmaf(dv, dv, m2); }
+          m2 += __shfl_xor(m2, 16);
+          m2 += __shfl_xor(m2, 32);
+          if (g16 == 0) *reinterpret_cast<float2*>(p.stats + (m * slices + (bn * 2 + wh)) * 2) = make_float2(mean, m2);
+        }
+      }
+    }
+  }
+  if (wh == 0) __builtin_amdgcn_s_barrier();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#undef R192_ISSUE1
+#undef R192_X0
+#undef R192_X1
+#undef R192_WC
+#undef R192_READ_X
+#undef R192_READ_W
+#undef R192_SYNC_IN
+#undef R192_SYNC_OUT
+#undef R192_MMA
+#undef R192_RLOAD
+}
+
 template <typename TO>
 int launch_g256x192(ConvKArgs& a, hipStream_t stream) {
   constexpr int lds = 2 * (256 + 192) * 128;
@@ -1505,6 +1739,22 @@ int launch_g256x192(ConvKArgs& a, hipStream_t stream) {
   // first-to-last by the launch in front of this one, so its LAST rows are the ones still on the die when this launch starts.
   static const int rev = getenv("CVMI_G192_REV") ? atoi(getenv("CVMI_G192_REV")) : 0;   // measured r03 (call r3j): no effect (207.6 vs 206.3 us) -- off
   a.rev_m = rev;
+  if constexpr (sizeof(TO) == 4) {
+    static const int persist = getenv("CVMI_G192_PERSIST") ? atoi(getenv("CVMI_G192_PERSIST")) : 1;     // A/B runs only
+    if (persist && m16 && a.res && a.act == CVMI_ACT_NONE && !a.act_after_res && a.res_mod == 0 && a.M % 256 == 0 && a.N % 192 == 0 &&
+        a.K % 256 == 0 && a.K / 256 >= 9 && blocks % 256 == 0) {             // whole rounds of 256 tiles: one workgroup per CU
+      static bool attr_r = false;
+      if (!attr_r) {
+        CVMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256x192r_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_r = true;
+      }
+      cvmi_note_kernel("gemm256x192r_kernel");
+      a.per_xcd = (int)(blocks / 8);
+      hipLaunchKernelGGL(gemm256x192r_kernel, dim3(256), dim3(512), lds, stream, a);
+      CVMI_LAUNCH_CHECK();
+      return 0;
+    }
+  }
   cvmi_note_kernel("gemm256x192_kernel<%s, %s>", sizeof(TO) == 2 ? CVMI_F16NAME : "float", CVMI_BOOLNAME(m16));
   if (m16) hipLaunchKernelGGL((gemm256x192_kernel<TO, true>), dim3((unsigned)blocks), dim3(512), bytes, stream, a);
   else hipLaunchKernelGGL((gemm256x192_kernel<TO, false>), dim3((unsigned)blocks), dim3(512), bytes, stream, a);

@@ -741,8 +741,10 @@ def test_gemm_row_statistics_feed_the_next_layernorm(dt):
     torch.testing.assert_close(parts, exp, rtol=2e-5, atol=2e-4)
     # the offset rows: the forwarded statistics give the same normalised rows as the two-pass prologue (variance not lost to cancellation)
     torch.testing.assert_close(oa[:256].float(), ob[:256].float(), rtol=2e-3 * tol, atol=2e-3 * tol)
-    ref_rows = (x0.double() + hid.double() @ w.double().cuda().t() + b.double().cuda())[:512]
-    torch.testing.assert_close(x1[:512], ref_rows, rtol=2e-3 * tol, atol=2e-3 * tol)
+    wd, bd = w.double().cuda().t().contiguous(), b.double().cuda()
+    for r0 in range(0, M, 8192):                                 # EVERY row block and column tile (the row-block-persistent kernel walks 3 tiles per workgroup)
+        ref_rows = x0[r0:r0 + 8192].double() + hid[r0:r0 + 8192].double() @ wd + bd
+        torch.testing.assert_close(x1[r0:r0 + 8192], ref_rows, rtol=2e-3 * tol, atol=2e-3 * tol)
     torch.testing.assert_close(oa.float(), ob.float(), rtol=2e-3 * tol, atol=2e-3 * tol)
     first = (parts.clone(), oa.clone())
     xb.t.copy_(x0.view(1, 1, M, N)); parts.zero_()
