@@ -383,11 +383,16 @@ class SamStage:
             n_pass = sh["n"] // reps
             us = sh["ms"] / sh["n"] * 1e3
             tr = next((e["hbm_bytes"] for e in traffic.get(kn, []) if e.get("launches_per_pass") == n_pass), None)
-            mfma = sh["kind"] in self.MFMA_KINDS and f > 0
+            # which roof: the one that gives the LARGER lower bound on the launch's time (the roofline model's ridge, MFMA peak / HBM peak =
+            # 312 flop per byte): t_mfma = flops / dense peak, t_hbm = algorithmic (plan) bytes / HBM peak.  Both fractions are reported.
+            t_mfma = f / (MFMA_PEAK_TFLOPS * 1e12) if sh["kind"] in self.MFMA_KINDS else 0.0
+            t_hbm = b / (HBM_PEAK_GBS * 1e9)
+            mfma = t_mfma >= t_hbm and f > 0
             ach = f / (us * 1e-6) / 1e12 if mfma else b / (us * 1e-6) / 1e9
             peak = MFMA_PEAK_TFLOPS if mfma else HBM_PEAK_GBS
             tops.append({"bound": "mfma" if mfma else "hbm", "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s" if mfma else "GB/s",
                          "frac": round(ach / peak, 4), "traffic": tr, "traffic_source": tsrc if tr is not None else None,
+                         "mfma_frac": round(t_mfma / (us * 1e-6), 4), "hbm_frac": round(t_hbm / (us * 1e-6), 4),
                          "kernel": f"{kn}: {n_pass} launches per B={self.B} pass (e.g. {', '.join(sh['labels'])}), {100 * sh['ms'] / reps / total_ms:.1f} % of the pass's summed "
                                    "launch time; average of HIP event pairs on the engine stream over un-captured passes",
                          "us_per_launch": round(us, 2), "launches_per_pass": n_pass, "share_of_pass": round(sh["ms"] / reps / total_ms, 4),
@@ -406,11 +411,15 @@ class SamStage:
                                  ("sam2l_attention_window", "attn_window", "Hiera windowed attention (attn_res256 / attn_res64 / attn_win16 kernels)")):
             if kind not in acc:
                 continue
-            ms, n, _, fl = acc[kind]
-            ach = fl / (ms * 1e-3) / 1e12
-            roofs[name] = {"bound": "mfma", "achieved": round(ach, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4),
+            ms, n, by, fl = acc[kind]
+            t_mfma, t_hbm = fl / (MFMA_PEAK_TFLOPS * 1e12), by / (HBM_PEAK_GBS * 1e9)          # the family's two lower bounds (ridge rule as above)
+            mfma = t_mfma >= t_hbm
+            ach = fl / (ms * 1e-3) / 1e12 if mfma else by / (ms * 1e-3) / 1e9
+            peak = MFMA_PEAK_TFLOPS if mfma else HBM_PEAK_GBS
+            roofs[name] = {"bound": "mfma" if mfma else "hbm", "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s" if mfma else "GB/s",
+                           "frac": round(ach / peak, 4), "mfma_frac": round(t_mfma / (ms * 1e-3), 4), "hbm_frac": round(t_hbm / (ms * 1e-3), 4),
                            "traffic": None, "kernel": f"{what}: aggregate of {n // reps} launches per B={self.B} pass",
-                           "kernel_ms_per_step": round(ms, 3), "algorithmic_flops_per_step": int(fl)}
+                           "kernel_ms_per_step": round(ms, 3), "algorithmic_flops_per_step": int(fl), "plan_bytes_per_step": int(by)}
         roofs["sam2l_linear_gemm"]["whole_pass_tflops"] = round(self.B * SAM_FLOP_PER_IMAGE / (total_ms * 1e-3) / 1e12, 1)
         acc.pop("linear")
         breakdown = {k: {"ms": round(v[0], 3), "launches": v[1] // reps, "gflop": round(v[3] / 1e9, 1),

@@ -27,7 +27,6 @@ struct AttnArgs {
   int q_bdiv, kv_bdiv;   // batch sharing (no window): q rows of batch entry b come from entry b / q_bdiv, k / v rows from b / kv_bdiv
   int qtiles;      // ceil(Nq / 32)
   int items;       // B * heads * qtiles
-  int ostage;      // 1: head_dim-72 kernels store O through an LDS stage as 144-byte row pieces (needs 16-byte aligned o / strides); 0: direct 8-byte stores
   int diag;        // CVMI_ATTN_DIAG, timing experiments ONLY (results are wrong): bit 0 = attn_res256 skips its key-tile loop, bit 1 = skips its K / V DMA
   float defer;     // deferred-rescale threshold in log2 units (DEFER_LOG2; CVMI_ATTN_DEFER=0 restores "rescale on every new maximum" for A/B runs)
   int xcd;         // 1: XCD-aware workgroup order (xcd_order below); 0: natural order (CVMI_ATTN_XCD=0, A/B runs only)
@@ -60,37 +59,6 @@ __device__ __forceinline__ float xhalf_sum(float x) {
 // saw a new maximum: almost every tile) becomes rare.  Everything at the old scale is rescaled exactly once when the reference does move:
 // O and l here, and no P is pending (it is exponentiated after the decision).  The e4m3 product keeps DEFER = 0: its P is scaled by 2^8 already.
 constexpr float DEFER_LOG2 = 8.0f;
-
-// Epilogue of the head_dim-72 kernels.  The accumulator has the query on the lane: stored directly, a wave writes 8-byte pieces of 64
-// different rows per instruction (576 of them for a 32 x 72 tile) -- with the Q loads that was 50 of the 16 x 16-window launch's 91 us
-// (CVMI_ATTN_DIAG=3, r03).  Here the wave's tile goes through a wave-private 32 x 144-byte LDS stage (the K / V region, dead after the
-// key loop: callers put a barrier in front) and leaves as 16-byte pieces, nine lanes per 144-byte row.  row_off(r) = element offset of
-// query row r of the wave's tile in `o`, or -1 for a row that does not exist.
-template <typename RowOff>
-__device__ __forceinline__ void store_o72_staged(const f32x16 (&oacc)[3], float inv, char* stage, int lane, char* o, RowOff row_off) {
-  const int lr = lane & 31, lh = lane >> 5;
-#pragma unroll
-  for (int t = 0; t < 3; ++t)
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int d0 = t * 32 + 8 * g + 4 * lh;
-      if (d0 < 72) {
-        f16x4 ov;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) ov[e] = (f16)(oacc[t][4 * g + e] * inv);
-        *reinterpret_cast<f16x4*>(stage + lr * 144 + d0 * 2) = ov;
-      }
-    }
-#pragma unroll
-  for (int i = 0; i < 5; ++i) {
-    const int id = lane + 64 * i;
-    if (id < 288) {
-      const int r = id / 9, ch = id - r * 9;
-      const long long off = row_off(r);
-      if (off >= 0) *reinterpret_cast<u32x4*>(o + (off + ch * 8) * 2) = *reinterpret_cast<const u32x4*>(stage + r * 144 + ch * 16);
-    }
-  }
-}
 
 // XCD-aware workgroup order (speed only, bijective for any grid size).  Workgroups are dealt round-robin over the 8 XCDs, each with a
 // private L2.  With the natural order the 8 heads of one window -- whose 144-byte K / V rows share 128-byte lines of the interleaved
@@ -910,19 +878,6 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_res256_kernel(const AttnArgs 
           }
     }
   }
-  if (p.ostage) {                                           // (uniform)
-    __syncthreads();                                        // every wave is done with the window's K (and V): the stage reuses the K region
-    const float inv = 1.f / l_run;                          // (rows that do not exist: l_run of garbage, never stored)
-    const int ow_ = p.q_pool ? p.win / 2 : p.win, ogh_ = p.q_pool ? p.grid_h / 2 : p.grid_h, ogw_ = p.q_pool ? p.grid_w / 2 : p.grid_w;
-    if (live)
-      store_o72_staged(oacc, inv, Ks + wv * 4608, lane, p.o, [&](int r) -> long long {
-        const int q = qt * 32 + r;
-        if (q >= p.Nq) return -1;
-        const long long ob = p.win > 0 ? tok_off(b, q, p.o_sb, p.o_st, ow_, ogh_, ogw_) : (long long)b * p.o_sb + (long long)q * p.o_st;
-        return ob + (long long)h * p.o_sh;
-      });
-    return;
-  }
   if (q_ok) {
     const float inv = 1.f / l_run;
     long long obase;
@@ -1102,19 +1057,6 @@ __global__ __launch_bounds__(QT * 128, 4) void attn_res64_kernel(const AttnArgs 
           oacc[t] = CVMI_MFMA_32X32X16(__builtin_bit_cast(f16x8, vv), pf[u][s], oacc[t], 0, 0, 0);
         }
   }
-  if (p.ostage) {                                           // (uniform)
-    __syncthreads();                                        // both items' waves are done with their K / V
-    const float inv = 1.f / l_run;                          // (rows that do not exist: l_run of garbage, never stored)
-    const int ow_ = p.q_pool ? p.win / 2 : p.win, ogh_ = p.q_pool ? p.grid_h / 2 : p.grid_h, ogw_ = p.q_pool ? p.grid_w / 2 : p.grid_w;
-    if (live)
-      store_o72_staged(oacc, inv, Ks + wv * 4608, lane, p.o, [&](int r) -> long long {
-        const int q = qt * 32 + r;
-        if (q >= p.Nq) return -1;
-        const long long ob = p.win > 0 ? tok_off(b, q, p.o_sb, p.o_st, ow_, ogh_, ogw_) : (long long)b * p.o_sb + (long long)q * p.o_st;
-        return ob + (long long)h * p.o_sh;
-      });
-    return;
-  }
   if (q_ok) {
     const float inv = 1.f / l_run;
     long long obase;
@@ -1158,7 +1100,7 @@ int launch_res64(const AttnArgs& a, hipStream_t stream) {
 // the tile's e4m3 V^T operand image (d tile t = wave / 2, operand half u = wave & 1) from the 16-bit tile in front of the QK^T products; a
 // second barrier per tile (LDS writes only: the next tile's DMA stays in flight across it) publishes the image before the three MFMAs.
 template <int NW, bool AV8 = false>
-__global__ __launch_bounds__(NW * 64, 2) void attn_dma72_kernel(const AttnArgs p) {
+__global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : 2) void attn_dma72_kernel(const AttnArgs p) {
   constexpr int ROW = 144, TK = 64, QS = 5, DT = 3, CH = 9;
   constexpr int TILE_B = TK * ROW;                          // 9216 B per matrix per buffer
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1186,20 +1128,24 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_dma72_kernel(const AttnArgs p
     kbase = p.k + (korg + (long long)h * p.k_sh) * 2;
     vbase = p.v + (vorg + (long long)h * p.v_sh) * 2;
   }
+  // Plain sequences in whole tiles only (the Hiera global blocks; the dispatcher sends windows and ragged lengths elsewhere): a piece's
+  // source is (uniform K / V base of this head + the tile's offset) + a 32-bit lane offset that never changes -- one VGPR per piece instead
+  // of row / chunk / clamp / window / pointer arithmetic per tile, which held the kernel above 128 registers, i.e. at ONE workgroup per CU.
+  unsigned loff[(18 + NW - 1) / NW];
+#pragma unroll
+  for (int j = 0; j < (18 + NW - 1) / NW; ++j) {
+    const int ins = j * NW + wv, isv = ins >= 9 ? 1 : 0, pc = ins - 9 * isv;
+    const int L = pc * 64 + lane, row = L / CH, ch = L - row * CH;
+    loff[j] = (unsigned)((row * (isv ? p.v_st : p.k_st) + ch * 8) * 2);
+  }
   auto issue = [&](int kt, int buf) {
 #pragma unroll
     for (int j = 0; j < (18 + NW - 1) / NW; ++j) {
       const int ins = j * NW + wv;                           // 0..8: K pieces, 9..17: V pieces (wave-uniform)
       if (ins >= 18) break;
       const int isv = ins >= 9 ? 1 : 0, pc = ins - 9 * isv;
-      const int L = pc * 64 + lane;
-      const int row = L / CH, ch = L - row * CH;
-      int key = kt * TK + row;
-      key = key < p.Nk ? key : p.Nk - 1;
-      int pix = key;
-      if (p.win > 0) { const int ty = (int)p.div_win.div((unsigned)key); pix = ty * p.grid_w + (key - ty * p.win); }
-      const char* src = isv ? vbase + ((long long)pix * p.v_st + ch * 8) * 2 : kbase + ((long long)pix * p.k_st + ch * 8) * 2;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+      const char* tb = isv ? vbase + (long long)kt * TK * p.v_st * 2 : kbase + (long long)kt * TK * p.k_st * 2;      // (uniform)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(tb + loff[j]),
                                        (__attribute__((address_space(3))) void*)(smem + buf * 2 * TILE_B + isv * TILE_B + pc * 1024), 16, 0, 0);
     }
   };
@@ -1295,15 +1241,6 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_dma72_kernel(const AttnArgs p
         const f16x8 kf = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(kq + (kc * 64 + u * 32) * ROW + s * 32));
         sacc[u] = CVMI_MFMA_32X32X16(kf, __builtin_bit_cast(f16x8, qf[s]), sacc[u], 0, 0, 0);
       }
-    if (kt * TK + TK > p.Nk) {                              // ragged last tile only (wave-uniform)
-#pragma unroll
-      for (int u = 0; u < 2; ++u)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int key = kt * TK + u * 32 + key_perm72((r & 3) + 8 * (r >> 2) + 4 * lh);
-          if (key >= p.Nk) sacc[u][r] = -INFINITY;
-        }
-    }
     float mxa = max3f(sacc[0][0], sacc[1][0], sacc[0][8]), mxb = max3f(sacc[1][8], sacc[0][1], sacc[1][1]);      // two chains of v_max3_f32
 #pragma unroll
     for (int r = 2; r < 8; ++r) { mxa = max3f(mxa, sacc[0][r], sacc[1][r]); mxb = max3f(mxb, sacc[0][r + 7], sacc[1][r + 7]); }
@@ -1380,18 +1317,6 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_dma72_kernel(const AttnArgs p
     }
     dma_wait();                                             // this wave's pieces of tile kt + 1 (issued a whole tile of MFMAs ago)
     __syncthreads();                                        // tile kt fully read; tile kt + 1 landed in every wave
-  }
-  if (p.ostage) {                                           // (uniform)
-    const float inv = 1.f / l_run;                          // (rows that do not exist: l_run of garbage, never stored)
-    const int ow_ = p.q_pool ? p.win / 2 : p.win, ogh_ = p.q_pool ? p.grid_h / 2 : p.grid_h, ogw_ = p.q_pool ? p.grid_w / 2 : p.grid_w;
-    if (live)
-      store_o72_staged(oacc, inv, smem + wv * 4608, lane, p.o, [&](int r) -> long long {
-        const int q = qt * 32 + r;
-        if (q >= p.Nq) return -1;
-        const long long ob = p.win > 0 ? tok_off(b, q, p.o_sb, p.o_st, ow_, ogh_, ogw_) : (long long)b * p.o_sb + (long long)q * p.o_st;
-        return ob + (long long)h * p.o_sh;
-      });
-    return;
   }
   if (q_ok) {
     const float inv = 1.f / l_run;
@@ -1714,8 +1639,6 @@ extern "C" int CVMI_ENTRY(cvmi_attention)(const cvmi_attn_desc* d, cvmi_stream_t
   a.defer = defer;
   static const int diag = getenv("CVMI_ATTN_DIAG") ? atoi(getenv("CVMI_ATTN_DIAG")) : 0;
   a.diag = diag;
-  static const int ost = getenv("CVMI_ATTN_OSTAGE") ? atoi(getenv("CVMI_ATTN_OSTAGE")) : 1;                // A/B runs only
-  a.ostage = ost && ((uintptr_t)d->o & 15) == 0 && d->o_st % 8 == 0 && d->o_sh % 8 == 0 && d->o_sb % 8 == 0 && d->dv == 72;
   if (d->win > 0) {
     CVMI_CHECK(d->grid_h % d->win == 0 && d->grid_w % d->win == 0, "attention: grid %dx%d not divisible by window %d", d->grid_h, d->grid_w, d->win);
     CVMI_CHECK(d->Nk == d->win * d->win, "attention: window mode needs Nk == win^2");
@@ -1763,8 +1686,14 @@ extern "C" int CVMI_ENTRY(cvmi_attention)(const cvmi_attn_desc* d, cvmi_stream_t
   if (use_res64 && d->Nk == 64 && d->dqk == 72 && d->dv == 72 && d->k_st % 8 == 0 && d->v_st % 8 == 0 && (a.qtiles == 1 || a.qtiles == 2))
     return a.qtiles == 2 ? launch_res64<2>(a, stream) : launch_res64<1>(a, stream);
   static const int use_dma72 = getenv("CVMI_ATTN_DMA72") ? atoi(getenv("CVMI_ATTN_DMA72")) : 1;          // tuning experiments only
-  if (use_dma72 && d->Nk >= 512 && a.qtiles >= 8 && d->dqk == 72 && d->dv == 72 && d->k_st % 8 == 0 && d->v_st % 8 == 0 && !d->q_pool)
-    return d->av_fp8 ? launch_dma72<8, true>(a, stream) : launch_dma72<8>(a, stream);
+  if (use_dma72 && d->Nk >= 512 && d->Nk % 64 == 0 && d->win == 0 && a.qtiles >= 8 && d->dqk == 72 && d->dv == 72 && d->k_st % 8 == 0 && d->v_st % 8 == 0 && !d->q_pool)
+  {
+    // 4-wave workgroups: three per CU (3 waves per SIMD at <= 168 registers) against one 8-wave workgroup (2 per SIMD: 139 registers miss the
+    // 128 that a second one needs); each streams K / V for 128 queries instead of 256 (twice the L2 -> LDS traffic, same HBM traffic).
+    static const int nw = getenv("CVMI_ATTN_DMA72_NW") ? atoi(getenv("CVMI_ATTN_DMA72_NW")) : 4;            // A/B runs only
+    if (d->av_fp8) return launch_dma72<8, true>(a, stream);
+    return nw == 4 ? launch_dma72<4>(a, stream) : launch_dma72<8>(a, stream);
+  }
   if (d->dqk <= 32 && d->dv <= 32) return launch_f16_gs<32, 32>(a, stream);
   if (d->dqk <= 32 && d->dv <= 64) return launch_f16_gs<32, 64>(a, stream);
   if (d->dqk <= 64 && d->dv <= 64) return launch_f16_gs<64, 64>(a, stream);

@@ -280,8 +280,9 @@ def _attn_ref(q, k, v, scale):
     (1, 8, 300, 38, 32, 32),       # decoder image->token
     (1, 2, 130, 257, 72, 72),      # ragged q and key tiles
     (5, 3, 16, 16, 72, 72),        # tiny windows, private K/V tiles
-    (2, 3, 600, 600, 72, 72),      # long sequence, head_dim 72: DMA-streamed 64-key tiles (ragged last tile, ragged q tiles)
-    (1, 2, 1024, 1024, 72, 72),    # same, whole tiles
+    (2, 3, 600, 600, 72, 72),      # long sequence, head_dim 72, ragged last key tile: the general kernel
+    (2, 3, 600, 640, 72, 72),      # long sequence in whole 64-key tiles: DMA-streamed tiles (attn_dma72_kernel), ragged q tiles, idle waves in the last workgroup
+    (1, 2, 1024, 1024, 72, 72),    # same, whole q tiles
 ])
 def test_attention(dtype, shape):
     B, Hh, Nq, Nk, dqk, dv = shape
@@ -431,9 +432,10 @@ def test_attention_window_fp8_av_product(dtype):
 
 
 @pytest.mark.parametrize("dtype", [F16, BF16])
-@pytest.mark.parametrize("N", [1024, 600])
+@pytest.mark.parametrize("N", [1024, 1536])
 def test_attention_global_fp8_av_product(dtype, N):
-    """The same on the long-sequence kernel (attn_dma72_kernel<8, true>: Hiera's global blocks), whole tiles and a ragged last tile."""
+    """The same on the long-sequence kernel (attn_dma72_kernel<8, true>: Hiera's global blocks; whole 64-key tiles -- the dispatcher sends
+    ragged lengths and windows to the general kernel since r03)."""
     from circuitvision_amd.engine import TORCH_DTYPE
     td = TORCH_DTYPE[dtype]
     B, Hh, hd = 2, 3, 72
@@ -456,7 +458,7 @@ def test_attention_global_fp8_av_product(dtype, N):
         op_attention(plan, "t", desc, (qd, kd, vd, od))
         lib.cvmi_last_kernel()
         run(plan)
-        assert lib.cvmi_last_kernel().decode() == ("attn_dma72_kernel<8, true>" if fp8 else "attn_dma72_kernel<8, false>")
+        assert lib.cvmi_last_kernel().decode() in (("attn_dma72_kernel<8, true>",) if fp8 else ("attn_dma72_kernel<4, false>", "attn_dma72_kernel<8, false>"))
         outs[fp8] = od.float().cpu().view(B, N, Hh, hd).permute(0, 2, 1, 3)
     _check_fp8_av(f"global N = {N}", outs[1], outs[0], ref, emu, dtype, _attn_ref(q, k, v.abs(), scale))
 
