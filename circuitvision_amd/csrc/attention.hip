@@ -60,6 +60,34 @@ __device__ __forceinline__ float xhalf_sum(float x) {
 // O and l here, and no P is pending (it is exponentiated after the decision).  The e4m3 product keeps DEFER = 0: its P is scaled by 2^8 already.
 constexpr float DEFER_LOG2 = 8.0f;
 
+// 16 bytes per lane, global -> LDS, buffer addressing: descriptor over `base` (wave-uniform), lane offset in one VGPR, `soff` in an SGPR.
+// (A __device__ function, not kernel-body code: the host pass of hipcc drops a kernel's launch stub when its body names the descriptor type.)
+__device__ __forceinline__ void dma16_buffer(const char* base, char* lds, int voff, int soff) {
+  const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(base), 0, 0x7fffffff, 0x00020000);
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lds, 16, voff, soff, 0, 0);
+}
+
+// exp2(s c - mc) over two 32 x 32 score tiles -> the 16-bit P fragments and this lane's part of the row sum, as v_pk_fma_f32 / v_pk_add_f32
+// (two elements per VALU issue).  hipcc does not pair the scalar form by itself: 32 v_fma_f32 + 32 v_add_f32 per tile in the ISA of the
+// kernels before this helper, a quarter of the loop's VALU issue cycles.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float softmax_tiles_pk(const f32x16 (&sacc)[2], float c, float mc, f16x8 (&pf)[2][2]) {
+  const f32x2 c2 = {c, c}, m2 = {-mc, -mc};
+  f32x2 ps = {0.f, 0.f};
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+      f32x2 x = {sacc[u][r], sacc[u][r + 1]};
+      x = __builtin_elementwise_fma(x, c2, m2);
+      const f32x2 e = {__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1])};
+      ps += e;
+      pf[u][r >> 3][r & 7] = (f16)e[0];
+      pf[u][r >> 3][(r & 7) + 1] = (f16)e[1];
+    }
+  return ps[0] + ps[1];
+}
+
 // XCD-aware workgroup order (speed only, bijective for any grid size).  Workgroups are dealt round-robin over the 8 XCDs, each with a
 // private L2.  With the natural order the 8 heads of one window -- whose 144-byte K / V rows share 128-byte lines of the interleaved
 // [token][3 x heads x 72] qkv buffer -- land on 8 different XCDs and every line is fetched twice (PMC, r03: 413 MB read by the 16 x 16
@@ -558,14 +586,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn64_kernel(const 
     const float alpha = __builtin_amdgcn_exp2f(fmaf(m_run, c, -mc));
     float psum = 0.f;
     f16x8 pf[2][2];
-#pragma unroll
-    for (int u = 0; u < 2; ++u)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float pv = __builtin_amdgcn_exp2f(fmaf(sacc[u][r], c, -mc));
-        psum += pv;
-        pf[u][r >> 3][r & 7] = (f16)pv;
-      }
+    psum = softmax_tiles_pk(sacc, c, mc, pf);
     psum += __shfl_xor(psum, 32);
     l_run = l_run * alpha + psum;
     const float m_prev = m_run;
@@ -833,18 +854,10 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_res256_kernel(const AttnArgs 
       }
       psum *= 0.00390625f;                                  // back to the scale of l_run (exact: a power of two)
     } else {
-#pragma unroll
-      for (int u = 0; u < 2; ++u)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float pv = __builtin_amdgcn_exp2f(fmaf(sacc[u][r], c, -mc));
-          psum += pv;
-          pf[u][r >> 3][r & 7] = (f16)pv;
-        }
+      psum = softmax_tiles_pk(sacc, c, mc, pf);
     }
     psum = xhalf_sum(psum);
     l_run = l_run * alpha + psum;
-    const float m_prev = m_run;
     m_run = m_new;
     if (__any(grow)) {                                      // (a real branch: rare once the first tiles have set the reference)
       asm volatile("" ::: "memory");
@@ -1024,17 +1037,9 @@ __global__ __launch_bounds__(QT * 128, 4) void attn_res64_kernel(const AttnArgs 
     const float alpha = grow ? __builtin_amdgcn_exp2f(fmaf(m_run, c, -mc)) : 1.0f;
     float psum = 0.f;
     f16x8 pf[2][2];
-#pragma unroll
-    for (int u = 0; u < 2; ++u)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float pv = __builtin_amdgcn_exp2f(fmaf(sacc[u][r], c, -mc));
-        psum += pv;
-        pf[u][r >> 3][r & 7] = (f16)pv;
-      }
+    psum = softmax_tiles_pk(sacc, c, mc, pf);
     psum = xhalf_sum(psum);
     l_run = l_run * alpha + psum;
-    const float m_prev = m_run;
     m_run = m_new;
     if (__any(grow)) {                                      // (a real branch: rare once the first tiles have set the reference)
       asm volatile("" ::: "memory");
@@ -1100,7 +1105,7 @@ int launch_res64(const AttnArgs& a, hipStream_t stream) {
 // the tile's e4m3 V^T operand image (d tile t = wave / 2, operand half u = wave & 1) from the 16-bit tile in front of the QK^T products; a
 // second barrier per tile (LDS writes only: the next tile's DMA stays in flight across it) publishes the image before the three MFMAs.
 template <int NW, bool AV8 = false>
-__global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : 2) void attn_dma72_kernel(const AttnArgs p) {
+__global__ __launch_bounds__(NW * 64, NW == 4 ? 4 : 2) void attn_dma72_kernel(const AttnArgs p) {
   constexpr int ROW = 144, TK = 64, QS = 5, DT = 3, CH = 9;
   constexpr int TILE_B = TK * ROW;                          // 9216 B per matrix per buffer
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1131,22 +1136,24 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : 2) void attn_dma72_kernel(co
   // Plain sequences in whole tiles only (the Hiera global blocks; the dispatcher sends windows and ragged lengths elsewhere): a piece's
   // source is (uniform K / V base of this head + the tile's offset) + a 32-bit lane offset that never changes -- one VGPR per piece instead
   // of row / chunk / clamp / window / pointer arithmetic per tile, which held the kernel above 128 registers, i.e. at ONE workgroup per CU.
-  unsigned loff[(18 + NW - 1) / NW];
+  // Addressing: buffer_load ... lds with one descriptor per matrix (base = this head's K / V, uniform), the tile's byte offset in the SGPR
+  // offset and the piece's lane offset in ONE VGPR -- flat 64-bit lane pointers (what hipcc makes of global_load_lds here) cost ten VGPRs
+  // and a 64-bit add per piece and tile, and were what kept the 4-wave form over the 128 registers of four workgroups per CU.
+  int loff[(18 + NW - 1) / NW];
 #pragma unroll
   for (int j = 0; j < (18 + NW - 1) / NW; ++j) {
     const int ins = j * NW + wv, isv = ins >= 9 ? 1 : 0, pc = ins - 9 * isv;
     const int L = pc * 64 + lane, row = L / CH, ch = L - row * CH;
-    loff[j] = (unsigned)((row * (isv ? p.v_st : p.k_st) + ch * 8) * 2);
+    loff[j] = (row * (isv ? p.v_st : p.k_st) + ch * 8) * 2;
   }
+  const int ktile_b = TK * p.k_st * 2, vtile_b = TK * p.v_st * 2;                  // bytes per 64-key tile (host: Nk * stride * 2 < 2^31)
   auto issue = [&](int kt, int buf) {
 #pragma unroll
     for (int j = 0; j < (18 + NW - 1) / NW; ++j) {
       const int ins = j * NW + wv;                           // 0..8: K pieces, 9..17: V pieces (wave-uniform)
       if (ins >= 18) break;
       const int isv = ins >= 9 ? 1 : 0, pc = ins - 9 * isv;
-      const char* tb = isv ? vbase + (long long)kt * TK * p.v_st * 2 : kbase + (long long)kt * TK * p.k_st * 2;      // (uniform)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(tb + loff[j]),
-                                       (__attribute__((address_space(3))) void*)(smem + buf * 2 * TILE_B + isv * TILE_B + pc * 1024), 16, 0, 0);
+      dma16_buffer(isv ? vbase : kbase, smem + buf * 2 * TILE_B + isv * TILE_B + pc * 1024, loff[j], kt * (isv ? vtile_b : ktile_b));
     }
   };
   const int nkt = (p.Nk + TK - 1) / TK;
@@ -1269,18 +1276,10 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : 2) void attn_dma72_kernel(co
       }
       psum *= 0.00390625f;
     } else {
-#pragma unroll
-      for (int u = 0; u < 2; ++u)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float pv = __builtin_amdgcn_exp2f(fmaf(sacc[u][r], c, -mc));
-          psum += pv;
-          pf[u][r >> 3][r & 7] = (f16)pv;
-        }
+      psum = softmax_tiles_pk(sacc, c, mc, pf);
     }
     psum = xhalf_sum(psum);
     l_run = l_run * alpha + psum;
-    const float m_prev = m_run;
     m_run = m_new;
     if (__any(grow)) {                                      // (a real branch: rare once the first tiles have set the reference)
       asm volatile("" ::: "memory");
@@ -1686,11 +1685,13 @@ extern "C" int CVMI_ENTRY(cvmi_attention)(const cvmi_attn_desc* d, cvmi_stream_t
   if (use_res64 && d->Nk == 64 && d->dqk == 72 && d->dv == 72 && d->k_st % 8 == 0 && d->v_st % 8 == 0 && (a.qtiles == 1 || a.qtiles == 2))
     return a.qtiles == 2 ? launch_res64<2>(a, stream) : launch_res64<1>(a, stream);
   static const int use_dma72 = getenv("CVMI_ATTN_DMA72") ? atoi(getenv("CVMI_ATTN_DMA72")) : 1;          // tuning experiments only
-  if (use_dma72 && d->Nk >= 512 && d->Nk % 64 == 0 && d->win == 0 && a.qtiles >= 8 && d->dqk == 72 && d->dv == 72 && d->k_st % 8 == 0 && d->v_st % 8 == 0 && !d->q_pool)
+  if (use_dma72 && d->Nk >= 512 && d->Nk % 64 == 0 && d->win == 0 && a.qtiles >= 8 && d->dqk == 72 && d->dv == 72 && d->k_st % 8 == 0 && d->v_st % 8 == 0 && !d->q_pool &&
+      (long long)d->Nk * d->k_st * 2 < (1ll << 31) && (long long)d->Nk * d->v_st * 2 < (1ll << 31))
   {
-    // 4-wave workgroups: three per CU (3 waves per SIMD at <= 168 registers) against one 8-wave workgroup (2 per SIMD: 139 registers miss the
-    // 128 that a second one needs); each streams K / V for 128 queries instead of 256 (twice the L2 -> LDS traffic, same HBM traffic).
-    static const int nw = getenv("CVMI_ATTN_DMA72_NW") ? atoi(getenv("CVMI_ATTN_DMA72_NW")) : 4;            // A/B runs only
+    // 8 waves x 2 workgroups per CU (4 waves per SIMD: the kernel holds 127 registers since its DMA went to buffer addressing; at 139 it ran ONE
+    // workgroup per CU, 830 us per Hiera-L global block at B = 16).  4-wave workgroups, four per CU, were the stop-gap that showed it (-12 %);
+    // they stream K / V from L2 twice as often and are kept for A/B runs.
+    static const int nw = getenv("CVMI_ATTN_DMA72_NW") ? atoi(getenv("CVMI_ATTN_DMA72_NW")) : 8;
     if (d->av_fp8) return launch_dma72<8, true>(a, stream);
     return nw == 4 ? launch_dma72<4>(a, stream) : launch_dma72<8>(a, stream);
   }

@@ -194,3 +194,22 @@ def test_counted_lds_rings_hold_no_scalar_memory_instruction():
     if not os.path.exists(m.HIPCC):
         pytest.skip("hipcc not available")
     assert m.main(["tok_linear16.hip", "hiera_mlp.hip", "tok_linear.hip"]) == 0
+
+
+def test_attention_kernels_stay_inside_their_occupancy_register_budget():
+    """The global / windowed head_dim-72 attention kernels are designed for four waves per SIMD (two 8-wave workgroups per CU): <= 128 registers,
+    nothing spilled.  `__launch_bounds__` does not enforce that -- attn_dma72_kernel drifted to 139 registers in r03 and ran one workgroup per
+    CU, correct and 13 % slower.  tools/check_occupancy.py reads the kernel descriptors of the device assembly; the extraction is exercised on
+    a synthetic descriptor first."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("check_occupancy", os.path.join(ROOT, "tools", "check_occupancy.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    fake = "    .name:           _Zfoo_kernelILi8ELb0EE\n    .sgpr_count:     40\n    .vgpr_count:     139\n    .vgpr_spill_count: 0\n"
+    t = m.parse_table(fake)
+    assert t == {"_Zfoo_kernelILi8ELb0EE": (139, 0)}
+    assert m.check(t, {"foo_kernelILi8ELb0EE": 128}) and not m.check(t, {"foo_kernelILi8ELb0EE": 168}) and m.check(t, {"bar": 128})
+    if not os.path.exists(m.HIPCC):
+        pytest.skip("hipcc not available")
+    src, (extra, budgets) = next(iter(m.BUDGETS.items()))
+    assert m.check(m.kernel_table(src, extra), budgets) == []
