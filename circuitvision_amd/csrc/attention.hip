@@ -67,25 +67,21 @@ __device__ __forceinline__ void dma16_buffer(const char* base, char* lds, int vo
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lds, 16, voff, soff, 0, 0);
 }
 
-// exp2(s c - mc) over two 32 x 32 score tiles -> the 16-bit P fragments and this lane's part of the row sum, as v_pk_fma_f32 / v_pk_add_f32
-// (two elements per VALU issue).  hipcc does not pair the scalar form by itself: 32 v_fma_f32 + 32 v_add_f32 per tile in the ISA of the
-// kernels before this helper, a quarter of the loop's VALU issue cycles.
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ float softmax_tiles_pk(const f32x16 (&sacc)[2], float c, float mc, f16x8 (&pf)[2][2]) {
-  const f32x2 c2 = {c, c}, m2 = {-mc, -mc};
-  f32x2 ps = {0.f, 0.f};
+// exp2(s c - mc) over two 32 x 32 score tiles -> the 16-bit P fragments; returns this lane's part of the row sum (SUM = false: 0, the
+// caller takes the row sums from the matrix pipe).  Scalar f32 on purpose: packed v_pk_fma_f32 / v_pk_add_f32 halve the instruction
+// count but not the issue cycles beside MFMAs (MI355X_MICROARCH.md, 'price of one filler'; measured here r03: no change).
+template <bool SUM>
+__device__ __forceinline__ float softmax_tiles(const f32x16 (&sacc)[2], float c, float mc, f16x8 (&pf)[2][2]) {
+  float ps = 0.f;
 #pragma unroll
   for (int u = 0; u < 2; ++u)
 #pragma unroll
-    for (int r = 0; r < 16; r += 2) {
-      f32x2 x = {sacc[u][r], sacc[u][r + 1]};
-      x = __builtin_elementwise_fma(x, c2, m2);
-      const f32x2 e = {__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1])};
-      ps += e;
-      pf[u][r >> 3][r & 7] = (f16)e[0];
-      pf[u][r >> 3][(r & 7) + 1] = (f16)e[1];
+    for (int r = 0; r < 16; ++r) {
+      const float pv = __builtin_amdgcn_exp2f(fmaf(sacc[u][r], c, -mc));
+      if constexpr (SUM) ps += pv;
+      pf[u][r >> 3][r & 7] = (f16)pv;
     }
-  return ps[0] + ps[1];
+  return ps;
 }
 
 // XCD-aware workgroup order (speed only, bijective for any grid size).  Workgroups are dealt round-robin over the 8 XCDs, each with a
@@ -586,7 +582,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn64_kernel(const 
     const float alpha = __builtin_amdgcn_exp2f(fmaf(m_run, c, -mc));
     float psum = 0.f;
     f16x8 pf[2][2];
-    psum = softmax_tiles_pk(sacc, c, mc, pf);
+    psum = softmax_tiles<true>(sacc, c, mc, pf);
     psum += __shfl_xor(psum, 32);
     l_run = l_run * alpha + psum;
     const float m_prev = m_run;
@@ -854,7 +850,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_res256_kernel(const AttnArgs 
       }
       psum *= 0.00390625f;                                  // back to the scale of l_run (exact: a power of two)
     } else {
-      psum = softmax_tiles_pk(sacc, c, mc, pf);
+      psum = softmax_tiles<true>(sacc, c, mc, pf);
     }
     psum = xhalf_sum(psum);
     l_run = l_run * alpha + psum;
@@ -1037,7 +1033,7 @@ __global__ __launch_bounds__(QT * 128, 4) void attn_res64_kernel(const AttnArgs 
     const float alpha = grow ? __builtin_amdgcn_exp2f(fmaf(m_run, c, -mc)) : 1.0f;
     float psum = 0.f;
     f16x8 pf[2][2];
-    psum = softmax_tiles_pk(sacc, c, mc, pf);
+    psum = softmax_tiles<true>(sacc, c, mc, pf);
     psum = xhalf_sum(psum);
     l_run = l_run * alpha + psum;
     m_run = m_new;
@@ -1205,6 +1201,19 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 4 : 2) void attn_dma72_kernel(co
   const int li = lane & 15;
   const int vt_off = TILE_B + (lh + 4 * (li >> 2)) * ROW + (16 * (lr >> 4) + 4 * (li & 3)) * 2;      // key rows 4 apart: see key_perm72
   const int kq_off = key_perm72(lr) * ROW + lh * 16;
+  // Row sums from the matrix pipe (16-bit form): the third 32-row tile of O^T = V^T P^T has rows d = 72..95 to spare, and the lanes whose
+  // transposing reads would fetch V[key][72..75] (past the row: the next key's first elements, rows never stored) read a constant (1, 0, 0, 0)
+  // instead -- row d = 72 of the accumulator is then the sum over keys of the ROUNDED probabilities, rescaled with the rest of the tile when
+  // the running maximum moves.  That takes 32 v_add_f32 per tile and wave off the vector issue port, which -- not the matrix pipe -- bounds
+  // this loop (ISA counts in DESIGN.md).  The constants sit at the eight offsets (32 u + 16 s) * ROW + {0, 2 ROW} the reads of one tile use.
+  constexpr int ONES = 4 * TILE_B + 256;                     // behind the buffers and their over-read slack
+  const bool ones_lane = !AV8 && (lr >> 4) == 0 && (li & 3) == 2;
+  if constexpr (!AV8) {
+    if (tid < 8) {
+      const int off = ((tid >> 2) * 32 + ((tid >> 1) & 1) * 16 + (tid & 1) * 2) * ROW;
+      *reinterpret_cast<u32x2*>(smem + ONES + off) = (u32x2){CVMI_ONE16X2 & 0xFFFFu, 0u};
+    }
+  }
   dma_wait();
   __syncthreads();                                          // tile 0 landed
 
@@ -1212,6 +1221,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 4 : 2) void attn_dma72_kernel(co
   for (int kt = 0; kt < nkt; ++kt) {
     const char* const kq = smem + (kt & 1) * 2 * TILE_B + kq_off;
     const char* const vt = smem + (kt & 1) * 2 * TILE_B + vt_off;
+    const char* const vt2 = ones_lane ? smem + ONES - 128 : vt;      // base of the t = 2 reads (their + 128 lands on the constants)
     if (kt + 1 < nkt) issue(kt + 1, (kt + 1) & 1);          // the other buffer was last read in iteration kt - 1 (barrier below)
     constexpr int kc = 0;
     if constexpr (AV8) {
@@ -1276,10 +1286,12 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 4 : 2) void attn_dma72_kernel(co
       }
       psum *= 0.00390625f;
     } else {
-      psum = softmax_tiles_pk(sacc, c, mc, pf);
+      softmax_tiles<false>(sacc, c, mc, pf);
     }
-    psum = xhalf_sum(psum);
-    l_run = l_run * alpha + psum;
+    if constexpr (AV8) {
+      psum = xhalf_sum(psum);
+      l_run = l_run * alpha + psum;
+    }
     m_run = m_new;
     if (__any(grow)) {                                      // (a real branch: rare once the first tiles have set the reference)
       asm volatile("" ::: "memory");
@@ -1306,7 +1318,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 4 : 2) void attn_dma72_kernel(co
         for (int s = 0; s < 2; ++s)
 #pragma unroll
           for (int t = 0; t < DT; ++t) {
-            const char* a0 = vt + (kc * 64 + u * 32 + s * 16) * ROW + t * 64;
+            const char* a0 = (t == 2 ? vt2 : vt) + (kc * 64 + u * 32 + s * 16) * ROW + t * 64;
             const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0));
             const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0 + 2 * ROW));
             const u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
@@ -1317,6 +1329,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 4 : 2) void attn_dma72_kernel(co
     dma_wait();                                             // this wave's pieces of tile kt + 1 (issued a whole tile of MFMAs ago)
     __syncthreads();                                        // tile kt fully read; tile kt + 1 landed in every wave
   }
+  if constexpr (!AV8) l_run = __shfl(oacc[2][4], lr);        // row d = 72 (tile 2, row 8): register 4 of the lanes of half 0, column = query
   if (q_ok) {
     const float inv = 1.f / l_run;
     long long obase;
@@ -1344,7 +1357,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 4 : 2) void attn_dma72_kernel(co
 
 template <int NW, bool AV8 = false>
 int launch_dma72(const AttnArgs& a, hipStream_t stream) {
-  constexpr int lds = 4 * 64 * 144 + (AV8 ? 6 * 1024 : 0) + 256;          // AV8: + the tile's e4m3 V^T image
+  constexpr int lds = 4 * 64 * 144 + (AV8 ? 6 * 1024 : 7232) + 256;       // AV8: + the tile's e4m3 V^T image; 16-bit: + the row-sum constants
   const long long blocks = (long long)a.B * a.heads * ((a.qtiles + NW - 1) / NW);
   CVMI_CHECK(blocks > 0 && blocks < (1ll << 31), "attention: bad grid");
   cvmi_note_kernel(AV8 ? "attn_dma72_kernel<%d, true>" : "attn_dma72_kernel<%d, false>", NW);
