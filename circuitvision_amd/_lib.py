@@ -61,7 +61,7 @@ class AttnDesc(C.Structure):
         ("B", C.c_int), ("heads", C.c_int), ("Nq", C.c_int), ("Nk", C.c_int),
         ("dqk", C.c_int), ("dv", C.c_int), ("scale", C.c_float), ("dtype", C.c_int),
         ("win", C.c_int), ("grid_h", C.c_int), ("grid_w", C.c_int), ("q_pool", C.c_int),
-        ("q_bdiv", C.c_int), ("kv_bdiv", C.c_int), ("av_fp8", C.c_int),
+        ("q_bdiv", C.c_int), ("kv_bdiv", C.c_int), ("av_fp8", C.c_int), ("q_log2", C.c_int),
     ]
 
 

@@ -29,6 +29,7 @@ struct AttnArgs {
   int items;       // B * heads * qtiles
   int diag;        // CVMI_ATTN_DIAG, timing experiments ONLY (results are wrong): bit 0 = attn_res256 skips its key-tile loop, bit 1 = skips its K / V DMA
   float defer;     // deferred-rescale threshold in log2 units (DEFER_LOG2; CVMI_ATTN_DEFER=0 restores "rescale on every new maximum" for A/B runs)
+  int q_log2;      // cvmi_attn_desc.q_log2: q already carries scale * log2(e) (the dispatcher then passes scale = 1 / log2(e): every kernel's c = scale * log2(e) is 1 to one ulp; attn_dma72_kernel<.., QL = true> uses exactly 1)
   int xcd;         // 1: XCD-aware workgroup order (xcd_order below); 0: natural order (CVMI_ATTN_XCD=0, A/B runs only)
   FastDiv div_win; // window mode: key -> (row, column) inside the window without a hardware division
 };
@@ -1100,7 +1101,7 @@ int launch_res64(const AttnArgs& a, hipStream_t stream) {
 // AV8: as in attn_res256_kernel -- the AV product on the block-scaled fp8 MFMA.  Per 64-key tile, waves 0..5 build one 1-KiB piece each of
 // the tile's e4m3 V^T operand image (d tile t = wave / 2, operand half u = wave & 1) from the 16-bit tile in front of the QK^T products; a
 // second barrier per tile (LDS writes only: the next tile's DMA stays in flight across it) publishes the image before the three MFMAs.
-template <int NW, bool AV8 = false>
+template <int NW, bool AV8 = false, bool QL = false>
 __global__ __launch_bounds__(NW * 64, NW == 4 ? 4 : 2) void attn_dma72_kernel(const AttnArgs p) {
   constexpr int ROW = 144, TK = 64, QS = 5, DT = 3, CH = 9;
   constexpr int TILE_B = TK * ROW;                          // 9216 B per matrix per buffer
@@ -1206,14 +1207,23 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 4 : 2) void attn_dma72_kernel(co
   // instead -- row d = 72 of the accumulator is then the sum over keys of the ROUNDED probabilities, rescaled with the rest of the tile when
   // the running maximum moves.  That takes 32 v_add_f32 per tile and wave off the vector issue port, which -- not the matrix pipe -- bounds
   // this loop (ISA counts in DESIGN.md).  The constants sit at the eight offsets (32 u + 16 s) * ROW + {0, 2 ROW} the reads of one tile use.
+  // QL (q pre-multiplied by scale * log2 e where it was produced, cvmi_attn_desc.q_log2): the running maximum goes through the matrix pipe
+  // too.  head_dim 72 leaves k = 72..79 of the fifth QK^T step unused: the lanes that hold those k read K = (1, 0, .., 0) from a constant
+  // instead of the next key's first bytes, and hold Q = (-m, 0, .., 0), m = the row's reference maximum ROUNDED to the operand type -- the
+  // score tile comes out of the MFMA as s - m and exp2 applies to it as it stands: no v_fma_f32 per score either.  m moves only when a tile's
+  // maximum exceeds it by more than the deferred-rescale threshold (and on the first tile): then the tile is corrected by the exact
+  // difference of the two rounded references, which is also what the accumulators are rescaled by.
   constexpr int ONES = 4 * TILE_B + 256;                     // behind the buffers and their over-read slack
   const bool ones_lane = !AV8 && (lr >> 4) == 0 && (li & 3) == 2;
   if constexpr (!AV8) {
     if (tid < 8) {
       const int off = ((tid >> 2) * 32 + ((tid >> 1) & 1) * 16 + (tid & 1) * 2) * ROW;
       *reinterpret_cast<u32x2*>(smem + ONES + off) = (u32x2){CVMI_ONE16X2 & 0xFFFFu, 0u};
+    } else if (QL && tid < 10) {
+      *reinterpret_cast<u32x4*>(smem + ONES + 16 + (tid - 8) * 32 * ROW) = (u32x4){CVMI_ONE16X2 & 0xFFFFu, 0u, 0u, 0u};      // K constants: (32 u) * ROW apart
     }
   }
+  float m_ref = 0.f;                                          // QL: the reference maximum held (negated) in the Q operand
   dma_wait();
   __syncthreads();                                          // tile 0 landed
 
@@ -1222,6 +1232,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 4 : 2) void attn_dma72_kernel(co
     const char* const kq = smem + (kt & 1) * 2 * TILE_B + kq_off;
     const char* const vt = smem + (kt & 1) * 2 * TILE_B + vt_off;
     const char* const vt2 = ones_lane ? smem + ONES - 128 : vt;      // base of the t = 2 reads (their + 128 lands on the constants)
+    const char* const kq4 = (QL && lh) ? smem + ONES + 16 - 128 : kq;   // QL: base of the s = 4 reads of the lanes that hold k = 72..79
     if (kt + 1 < nkt) issue(kt + 1, (kt + 1) & 1);          // the other buffer was last read in iteration kt - 1 (barrier below)
     constexpr int kc = 0;
     if constexpr (AV8) {
@@ -1255,21 +1266,49 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 4 : 2) void attn_dma72_kernel(co
     for (int s = 0; s < QS; ++s)
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
-        const f16x8 kf = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(kq + (kc * 64 + u * 32) * ROW + s * 32));
+        const f16x8 kf = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>((s == 4 ? kq4 : kq) + (kc * 64 + u * 32) * ROW + s * 32));
         sacc[u] = CVMI_MFMA_32X32X16(kf, __builtin_bit_cast(f16x8, qf[s]), sacc[u], 0, 0, 0);
       }
     float mxa = max3f(sacc[0][0], sacc[1][0], sacc[0][8]), mxb = max3f(sacc[1][8], sacc[0][1], sacc[1][1]);      // two chains of v_max3_f32
 #pragma unroll
     for (int r = 2; r < 8; ++r) { mxa = max3f(mxa, sacc[0][r], sacc[1][r]); mxb = max3f(mxb, sacc[0][r + 7], sacc[1][r + 7]); }
     const float mx = max3f(mxa, mxb, max3f(sacc[0][15], sacc[1][15], mxa));
+    f16x8 pf[2][2];
+    u32x4 p8[2];
+    if constexpr (QL) {
+      static_assert(!AV8, "QL is the 16-bit form");
+      const float top = xhalf_max(mx);                          // the tile's maximum RELATIVE to m_ref (the MFMA subtracted it)
+      const bool grow = kt == 0 || top > p.defer;
+      if (__any(grow)) {                                      // (a real branch: the first tile, then rare)
+        const float m_new = grow ? (float)(f16)(m_ref + top) : m_ref;       // representable in the operand type, so the Q slot holds it exactly
+        const float dlt = m_new - m_ref;                        // exact in f32 (both are 16-bit values of similar magnitude or m_ref = 0)
+        const float alpha = __builtin_amdgcn_exp2f(-dlt);
+        m_ref = m_new;
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) sacc[u][r] -= dlt;
+#pragma unroll
+        for (int t = 0; t < DT; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) oacc[t][r] *= alpha;
+        if (lh) {                                               // the lanes that hold k = 72..79 of the fifth step
+          f16x8 qv = __builtin_bit_cast(f16x8, qf[4]);
+          qv[0] = (f16)(-m_new);
+          qf[4] = __builtin_bit_cast(u32x4, qv);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) pf[u][r >> 3][r & 7] = (f16)__builtin_amdgcn_exp2f(sacc[u][r]);
+    } else {
     const float m_top = fmaxf(m_run, xhalf_max(mx));
     const bool grow = (m_top - m_run) * c > (AV8 ? 0.f : p.defer);      // first tile: m_run = -inf -> true
     const float m_new = grow ? m_top : m_run;
     const float mc = m_new * c;
     const float alpha = grow ? __builtin_amdgcn_exp2f(fmaf(m_run, c, -mc)) : 1.0f;
     float psum = 0.f;
-    f16x8 pf[2][2];
-    u32x4 p8[2];
     if constexpr (AV8) {
       const float mc8 = mc - 8.f;                           // p * 2^8 through the exponent
 #pragma unroll
@@ -1299,6 +1338,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 4 : 2) void attn_dma72_kernel(co
       for (int t = 0; t < DT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) oacc[t][r] *= alpha;
+    }
     }
     if constexpr (AV8) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's piece of the e4m3 image is written ...
@@ -1355,13 +1395,13 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 4 : 2) void attn_dma72_kernel(co
   }
 }
 
-template <int NW, bool AV8 = false>
+template <int NW, bool AV8 = false, bool QL = false>
 int launch_dma72(const AttnArgs& a, hipStream_t stream) {
   constexpr int lds = 4 * 64 * 144 + (AV8 ? 6 * 1024 : 7232) + 256;       // AV8: + the tile's e4m3 V^T image; 16-bit: + the row-sum constants
   const long long blocks = (long long)a.B * a.heads * ((a.qtiles + NW - 1) / NW);
   CVMI_CHECK(blocks > 0 && blocks < (1ll << 31), "attention: bad grid");
-  cvmi_note_kernel(AV8 ? "attn_dma72_kernel<%d, true>" : "attn_dma72_kernel<%d, false>", NW);
-  hipLaunchKernelGGL((attn_dma72_kernel<NW, AV8>), dim3((unsigned)blocks), dim3(NW * 64), lds, stream, a);
+  cvmi_note_kernel("attn_dma72_kernel<%d, %s, %s>", NW, CVMI_BOOLNAME(AV8), CVMI_BOOLNAME(QL));
+  hipLaunchKernelGGL((attn_dma72_kernel<NW, AV8, QL>), dim3((unsigned)blocks), dim3(NW * 64), lds, stream, a);
   CVMI_LAUNCH_CHECK();
   return 0;
 }
@@ -1636,7 +1676,7 @@ extern "C" int CVMI_ENTRY(cvmi_attention)(const cvmi_attn_desc* d, cvmi_stream_t
   a.q = (const char*)d->q; a.k = (const char*)d->k; a.v = (const char*)d->v; a.o = (char*)d->o;
   a.q_sb = d->q_sb; a.q_sh = d->q_sh; a.q_st = d->q_st; a.k_sb = d->k_sb; a.k_sh = d->k_sh; a.k_st = d->k_st;
   a.v_sb = d->v_sb; a.v_sh = d->v_sh; a.v_st = d->v_st; a.o_sb = d->o_sb; a.o_sh = d->o_sh; a.o_st = d->o_st;
-  a.B = d->B; a.heads = d->heads; a.Nq = d->Nq; a.Nk = d->Nk; a.dqk = d->dqk; a.dv = d->dv; a.scale = d->scale;
+  a.B = d->B; a.heads = d->heads; a.Nq = d->Nq; a.Nk = d->Nk; a.dqk = d->dqk; a.dv = d->dv; a.scale = d->q_log2 ? 0.6931471805599453f : d->scale; a.q_log2 = d->q_log2;
   a.win = d->win; a.grid_h = d->grid_h; a.grid_w = d->grid_w; a.q_pool = d->q_pool;
   a.q_bdiv = d->q_bdiv > 1 ? d->q_bdiv : 1; a.kv_bdiv = d->kv_bdiv > 1 ? d->kv_bdiv : 1;
   const bool shared = a.q_bdiv > 1 || a.kv_bdiv > 1;
@@ -1706,6 +1746,7 @@ extern "C" int CVMI_ENTRY(cvmi_attention)(const cvmi_attn_desc* d, cvmi_stream_t
     // they stream K / V from L2 twice as often and are kept for A/B runs.
     static const int nw = getenv("CVMI_ATTN_DMA72_NW") ? atoi(getenv("CVMI_ATTN_DMA72_NW")) : 8;
     if (d->av_fp8) return launch_dma72<8, true>(a, stream);
+    if (d->q_log2) return nw == 4 ? launch_dma72<4, false, true>(a, stream) : launch_dma72<8, false, true>(a, stream);
     return nw == 4 ? launch_dma72<4>(a, stream) : launch_dma72<8>(a, stream);
   }
   if (d->dqk <= 32 && d->dv <= 32) return launch_f16_gs<32, 32>(a, stream);

@@ -33,6 +33,7 @@ from .engine import (ESIZE, TORCH_DTYPE, is16, Buf, PackedConv, PackedHieraMlp, 
                      op_call, op_cast, op_conv, op_hiera_mlp, op_layernorm, op_maxpool2, op_tok_linear, op_tok_linear_pool, require_gpu, row_stats_supported,
                      tok_linear_supported)
 
+LOG2E = 1.4426950408889634
 HIERA_L = dict(embed_dim=144, num_heads=2, stages=(2, 6, 36, 4), global_att_blocks=(23, 33, 43), window_spec=(8, 4, 16, 8))
 HIERA_T = dict(embed_dim=96, num_heads=1, stages=(1, 2, 7, 2), global_att_blocks=(5, 7, 9), window_spec=(8, 4, 14, 7))
 
@@ -187,6 +188,8 @@ class Sam2Weights:
         self.pc, self.ln, self.const, self.mlp, self.tl = {}, {}, {}, {}, {}
         self.fused_mlp = os.environ.get("CVMI_SAM_FUSED_MLP", "1") != "0"      # (the switches are for A/B measurements)
         self.use_tok = os.environ.get("CVMI_SAM_TOKLIN", "1") != "0"
+        # Hiera q rows carry scale * log2(e) (16-bit plans): see _linear(row_scale=) and cvmi_attn_desc.q_log2
+        self.q_log2 = is16(dtype) and os.environ.get("CVMI_SAM_QLOG2", "1") != "0"
         self.param_bytes = 0
         self.flops_per_image = 0
         self._trunk()
@@ -201,8 +204,15 @@ class Sam2Weights:
         self.param_bytes += pc.param_bytes
         return pc
 
-    def _linear(self, key, mod, cout, cin, tok=False):
+    def _linear(self, key, mod, cout, cin, tok=False, row_scale=None):
         w, b = self.p.weight(mod, (cout, cin)), self.p.bias(mod, cout)
+        if row_scale is not None:
+            # (rows, factor): the attention scale * log2(e) folded into the q rows of a qkv projection, in fp32 before the weights are rounded
+            # to the operand type -- the attention kernels then take exp2 of q k^T as it stands (cvmi_attn_desc.q_log2)
+            n, f = row_scale
+            w, b = w.clone(), b.clone()
+            w[:n] *= f
+            b[:n] *= f
         if tok and self.use_tok and is16(self.dtype) and tok_linear_supported(cin, self.dtype, 256):
             # short-K Hiera linears also in the token-stationary kernel's fragment order (tok_linear.hip); the plan picks it
             # whenever its row count is a multiple of 256
@@ -244,7 +254,8 @@ class Sam2Weights:
                 dim_out, heads, cur = dim * 2, heads * 2, cur + 1
             b = f"{T}.blocks.{i}"
             self._norm(f"b{i}.norm1", f"{b}.norm1", dim)
-            self._linear(f"b{i}.qkv", f"{b}.attn.qkv", 3 * dim_out, dim, tok=True)
+            self._linear(f"b{i}.qkv", f"{b}.attn.qkv", 3 * dim_out, dim, tok=True,
+                         row_scale=(dim_out, (dim_out // heads) ** -0.5 * LOG2E) if self.q_log2 else None)
             self._linear(f"b{i}.proj", f"{b}.attn.proj", dim_out, dim_out, tok=True)
             self._norm(f"b{i}.norm2", f"{b}.norm2", dim_out)
             if self.fused_mlp and hiera_mlp_supported(dim_out, self.dtype):
@@ -530,14 +541,15 @@ class Sam2Plan:
             desc = make_attn_desc(q=base, k=base + dout * es, v=base + 2 * dout * es, o=ao.t.data_ptr(),
                                   q_sb=0, q_sh=hd, q_st=C3, k_sb=0, k_sh=hd, k_st=C3, v_sb=0, v_sh=hd, v_st=C3,
                                   o_sb=0, o_sh=hd, o_st=dout, B=nwin, heads=heads, Nq=nq, Nk=ws * ws, dqk=hd, dv=hd,
-                                  scale=hd ** -0.5, dtype=self.dt, win=ws, grid_h=Hp, grid_w=Wp, q_pool=1 if blk["q_pool"] else 0, av_fp8=self.av_fp8)
+                                  scale=hd ** -0.5, dtype=self.dt, win=ws, grid_h=Hp, grid_w=Wp, q_pool=1 if blk["q_pool"] else 0, av_fp8=self.av_fp8,
+                                  q_log2=1 if wt.q_log2 else 0)
             fl = 4 * nwin * heads * nq * ws * ws * hd
         else:
             N = H * W
             desc = make_attn_desc(q=base, k=base + dout * es, v=base + 2 * dout * es, o=ao.t.data_ptr(),
                                   q_sb=N * C3, q_sh=hd, q_st=C3, k_sb=N * C3, k_sh=hd, k_st=C3, v_sb=N * C3, v_sh=hd, v_st=C3,
                                   o_sb=N * dout, o_sh=hd, o_st=dout, B=B, heads=heads, Nq=N, Nk=N, dqk=hd, dv=hd,
-                                  scale=hd ** -0.5, dtype=self.dt, win=0, grid_h=0, grid_w=0, q_pool=0, av_fp8=self.av_fp8)
+                                  scale=hd ** -0.5, dtype=self.dt, win=0, grid_h=0, grid_w=0, q_pool=0, av_fp8=self.av_fp8, q_log2=1 if wt.q_log2 else 0)
             fl = 4 * B * heads * N * N * hd
         op_attention(self.plan, f"b{i}.attn", desc, (qkv, ao), bytes_=qkv.nbytes + ao.nbytes, flops=fl)
         self.plan.ops[-1] = (self.plan.ops[-1][0], "attn_global" if ws == 0 else "attn_window") + self.plan.ops[-1][2:]

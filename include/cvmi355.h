@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define CVMI_VERSION 120
+#define CVMI_VERSION 121
 
 typedef void* cvmi_stream_t; /* hipStream_t */
 
@@ -180,6 +180,9 @@ typedef struct cvmi_attn_desc {
                                 block-scaled fp8 MFMA (v_mfma_scale_f32_32x32x64_f8f6f4): P as e4m3 of p * 2^8 (block scale 2^-8), V as e4m3,
                                 fp32 accumulation, fp32 softmax statistics.  Honoured by the 256-key window kernel and the long-sequence
                                 kernel (Hiera stage-3 windows / global blocks); shapes served by other kernels ignore it.  0 = off (default) */
+  int q_log2;                /* 1: q was produced already multiplied by scale * log2(e) (e.g. folded into the rows of the projection that makes it):
+                                softmax(q k^T) is then exp2 of the products as they stand and `scale` is ignored.  Same result as 0 with the
+                                unscaled q; the long-sequence head_dim-72 kernel uses it to carry the running maximum through the matrix pipe. */
 } cvmi_attn_desc;
 int cvmi_attention(const cvmi_attn_desc* d, cvmi_stream_t stream);
 

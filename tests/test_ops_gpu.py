@@ -434,7 +434,7 @@ def test_attention_window_fp8_av_product(dtype):
 @pytest.mark.parametrize("dtype", [F16, BF16])
 @pytest.mark.parametrize("N", [1024, 1536])
 def test_attention_global_fp8_av_product(dtype, N):
-    """The same on the long-sequence kernel (attn_dma72_kernel<8, true>: Hiera's global blocks; whole 64-key tiles -- the dispatcher sends
+    """The same on the long-sequence kernel (attn_dma72_kernel<8, true, false>: Hiera's global blocks; whole 64-key tiles -- the dispatcher sends
     ragged lengths and windows to the general kernel since r03)."""
     from circuitvision_amd.engine import TORCH_DTYPE
     td = TORCH_DTYPE[dtype]
@@ -458,9 +458,55 @@ def test_attention_global_fp8_av_product(dtype, N):
         op_attention(plan, "t", desc, (qd, kd, vd, od))
         lib.cvmi_last_kernel()
         run(plan)
-        assert lib.cvmi_last_kernel().decode() in (("attn_dma72_kernel<8, true>",) if fp8 else ("attn_dma72_kernel<4, false>", "attn_dma72_kernel<8, false>"))
+        assert lib.cvmi_last_kernel().decode() in (("attn_dma72_kernel<8, true, false>",) if fp8 else ("attn_dma72_kernel<4, false, false>", "attn_dma72_kernel<8, false, false>"))
         outs[fp8] = od.float().cpu().view(B, N, Hh, hd).permute(0, 2, 1, 3)
     _check_fp8_av(f"global N = {N}", outs[1], outs[0], ref, emu, dtype, _attn_ref(q, k, v.abs(), scale))
+
+
+@pytest.mark.parametrize("dtype", [F16, BF16])
+@pytest.mark.parametrize("case", ["plain", "far_maxima", "late_maximum"])
+def test_attention_q_log2_prescaled_query(dtype, case):
+    """cvmi_attn_desc.q_log2: q handed over already multiplied by scale * log2(e) gives the attention of the unscaled q.  On the long-sequence
+    kernel (attn_dma72_kernel<8, false, true>) the running maximum then travels through the matrix pipe as a ROUNDED reference in a spare k slot
+    of Q: "far_maxima" puts the row maxima at 90-110 in log2 units (a reference that is many ulps of the 16-bit type wide), "late_maximum"
+    lets the maximum jump by >> the deferred-rescale threshold in the LAST key tile (the correction path after many plain tiles).  Reference:
+    fp32 softmax of the same 16-bit operands; also the 256-key window kernel and a general-kernel shape, which only see scale = 1 / log2(e)."""
+    from circuitvision_amd.engine import TORCH_DTYPE
+    td = TORCH_DTYPE[dtype]
+    hd = 72
+    c = hd ** -0.5 * 1.4426950408889634
+    lib = _lib.load()
+    for (B, Hh, N, expect) in ((2, 3, 1024, "attn_dma72_kernel<8, false, true>"), (3, 2, 256, "attn_res256_kernel<8, false>"), (1, 2, 600, None)):
+        g = torch.Generator().manual_seed(23 + N)
+        q = torch.randn(B, Hh, N, hd, generator=g)
+        k = torch.randn(B, Hh, N, hd, generator=g)
+        v = quant(torch.randn(B, Hh, N, hd, generator=g), dtype)
+        if case == "far_maxima":
+            q = q * 6.0; k = k * 4.0
+        if case == "late_maximum":
+            k[:, :, -7] = q[:, :, 5] * 3.0                       # every query's score against key N - 7 is far above the rest for rows like row 5
+        k = quant(k, dtype)
+        qs = quant(q * c, dtype)                                 # what a projection with c folded into its rows writes
+        ref = torch.softmax((qs @ k.transpose(-1, -2)) * 0.6931471805599453, -1) @ v
+        qd, kd, vd = (t.permute(0, 2, 1, 3).reshape(B, N, Hh * hd).to(td).cuda().contiguous() for t in (qs, k, v))
+        od = torch.zeros(B, N, Hh * hd, dtype=td, device="cuda")
+        desc = make_attn_desc(q=qd.data_ptr(), k=kd.data_ptr(), v=vd.data_ptr(), o=od.data_ptr(),
+                              q_sb=N * Hh * hd, q_sh=hd, q_st=Hh * hd, k_sb=N * Hh * hd, k_sh=hd, k_st=Hh * hd,
+                              v_sb=N * Hh * hd, v_sh=hd, v_st=Hh * hd, o_sb=N * Hh * hd, o_sh=hd, o_st=Hh * hd,
+                              B=B, heads=Hh, Nq=N, Nk=N, dqk=hd, dv=hd, scale=123.0, dtype=dtype, win=0, grid_h=0, grid_w=0, q_pool=0, av_fp8=0, q_log2=1)
+        plan = Plan(stream())
+        op_attention(plan, "t", desc, (qd, kd, vd, od))
+        lib.cvmi_last_kernel()
+        run(plan)
+        kn = lib.cvmi_last_kernel().decode()
+        assert expect is None or kn == expect, kn
+        got = od.float().cpu().view(B, N, Hh, hd).permute(0, 2, 1, 3)
+        assert torch.isfinite(got).all()
+        tol = 4e-3 if dtype == F16 else 2.5e-2                    # P and O rounded to the 16-bit type, fp32 accumulation
+        torch.testing.assert_close(got, ref, rtol=tol, atol=tol, msg=lambda m: f"{case} N={N} {kn}: {m}")
+        first = od.clone()
+        run(plan)
+        assert torch.equal(od, first)
 
 
 def test_graph_capture_replays_identically():
