@@ -32,6 +32,10 @@ struct AttnArgs {
   int q_log2;      // cvmi_attn_desc.q_log2: q already carries scale * log2(e) (the dispatcher then passes scale = 1 / log2(e): every kernel's c = scale * log2(e) is 1 to one ulp; attn_dma72_kernel<.., QL = true> uses exactly 1)
   int xcd;         // 1: XCD-aware workgroup order (xcd_order below); 0: natural order (CVMI_ATTN_XCD=0, A/B runs only)
   FastDiv div_win; // window mode: key -> (row, column) inside the window without a hardware division
+  // window mode, attn_res256_kernel: every integer division of its prologue / epilogue as a multiply (they were ~180 of the ~1100 vector
+  // instructions a wave of that kernel issues; the vector issue port is what bounds it)
+  int wpr, wpi;    // windows per grid row, windows per image
+  FastDiv div_wpr, div_wpi, div_ow, div_heads;       // ow = output-window side (win, or win / 2 with q_pool)
 };
 
 // Row maxima of the score tiles.  fmaxf on values that come out of an MFMA compiles to v_max_f32 plus a canonicalising `v_max_f32 x, x, x`
@@ -105,6 +109,15 @@ __device__ __forceinline__ long long tok_off(int b, int t, long long sb, long lo
   const int wi = b - img * (wpr * wpc);
   const int wy = wi / wpr, wx = wi - wy * wpr;
   const int ty = t / win, tx = t - ty * win;
+  const long long pix = ((long long)img * gh + (wy * win + ty)) * gw + (wx * win + tx);
+  return pix * st;
+}
+
+// tok_off() with the host's multipliers (window mode only): dwin divides by `win` (the side of the window t is counted in)
+__device__ __forceinline__ long long tok_off_fast(const AttnArgs& p, int b, int t, long long st, int win, int gh, int gw, const FastDiv& dwin) {
+  const int img = (int)p.div_wpi.div((unsigned)b), wi = b - img * p.wpi;
+  const int wy = (int)p.div_wpr.div((unsigned)wi), wx = wi - wy * p.wpr;
+  const int ty = (int)dwin.div((unsigned)t), tx = t - ty * win;
   const long long pix = ((long long)img * gh + (wy * win + ty)) * gw + (wx * win + tx);
   return pix * st;
 }
@@ -688,7 +701,7 @@ __device__ __forceinline__ int key_perm72(int i) {            // i = 4 a + b  ->
 // the unquantised p.  Operand maps measured on gfx950 (tools/probe/fp8_probe.hip, fp8_scale_probe.hip): lane (r = l & 31, h = l >> 5) holds
 // A[row r] / B[col r] bytes j = 0..31 which pair with the SAME (h, j) of the other operand; scale byte 0 of lane (r, h) scales that row's
 // bytes 16 h .. 16 h + 15 of both lane halves; C / D as every 32 x 32 MFMA.
-template <int NW, bool AV8 = false>
+template <int NW, bool AV8 = false, bool QL = false>
 __global__ __launch_bounds__(NW * 64, 2) void attn_res256_kernel(const AttnArgs p) {
   constexpr int ROW = 144, NK = 256, QS = 5, DT = 3, CH = 9;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -698,17 +711,17 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_res256_kernel(const AttnArgs 
   const int lr = lane & 31, lh = lane >> 5;
   const int qgroups = (p.qtiles + NW - 1) / NW;
   const int wgx = xcd_order((int)blockIdx.x, (int)gridDim.x, p.xcd);
-  const int item = wgx / qgroups;
+  const int item = qgroups == 1 ? wgx : wgx / qgroups;      // (16 x 16 windows, 8 waves: one group per item)
   const int qt = (wgx - item * qgroups) * NW + wv;
   const bool live = qt < p.qtiles;
-  const int b = item / p.heads, h = item - b * p.heads;
+  const int b = (int)p.div_heads.div((unsigned)item), h = item - b * p.heads;
   const int qwin = p.q_pool ? p.win / 2 : p.win;
 
   // ---- DMA the window's K and V: chunk L -> (key row L / 9, 16-byte chunk L % 9); 36 wave-instructions per matrix
   {
     long long korg, vorg;
     if (p.win > 0) {
-      const long long pix0 = tok_off(b, 0, 1, 1, p.win, p.grid_h, p.grid_w);
+      const long long pix0 = tok_off_fast(p, b, 0, 1, p.win, p.grid_h, p.grid_w, p.div_win);
       korg = pix0 * p.k_st; vorg = pix0 * p.v_st;
     } else {
       korg = (long long)b * p.k_sb; vorg = (long long)b * p.v_sb;
@@ -736,8 +749,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_res256_kernel(const AttnArgs 
   {
     const int qc = q_ok ? qi : 0;
     int t = qc;
-    if (p.q_pool) { const int py = qc / qwin, px = qc - py * qwin; t = (2 * py) * p.win + 2 * px; }
-    qoff0 = tok_off(b, t, p.q_sb, p.q_st, p.win, p.grid_h, p.grid_w) + (long long)h * p.q_sh;
+    if (p.q_pool) { const int py = (int)p.div_ow.div((unsigned)qc), px = qc - py * qwin; t = (2 * py) * p.win + 2 * px; }
+    qoff0 = (p.win > 0 ? tok_off_fast(p, b, t, p.q_st, p.win, p.grid_h, p.grid_w, p.div_win) : (long long)b * p.q_sb + (long long)t * p.q_st) + (long long)h * p.q_sh;
   }
   u32x4 qf[QS];
 #pragma unroll
@@ -775,6 +788,18 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_res256_kernel(const AttnArgs 
   const int li = lane & 15;
   const char* const vt = Vs + (lh + 4 * (li >> 2)) * ROW + (16 * (lr >> 4) + 4 * (li & 3)) * 2;      // key rows 4 apart: see key_perm72
   const char* const kq = Ks + key_perm72(lr) * ROW + lh * 16;
+  // Row sums and (QL) the running maximum on the matrix pipe: as in attn_dma72_kernel, which documents both.  The constants live behind V.
+  constexpr int ONES = 2 * NK * ROW + 256;
+  const bool ones_lane = !AV8 && (lr >> 4) == 0 && (li & 3) == 2;
+  if constexpr (!AV8) {
+    if (tid < 8) {
+      const int off = ((tid >> 2) * 32 + ((tid >> 1) & 1) * 16 + (tid & 1) * 2) * ROW;
+      *reinterpret_cast<u32x2*>(smem + ONES + off) = (u32x2){CVMI_ONE16X2 & 0xFFFFu, 0u};
+    } else if (QL && tid < 10) {
+      *reinterpret_cast<u32x4*>(smem + ONES + 16 + (tid - 8) * 32 * ROW) = (u32x4){CVMI_ONE16X2 & 0xFFFFu, 0u, 0u, 0u};
+    }
+  }
+  float m_ref = 0.f;                                          // QL: the reference maximum held (negated) in the Q operand
   dma_wait();                                               // every wave waits for its OWN LDS-DMA pieces ...
   __syncthreads();                                          // ... and the barrier publishes the window
 
@@ -820,21 +845,52 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_res256_kernel(const AttnArgs 
     for (int s = 0; s < QS; ++s)
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
-        const f16x8 kf = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(kq + (kc * 64 + u * 32) * ROW + s * 32));
+        const char* ka = (QL && s == 4 && lh) ? smem + ONES + 16 + u * 32 * ROW : kq + (kc * 64 + u * 32) * ROW + s * 32;      // QL: k = 72..79 read (1, 0, .., 0)
+        const f16x8 kf = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(ka));
         sacc[u] = CVMI_MFMA_32X32X16(kf, __builtin_bit_cast(f16x8, qf[s]), sacc[u], 0, 0, 0);
       }
     float mxa = max3f(sacc[0][0], sacc[1][0], sacc[0][8]), mxb = max3f(sacc[1][8], sacc[0][1], sacc[1][1]);      // two chains of v_max3_f32
 #pragma unroll
     for (int r = 2; r < 8; ++r) { mxa = max3f(mxa, sacc[0][r], sacc[1][r]); mxb = max3f(mxb, sacc[0][r + 7], sacc[1][r + 7]); }
     const float mx = max3f(mxa, mxb, max3f(sacc[0][15], sacc[1][15], mxa));
+    f16x8 pf[2][2];
+    u32x4 p8[2];                                            // AV8: this lane's 32 e4m3 bytes of P^T (tile u -> bytes 16 u .. 16 u + 15)
+    if constexpr (QL) {
+      static_assert(!AV8, "QL is the 16-bit form");
+      const float top = xhalf_max(mx);                          // the tile's maximum RELATIVE to m_ref (the MFMA subtracted it)
+      const bool grow = kc == 0 || top > p.defer;
+      if (__any(grow)) {                                      // (a real branch: the first tile, then rare)
+        const float m_new = grow ? (float)(f16)(m_ref + top) : m_ref;
+        const float dlt = m_new - m_ref;
+        m_ref = m_new;
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) sacc[u][r] -= dlt;
+        if (kc > 0) {                                           // (uniform; the accumulators are still zero in the first tile)
+          const float alpha = __builtin_amdgcn_exp2f(-dlt);
+#pragma unroll
+          for (int t = 0; t < DT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oacc[t][r] *= alpha;
+        }
+        if (lh) {
+          f16x8 qv = __builtin_bit_cast(f16x8, qf[4]);
+          qv[0] = (f16)(-m_new);
+          qf[4] = __builtin_bit_cast(u32x4, qv);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) pf[u][r >> 3][r & 7] = (f16)__builtin_amdgcn_exp2f(sacc[u][r]);
+    } else {
     const float m_top = fmaxf(m_run, xhalf_max(mx));
     const bool grow = (m_top - m_run) * c > (AV8 ? 0.f : p.defer);      // first tile: m_run = -inf -> true
     const float m_new = grow ? m_top : m_run;
     const float mc = m_new * c;
     const float alpha = grow ? __builtin_amdgcn_exp2f(fmaf(m_run, c, -mc)) : 1.0f;
     float psum = 0.f;
-    f16x8 pf[2][2];
-    u32x4 p8[2];                                            // AV8: this lane's 32 e4m3 bytes of P^T (tile u -> bytes 16 u .. 16 u + 15)
     if constexpr (AV8) {
       const float mc8 = mc - 8.f;                           // p * 2^8 through the exponent
 #pragma unroll
@@ -851,10 +907,12 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_res256_kernel(const AttnArgs 
       }
       psum *= 0.00390625f;                                  // back to the scale of l_run (exact: a power of two)
     } else {
-      psum = softmax_tiles<true>(sacc, c, mc, pf);
+      softmax_tiles<false>(sacc, c, mc, pf);
     }
-    psum = xhalf_sum(psum);
-    l_run = l_run * alpha + psum;
+    if constexpr (AV8) {
+      psum = xhalf_sum(psum);
+      l_run = l_run * alpha + psum;
+    }
     m_run = m_new;
     if (__any(grow)) {                                      // (a real branch: rare once the first tiles have set the reference)
       asm volatile("" ::: "memory");
@@ -862,6 +920,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_res256_kernel(const AttnArgs 
       for (int t = 0; t < DT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) oacc[t][r] *= alpha;
+    }
     }
     if constexpr (AV8) {
       const v8i32 pb = {(int)p8[0][0], (int)p8[0][1], (int)p8[0][2], (int)p8[0][3], (int)p8[1][0], (int)p8[1][1], (int)p8[1][2], (int)p8[1][3]};
@@ -879,7 +938,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_res256_kernel(const AttnArgs 
         for (int s = 0; s < 2; ++s)
 #pragma unroll
           for (int t = 0; t < DT; ++t) {
-            const char* a0 = vt + (kc * 64 + u * 32 + s * 16) * ROW + t * 64;
+            const char* a0 = (t == 2 && ones_lane) ? smem + ONES + (u * 32 + s * 16) * ROW              // (the lanes of d = 72..75: the row-sum constants)
+                                                   : vt + (kc * 64 + u * 32 + s * 16) * ROW + t * 64;
             const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0));
             const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0 + 2 * ROW));
             const u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
@@ -888,12 +948,13 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_res256_kernel(const AttnArgs 
           }
     }
   }
+  if constexpr (!AV8) l_run = __shfl(oacc[2][4], lr);        // row d = 72 (tile 2, row 8): register 4 of the lanes of half 0, column = query
   if (q_ok) {
     const float inv = 1.f / l_run;
     long long obase;
     if (p.win > 0) {
       const int ow = p.q_pool ? p.win / 2 : p.win, ogh = p.q_pool ? p.grid_h / 2 : p.grid_h, ogw = p.q_pool ? p.grid_w / 2 : p.grid_w;
-      obase = tok_off(b, qi, p.o_sb, p.o_st, ow, ogh, ogw);
+      obase = tok_off_fast(p, b, qi, p.o_st, ow, ogh, ogw, p.div_ow);
     } else {
       obase = (long long)b * p.o_sb + (long long)qi * p.o_st;
     }
@@ -1406,18 +1467,18 @@ int launch_dma72(const AttnArgs& a, hipStream_t stream) {
   return 0;
 }
 
-template <int NW, bool AV8 = false>
+template <int NW, bool AV8 = false, bool QL = false>
 int launch_res256(const AttnArgs& a, hipStream_t stream) {
-  constexpr int lds = 2 * 256 * 144 + 256;                 // + slack: the last rows' over-reads stay inside the allocation
+  constexpr int lds = 2 * 256 * 144 + 256 + (AV8 ? 0 : 7232);      // + slack: the last rows' over-reads stay inside the allocation; 16-bit: + the row-sum / maximum constants (two workgroups: 162,432 of a CU's 163,840 bytes)
   static bool attr_done = false;
   if (!attr_done) {
-    CVMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_res256_kernel<NW, AV8>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    CVMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_res256_kernel<NW, AV8, QL>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     attr_done = true;
   }
   const long long blocks = (long long)a.B * a.heads * ((a.qtiles + NW - 1) / NW);
   CVMI_CHECK(blocks > 0 && blocks < (1ll << 31), "attention: bad grid");
-  cvmi_note_kernel(AV8 ? "attn_res256_kernel<%d, true>" : "attn_res256_kernel<%d, false>", NW);
-  hipLaunchKernelGGL((attn_res256_kernel<NW, AV8>), dim3((unsigned)blocks), dim3(NW * 64), lds, stream, a);
+  cvmi_note_kernel("attn_res256_kernel<%d, %s, %s>", NW, CVMI_BOOLNAME(AV8), CVMI_BOOLNAME(QL));
+  hipLaunchKernelGGL((attn_res256_kernel<NW, AV8, QL>), dim3((unsigned)blocks), dim3(NW * 64), lds, stream, a);
   CVMI_LAUNCH_CHECK();
   return 0;
 }
@@ -1684,6 +1745,11 @@ extern "C" int CVMI_ENTRY(cvmi_attention)(const cvmi_attn_desc* d, cvmi_stream_t
              "attention: batch sharing (q_bdiv / kv_bdiv) needs fp16, no window, head dims <= 64 and B a multiple of the divisor");
   a.qtiles = (d->Nq + 31) / 32;
   a.div_win.init(d->win > 0 ? (unsigned)d->win : 1u);
+  a.wpr = d->win > 0 ? d->grid_w / d->win : 1;
+  a.wpi = d->win > 0 ? a.wpr * (d->grid_h / d->win) : 1;
+  a.div_wpr.init((unsigned)(a.wpr > 0 ? a.wpr : 1)); a.div_wpi.init((unsigned)(a.wpi > 0 ? a.wpi : 1));
+  a.div_ow.init(d->win > 0 ? (unsigned)(d->q_pool ? (d->win / 2 > 0 ? d->win / 2 : 1) : d->win) : 1u);
+  a.div_heads.init((unsigned)(d->heads > 0 ? d->heads : 1));
   a.items = d->B * d->heads * a.qtiles;
   static const int use_xcd = getenv("CVMI_ATTN_XCD") ? atoi(getenv("CVMI_ATTN_XCD")) : 1;                 // A/B runs only
   a.xcd = use_xcd;
@@ -1732,6 +1798,7 @@ extern "C" int CVMI_ENTRY(cvmi_attention)(const cvmi_attn_desc* d, cvmi_stream_t
   static const int use_res256 = getenv("CVMI_ATTN_RES256") ? atoi(getenv("CVMI_ATTN_RES256")) : 2;      // tuning experiments only: 0 off, 1 four waves, 2 eight waves (4 per SIMD at 125 VGPRs)
   if (use_res256 && d->Nk == 256 && d->dqk == 72 && d->dv == 72 && d->k_st % 8 == 0 && d->v_st % 8 == 0) {
     if (d->av_fp8 && a.qtiles >= 8) return launch_res256<8, true>(a, stream);          // block-scaled fp8 AV product (configs[4])
+    if (d->q_log2) return (use_res256 == 2 && a.qtiles >= 8) ? launch_res256<8, false, true>(a, stream) : launch_res256<4, false, true>(a, stream);
     return (use_res256 == 2 && a.qtiles >= 8) ? launch_res256<8>(a, stream) : launch_res256<4>(a, stream);
   }
   static const int use_res64 = getenv("CVMI_ATTN_RES64") ? atoi(getenv("CVMI_ATTN_RES64")) : 1;          // tuning experiments only

@@ -426,7 +426,7 @@ def test_attention_window_fp8_av_product(dtype):
         op_attention(plan, "t", desc, (qkv_d, od))
         lib.cvmi_last_kernel()
         run(plan)
-        assert lib.cvmi_last_kernel().decode() == ("attn_res256_kernel<8, true>" if fp8 else "attn_res256_kernel<8, false>")
+        assert lib.cvmi_last_kernel().decode() == ("attn_res256_kernel<8, true, false>" if fp8 else "attn_res256_kernel<8, false, false>")
         outs[fp8] = od.float().cpu()
     _check_fp8_av("16 x 16 windows", outs[1], outs[0], unwin(ref), unwin(emu), dtype, unwin(_attn_ref(q, k, v.clamp(-448, 448).abs(), scale)))
 
@@ -476,7 +476,7 @@ def test_attention_q_log2_prescaled_query(dtype, case):
     hd = 72
     c = hd ** -0.5 * 1.4426950408889634
     lib = _lib.load()
-    for (B, Hh, N, expect) in ((2, 3, 1024, "attn_dma72_kernel<8, false, true>"), (3, 2, 256, "attn_res256_kernel<8, false>"), (1, 2, 600, None)):
+    for (B, Hh, N, expect) in ((2, 3, 1024, "attn_dma72_kernel<8, false, true>"), (3, 2, 256, "attn_res256_kernel<8, false, true>"), (1, 2, 600, None)):
         g = torch.Generator().manual_seed(23 + N)
         q = torch.randn(B, Hh, N, hd, generator=g)
         k = torch.randn(B, Hh, N, hd, generator=g)

@@ -23,7 +23,8 @@ BUDGETS = {
     "attention.hip": (["-fno-honor-nans"], {
         "attn_dma72_kernelILi8ELb0ELb0EE": 128,   # long sequences: two 8-wave workgroups per CU
         "attn_dma72_kernelILi8ELb0ELb1EE": 128,   # the same with the running maximum on the matrix pipe (q_log2: Hiera global attention)
-        "attn_res256_kernelILi8ELb0EE": 128,      # 16 x 16 windows: two 8-wave workgroups per CU (2 x 72 KiB of K / V in LDS)
+        "attn_res256_kernelILi8ELb0ELb0EE": 128,  # 16 x 16 windows: two 8-wave workgroups per CU (2 x 79 KiB of LDS)
+        "attn_res256_kernelILi8ELb0ELb1EE": 128,  # the same on log2-prescaled q (Hiera stage 3)
         "attn_res64_kernelILi2EE": 128,           # 8 x 8 windows: launch bounds ask for 4 waves per SIMD
     }),
 }
