@@ -1491,9 +1491,12 @@ int launch_res256(const AttnArgs& a, hipStream_t stream) {
 // two-pass over 16 registers, and the output row accumulates in 72 fp32 registers.  No cross-lane traffic at all.
 template <int NQ, int DCH>                                  // NQ queries per item (16, or 4 when q-pooled); DCH = head_dim / 8
 __global__ __launch_bounds__(128) void attn_win16_kernel(const AttnArgs p) {
-  constexpr int NK = 16, IPW = 4, D = DCH * 8, ROW = D * 2;        // row bytes (unpadded: every read is a broadcast)
-  constexpr int ITEM_B = NK * ROW;
-  __shared__ __attribute__((aligned(16))) char lds[2 * 2 * IPW * ITEM_B];          // 2 waves x (K, V) x 4 items x 2304 B = 36 KiB
+  constexpr int NK = 16, IPW = 4, D = DCH * 8, ROW = D * 2;        // row bytes (unpadded: the 16 query lanes of an item read one address)
+  // Item pitch: a wave's read touches FOUR addresses (its four items, same key / chunk).  At the natural pitch (16 x 144 = 2304 B = 9 x 256) all
+  // four fall on the same 4 banks -- a 4-way conflict on every ds_read_b128 of the kernel (PMC r02 / r03: SQ_LDS_BANK_CONFLICT = 0.46 of the LDS
+  // cycles, and 288 such reads per thread are more LDS time than the kernel's VALU time).  + 64 B per item puts them on 16 distinct banks.
+  constexpr int ITEM_B = NK * ROW + 64;
+  __shared__ __attribute__((aligned(16))) char lds[2 * 2 * IPW * ITEM_B];          // 2 waves x (K, V) x 4 items x 2368 B = 37 KiB
   const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
   char* const Kl = lds + wv * 2 * IPW * ITEM_B;
   char* const Vl = Kl + IPW * ITEM_B;
@@ -1528,7 +1531,7 @@ __global__ __launch_bounds__(128) void attn_win16_kernel(const AttnArgs p) {
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
       const int id = lane + i * 64;
-      if (id < NCHUNK) *reinterpret_cast<u32x4*>((m == 0 ? Kl : Vl) + id * 16) = r[i];
+      if (id < NCHUNK) *reinterpret_cast<u32x4*>((m == 0 ? Kl : Vl) + id * 16 + (id / (NK * DCH)) * 64) = r[i];       // (+ the item pad)
     }
   }
   // ---- my query row (2 x 2 max-pool of the projected q tokens when q_pool)
