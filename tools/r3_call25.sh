@@ -7,5 +7,5 @@ timeout -k 10 900 python -m pytest tests/test_ops_gpu.py tests/test_sam2_gpu.py 
 tail -2 $O/pytest.log
 cd /tmp && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/prof -o s -- python3 $GRAFT_REPO_ROOT/bench.py --workload sam2l --steps 3 --warmup 1 --no-cpu-baseline > $GRAFT_REPO_ROOT/$O/prof.log 2>&1
 cd $GRAFT_REPO_ROOT; tail -1 $O/prof.log | cut -c1-200
-f=$(ls $O/prof/*/*kernel_stats.csv 2>/dev/null | head -1); grep -i "win16\|res64" $f | cut -c1-160
+[ -s $O/prof/s_kernel_stats.csv ] && grep -i "win16\|res64" $O/prof/s_kernel_stats.csv | cut -c1-160
 find $O -name "*.db" -delete
