@@ -702,7 +702,7 @@ __device__ __forceinline__ int key_perm72(int i) {            // i = 4 a + b  ->
 // A[row r] / B[col r] bytes j = 0..31 which pair with the SAME (h, j) of the other operand; scale byte 0 of lane (r, h) scales that row's
 // bytes 16 h .. 16 h + 15 of both lane halves; C / D as every 32 x 32 MFMA.
 template <int NW, bool AV8 = false, bool QL = false>
-__global__ __launch_bounds__(NW * 64, 2) void attn_res256_kernel(const AttnArgs p) {
+__global__ __launch_bounds__(NW * 64, (AV8 || NW != 8) ? 2 : 4) void attn_res256_kernel(const AttnArgs p) {
   constexpr int ROW = 144, NK = 256, QS = 5, DT = 3, CH = 9;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const Ks = smem;
@@ -792,11 +792,11 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_res256_kernel(const AttnArgs 
   constexpr int ONES = 2 * NK * ROW + 256;
   const bool ones_lane = !AV8 && (lr >> 4) == 0 && (li & 3) == 2;
   if constexpr (!AV8) {
-    if (tid < 8) {
-      const int off = ((tid >> 2) * 32 + ((tid >> 1) & 1) * 16 + (tid & 1) * 2) * ROW;
-      *reinterpret_cast<u32x2*>(smem + ONES + off) = (u32x2){CVMI_ONE16X2 & 0xFFFFu, 0u};
-    } else if (QL && tid < 10) {
-      *reinterpret_cast<u32x4*>(smem + ONES + 16 + (tid - 8) * 32 * ROW) = (u32x4){CVMI_ONE16X2 & 0xFFFFu, 0u, 0u, 0u};
+    if (tid < 16) {                                           // two copies: see ONES_V in attn_dma72_kernel
+      const int t8 = tid & 7, off = ((t8 >> 2) * 32 + ((t8 >> 1) & 1) * 16 + (t8 & 1) * 2) * ROW;
+      *reinterpret_cast<u32x2*>(smem + ONES + (tid < 8 ? 144 : 32) + off) = (u32x2){CVMI_ONE16X2 & 0xFFFFu, 0u};
+    } else if (QL && tid < 18) {
+      *reinterpret_cast<u32x4*>(smem + ONES + 16 + (tid - 16) * 32 * ROW) = (u32x4){CVMI_ONE16X2 & 0xFFFFu, 0u, 0u, 0u};
     }
   }
   float m_ref = 0.f;                                          // QL: the reference maximum held (negated) in the Q operand
@@ -938,7 +938,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_res256_kernel(const AttnArgs 
         for (int s = 0; s < 2; ++s)
 #pragma unroll
           for (int t = 0; t < DT; ++t) {
-            const char* a0 = (t == 2 && ones_lane) ? smem + ONES + (u * 32 + s * 16) * ROW              // (the lanes of d = 72..75: the row-sum constants)
+            const char* a0 = (t == 2 && ones_lane) ? smem + ONES + (lh ? 32 : 144) + (u * 32 + s * 16) * ROW     // (the lanes of d = 72..75: the row-sum constants)
                                                    : vt + (kc * 64 + u * 32 + s * 16) * ROW + t * 64;
             const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0));
             const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0 + 2 * ROW));
@@ -1277,11 +1277,15 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 4 : 2) void attn_dma72_kernel(co
   constexpr int ONES = 4 * TILE_B + 256;                     // behind the buffers and their over-read slack
   const bool ones_lane = !AV8 && (lr >> 4) == 0 && (li & 3) == 2;
   if constexpr (!AV8) {
-    if (tid < 8) {
-      const int off = ((tid >> 2) * 32 + ((tid >> 1) & 1) * 16 + (tid & 1) * 2) * ROW;
-      *reinterpret_cast<u32x2*>(smem + ONES + off) = (u32x2){CVMI_ONE16X2 & 0xFFFFu, 0u};
-    } else if (QL && tid < 10) {
-      *reinterpret_cast<u32x4*>(smem + ONES + 16 + (tid - 8) * 32 * ROW) = (u32x4){CVMI_ONE16X2 & 0xFFFFu, 0u, 0u, 0u};      // K constants: (32 u) * ROW apart
+    // TWO copies of the V constants, one per 32-lane half (= LDS lane group of a transposing read): the 28 ordinary lanes of a group and
+    // the V rows they read cover 56 of the 64 banks exactly once, and the 8 banks left over are the ones the redirected lanes WOULD have
+    // used -- banks 36 / 52 / 4 / 20 (+ 1) in the half lh = 0, banks 8 / 24 / 40 / 56 in lh = 1 (tile bases are multiples of 256 bytes).  A
+    // constant anywhere else costs every t = 2 read a conflict cycle (PMC r03: 0.15 of the LDS cycles with one copy at bank 0).
+    if (tid < 16) {
+      const int t8 = tid & 7, off = ((t8 >> 2) * 32 + ((t8 >> 1) & 1) * 16 + (t8 & 1) * 2) * ROW;
+      *reinterpret_cast<u32x2*>(smem + ONES + (tid < 8 ? 144 : 32) + off) = (u32x2){CVMI_ONE16X2 & 0xFFFFu, 0u};
+    } else if (QL && tid < 18) {
+      *reinterpret_cast<u32x4*>(smem + ONES + 16 + (tid - 16) * 32 * ROW) = (u32x4){CVMI_ONE16X2 & 0xFFFFu, 0u, 0u, 0u};      // K constants: (32 u) * ROW apart
     }
   }
   float m_ref = 0.f;                                          // QL: the reference maximum held (negated) in the Q operand
@@ -1292,7 +1296,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 4 : 2) void attn_dma72_kernel(co
   for (int kt = 0; kt < nkt; ++kt) {
     const char* const kq = smem + (kt & 1) * 2 * TILE_B + kq_off;
     const char* const vt = smem + (kt & 1) * 2 * TILE_B + vt_off;
-    const char* const vt2 = ones_lane ? smem + ONES - 128 : vt;      // base of the t = 2 reads (their + 128 lands on the constants)
+    const char* const vt2 = ones_lane ? smem + ONES + (lh ? 32 : 144) - 128 : vt;      // base of the t = 2 reads (their + 128 lands on the constants)
     const char* const kq4 = (QL && lh) ? smem + ONES + 16 - 128 : kq;   // QL: base of the s = 4 reads of the lanes that hold k = 72..79
     if (kt + 1 < nkt) issue(kt + 1, (kt + 1) & 1);          // the other buffer was last read in iteration kt - 1 (barrier below)
     constexpr int kc = 0;
@@ -1458,7 +1462,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 4 : 2) void attn_dma72_kernel(co
 
 template <int NW, bool AV8 = false, bool QL = false>
 int launch_dma72(const AttnArgs& a, hipStream_t stream) {
-  constexpr int lds = 4 * 64 * 144 + (AV8 ? 6 * 1024 : 7232) + 256;       // AV8: + the tile's e4m3 V^T image; 16-bit: + the row-sum constants
+  constexpr int lds = 4 * 64 * 144 + (AV8 ? 6 * 1024 : 7360) + 256;       // AV8: + the tile's e4m3 V^T image; 16-bit: + the row-sum constants
   const long long blocks = (long long)a.B * a.heads * ((a.qtiles + NW - 1) / NW);
   CVMI_CHECK(blocks > 0 && blocks < (1ll << 31), "attention: bad grid");
   cvmi_note_kernel("attn_dma72_kernel<%d, %s, %s>", NW, CVMI_BOOLNAME(AV8), CVMI_BOOLNAME(QL));
@@ -1469,7 +1473,7 @@ int launch_dma72(const AttnArgs& a, hipStream_t stream) {
 
 template <int NW, bool AV8 = false, bool QL = false>
 int launch_res256(const AttnArgs& a, hipStream_t stream) {
-  constexpr int lds = 2 * 256 * 144 + 256 + (AV8 ? 0 : 7232);      // + slack: the last rows' over-reads stay inside the allocation; 16-bit: + the row-sum / maximum constants (two workgroups: 162,432 of a CU's 163,840 bytes)
+  constexpr int lds = 2 * 256 * 144 + 256 + (AV8 ? 0 : 7360);      // + slack: the last rows' over-reads stay inside the allocation; 16-bit: + the row-sum / maximum constants (two workgroups: 162,688 of a CU's 163,840 bytes)
   static bool attr_done = false;
   if (!attr_done) {
     CVMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_res256_kernel<NW, AV8, QL>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
