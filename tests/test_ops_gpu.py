@@ -476,31 +476,33 @@ def test_attention_q_log2_prescaled_query(dtype, case):
     hd = 72
     c = hd ** -0.5 * 1.4426950408889634
     lib = _lib.load()
-    for (B, Hh, N, expect) in ((2, 3, 1024, "attn_dma72_kernel<8, false, true>"), (3, 2, 256, "attn_res256_kernel<8, false, true>"), (1, 2, 600, None)):
+    for (B, Hh, Nq, N, expect) in ((2, 3, 1024, 1024, "attn_dma72_kernel<8, false, true>"), (2, 2, 600, 640, "attn_dma72_kernel<8, false, true>"),
+                                   (3, 2, 256, 256, "attn_res256_kernel<8, false, true>"), (1, 2, 600, 600, None)):
         g = torch.Generator().manual_seed(23 + N)
-        q = torch.randn(B, Hh, N, hd, generator=g)
+        q = torch.randn(B, Hh, Nq, hd, generator=g)
         k = torch.randn(B, Hh, N, hd, generator=g)
         v = quant(torch.randn(B, Hh, N, hd, generator=g), dtype)
         if case == "far_maxima":
             q = q * 6.0; k = k * 4.0
         if case == "late_maximum":
-            k[:, :, -7] = q[:, :, 5] * 3.0                       # every query's score against key N - 7 is far above the rest for rows like row 5
+            k[:, :, -7] = q[:, :, 5] * 3.0                       # key N - 7 scores far above the rest for rows like row 5
         k = quant(k, dtype)
         qs = quant(q * c, dtype)                                 # what a projection with c folded into its rows writes
         ref = torch.softmax((qs @ k.transpose(-1, -2)) * 0.6931471805599453, -1) @ v
-        qd, kd, vd = (t.permute(0, 2, 1, 3).reshape(B, N, Hh * hd).to(td).cuda().contiguous() for t in (qs, k, v))
-        od = torch.zeros(B, N, Hh * hd, dtype=td, device="cuda")
+        qd = qs.permute(0, 2, 1, 3).reshape(B, Nq, Hh * hd).to(td).cuda().contiguous()
+        kd, vd = (t.permute(0, 2, 1, 3).reshape(B, N, Hh * hd).to(td).cuda().contiguous() for t in (k, v))
+        od = torch.zeros(B, Nq, Hh * hd, dtype=td, device="cuda")
         desc = make_attn_desc(q=qd.data_ptr(), k=kd.data_ptr(), v=vd.data_ptr(), o=od.data_ptr(),
-                              q_sb=N * Hh * hd, q_sh=hd, q_st=Hh * hd, k_sb=N * Hh * hd, k_sh=hd, k_st=Hh * hd,
-                              v_sb=N * Hh * hd, v_sh=hd, v_st=Hh * hd, o_sb=N * Hh * hd, o_sh=hd, o_st=Hh * hd,
-                              B=B, heads=Hh, Nq=N, Nk=N, dqk=hd, dv=hd, scale=123.0, dtype=dtype, win=0, grid_h=0, grid_w=0, q_pool=0, av_fp8=0, q_log2=1)
+                              q_sb=Nq * Hh * hd, q_sh=hd, q_st=Hh * hd, k_sb=N * Hh * hd, k_sh=hd, k_st=Hh * hd,
+                              v_sb=N * Hh * hd, v_sh=hd, v_st=Hh * hd, o_sb=Nq * Hh * hd, o_sh=hd, o_st=Hh * hd,
+                              B=B, heads=Hh, Nq=Nq, Nk=N, dqk=hd, dv=hd, scale=123.0, dtype=dtype, win=0, grid_h=0, grid_w=0, q_pool=0, av_fp8=0, q_log2=1)
         plan = Plan(stream())
         op_attention(plan, "t", desc, (qd, kd, vd, od))
         lib.cvmi_last_kernel()
         run(plan)
         kn = lib.cvmi_last_kernel().decode()
         assert expect is None or kn == expect, kn
-        got = od.float().cpu().view(B, N, Hh, hd).permute(0, 2, 1, 3)
+        got = od.float().cpu().view(B, Nq, Hh, hd).permute(0, 2, 1, 3)
         assert torch.isfinite(got).all()
         tol = 4e-3 if dtype == F16 else 2.5e-2                    # P and O rounded to the 16-bit type, fp32 accumulation
         torch.testing.assert_close(got, ref, rtol=tol, atol=tol, msg=lambda m: f"{case} N={N} {kn}: {m}")
