@@ -127,7 +127,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in cvmi355.h but not exported"
     assert set(_lib.SIGNATURES) == declared
-    assert lib.cvmi_version() >= 120
+    assert lib.cvmi_version() >= 121                      # 121: cvmi_attn_desc.q_log2
 
 
 def test_descriptor_mirrors_match_the_library_and_a_short_struct_is_rejected():
