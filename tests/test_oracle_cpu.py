@@ -213,3 +213,26 @@ def test_attention_kernels_stay_inside_their_occupancy_register_budget():
         pytest.skip("hipcc not available")
     src, (extra, budgets) = next(iter(m.BUDGETS.items()))
     assert m.check(m.kernel_table(src, extra), budgets) == []
+
+
+def test_asm_loads_of_the_persistent_fc2_kernel_are_not_touched_before_their_wait():
+    """gemm256x192r_kernel loads its residual / bias by inline asm so that hipcc's waitcnt pass does not drain the DMA for them; the price is that the
+    compiler believes the destination registers valid at once.  tools/check_asm_loads.py fails if any instruction between such a load and the next
+    `s_waitcnt vmcnt` touches its destination (a copy, a spill, an accumulate) -- hipcc did that to another kernel in r03.  The checker is
+    exercised on a synthetic stream first."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("check_asm_loads", os.path.join(ROOT, "tools", "check_asm_loads.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    good = [";;#ASMSTART", "global_load_dwordx4 v[4:7], v[2:3], off offset:64", ";;#ASMEND", "v_mov_b32_e32 v9, v8", ";;#ASMSTART",
+            "s_waitcnt vmcnt(6)", ";;#ASMEND", "v_pk_add_f32 v[100:101], v[4:5], v[100:101]"]
+    bad = good[:3] + ["v_mov_b32_e32 v89, v5"] + good[3:]
+    assert m.check(good) == (1, [])
+    seen, hits = m.check(bad)
+    assert seen == 1 and [h[2] for h in hits] == [[5]]
+    if not os.path.exists(m.HIPCC):
+        pytest.skip("hipcc not available")
+    body = m.kernel_body(m.device_asm("igemm.hip"), "gemm256x192r_kernel")
+    assert body is not None
+    seen, hits = m.check(body)
+    assert seen == 30 and hits == [], hits[:3]
