@@ -38,6 +38,7 @@ struct ConvKArgs {
   int bias_off;                          // igemm_kernel: LDS byte offset of the parked bias row
   int rev_m;                             // gemm256x192: 1 = walk the row blocks last-to-first (see launch_g256x192)
   int per_xcd;                           // gemm256x192r: tiles per XCD
+  int diag;                              // gemm256x192r, CVMI_G192_DIAG, timing experiments ONLY (results are wrong): bit 0 = no DMA behind the prologue, bit 1 = no MFMAs, bit 2 = no residual loads
   float* stats;                          // gemm256x192 (f32 out): per row and 96-column slice (mean, sum of squared deviations from it) of the values written, or null
   FastDiv div_ctot, div_kw;
 };
@@ -1626,7 +1627,7 @@ __global__ __launch_bounds__(512, 1) void gemm256x192r_kernel(const ConvKArgs p)
       for (int j = 0; j < nseg; ++j, ++g) {
         const int b = g & 1;
         const char* st = smem + b * STAGE;
-        const bool more1 = g + 1 < ng, more2 = g + 2 < ng;
+        const bool dma = !(p.diag & 1), more1 = dma && g + 1 < ng, more2 = dma && g + 2 < ng;
         if (j == nseg - 1) {                                // the same K-tile in EVERY workgroup (the rounding sequence of a row must not depend on where its image sits in the batch); the batch was retired by the counted wait of K-tile ji + 1 <= nseg - 2
 #pragma unroll
           for (int i = 0; i < 3; ++i)
@@ -1639,18 +1640,20 @@ __global__ __launch_bounds__(512, 1) void gemm256x192r_kernel(const ConvKArgs p)
         R192_READ_X(1);
         if (more1) R192_WC(2, b ^ 1, wo1);
         R192_SYNC_IN();
-        R192_MMA(0)
+        if (!(p.diag & 2)) { R192_MMA(0) }
         R192_SYNC_OUT();
         // ---- phase 2
         R192_READ_W(1);
-        if (more2) { R192_X0(b, xo2); R192_WC(0, b, wo2); }
+        // (both X halves of stage b were read in phase 1: X1 goes out here, a phase earlier than in gemm256x192_kernel -- the A rows are the
+        //  loads that come from HBM, and CVMI_G192_DIAG shows the loop waiting on its DMA, not on the matrix pipe: r03, 181 us WITHOUT the MFMAs)
+        if (more2) { R192_X0(b, xo2); R192_X1(b, xo2); R192_WC(0, b, wo2); }
         R192_SYNC_IN();
-        R192_MMA(1)
+        if (!(p.diag & 2)) { R192_MMA(1) }
         R192_SYNC_OUT();
         // ---- phase 3
         R192_READ_W(2);
-        if (more2) { R192_X1(b, xo2); R192_WC(1, b, wo2); }
-        if (j == ji) {                                      // (uniform) six more loads in flight behind the DMA: one counted wait covers both
+        if (more2) { R192_WC(1, b, wo2); }
+        if (j == ji && !(p.diag & 4)) {                     // (uniform) six more loads in flight behind the DMA: one counted wait covers both
           R192_RLOAD(0, 0); R192_RLOAD(1, 64); R192_RLOAD(2, 128); R192_RLOAD(3, 192); R192_RLOAD(4, 256); R192_RLOAD(5, 320);
           if (more2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
           else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");          // (cannot happen for ji + 2 < nseg; kept exact anyway)
@@ -1659,7 +1662,7 @@ __global__ __launch_bounds__(512, 1) void gemm256x192r_kernel(const ConvKArgs p)
           else if (more1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         R192_SYNC_IN();
-        R192_MMA(2)
+        if (!(p.diag & 2)) { R192_MMA(2) }
         R192_SYNC_OUT();
         xo1 = xo2; wo1 = wo2;
         if (++kt2 == nk) {
@@ -1750,6 +1753,8 @@ int launch_g256x192(ConvKArgs& a, hipStream_t stream) {
       }
       cvmi_note_kernel("gemm256x192r_kernel");
       a.per_xcd = (int)(blocks / 8);
+      static const int diag = getenv("CVMI_G192_DIAG") ? atoi(getenv("CVMI_G192_DIAG")) : 0;
+      a.diag = diag;
       hipLaunchKernelGGL(gemm256x192r_kernel, dim3(256), dim3(512), lds, stream, a);
       CVMI_LAUNCH_CHECK();
       return 0;
