@@ -16,6 +16,12 @@
 #include "common.hpp"
 #include <stdlib.h>
 
+// CVMI_TL16_DIAG (compile time, timing-only builds -- tools/r3_call32.sh links them into alternative libraries; results are wrong): bit 0 = no
+// weight DMA behind the first chunks, bit 1 = no MFMAs (the ring reads stay), bit 2 = no epilogue (no GELU, no stores).  0 in the shipped library.
+#ifndef CVMI_TL16_DIAG
+#define CVMI_TL16_DIAG 0
+#endif
+
 namespace {
 
 constexpr int TL_NW = 8;
@@ -283,8 +289,12 @@ __global__ __launch_bounds__(TL_NW * 64, 2) void tok_linear16_kernel(const void*
       }
       const f16x8 a = __builtin_bit_cast(f16x8, ring[f % PF]);
       const int s = f >> 1, hh = f & 1;
-      acc.v[hh][0] = CVMI_MFMA_16X16X32(a, __builtin_bit_cast(f16x8, xn[0][s]), acc.v[hh][0], 0, 0, 0);
-      acc.v[hh][1] = CVMI_MFMA_16X16X32(a, __builtin_bit_cast(f16x8, xn[1][s]), acc.v[hh][1], 0, 0, 0);
+      if constexpr (!(CVMI_TL16_DIAG & 2)) {
+        acc.v[hh][0] = CVMI_MFMA_16X16X32(a, __builtin_bit_cast(f16x8, xn[0][s]), acc.v[hh][0], 0, 0, 0);
+        acc.v[hh][1] = CVMI_MFMA_16X16X32(a, __builtin_bit_cast(f16x8, xn[1][s]), acc.v[hh][1], 0, 0, 0);
+      } else {
+        asm volatile("" :: "v"(a));                           // (keeps the ring read and its wait)
+      }
       if (f + PF < NF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(ring[f % PF]) : "v"(lbase), "i"((f + PF) * 1024));
     }
     return acc;
@@ -316,15 +326,15 @@ __global__ __launch_bounds__(TL_NW * 64, 2) void tok_linear16_kernel(const void*
       acc = mfma_seq(j);
       asm volatile("s_waitcnt vmcnt(0)" : "+v"(acc.v[0][0]), "+v"(acc.v[0][1]), "+v"(acc.v[1][0]), "+v"(acc.v[1][1]) :: "memory");
       bar();
-      if (j + SLOTS - 1 < nch) issue_chunk(j + SLOTS - 1);
-      epilogue(acc, j);
+      if (!(CVMI_TL16_DIAG & 1) && j + SLOTS - 1 < nch) issue_chunk(j + SLOTS - 1);
+      if (!(CVMI_TL16_DIAG & 4)) epilogue(acc, j);
     }
   } else {
 #pragma unroll 1
     for (int j = 0; j < nch; ++j) {
       bar();
-      if (j + SLOTS - 1 < nch) issue_chunk(j + SLOTS - 1);
-      if (j > 0) epilogue(acc, j - 1);
+      if (!(CVMI_TL16_DIAG & 1) && j + SLOTS - 1 < nch) issue_chunk(j + SLOTS - 1);
+      if (!(CVMI_TL16_DIAG & 4) && j > 0) epilogue(acc, j - 1);
       if constexpr (RES) res_load(j);
       bar();
       acc = mfma_seq(j);

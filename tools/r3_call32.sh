@@ -1,0 +1,18 @@
+#!/bin/bash
+# what bounds the token-stationary K = 576 linears: timing-only builds of tok_linear16.hip (-DCVMI_TL16_DIAG=n, tools: see the loop in this
+# script's caller), swapped in on the box's scratch copy.  Results are wrong in every build but the shipped one.
+TAG=${1:-r3td}
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+O=gpurun_out/$TAG; mkdir -p $O
+L=circuitvision_amd/libcvmi355.so
+cp $L /tmp/lib_ship.so
+for v in ship d1 d2 d4 d6 d7 ship; do
+  if [ $v = ship ]; then cp /tmp/lib_ship.so $L; else cp circuitvision_amd/libcvmi355_$v.so $L; fi
+  timeout -k 10 300 python bench.py --workload sam2l --no-cpu-baseline --steps 3 > $O/sam_$v.json 2>/dev/null || exit 1
+  python3 - <<PY
+import json
+d=json.loads(open("$O/sam_$v.json").read().strip().splitlines()[-1])
+print("$v:", d["ms_per_step"], "ms/step;", [(t["kernel"].split(":")[0][20:52], t["us_per_launch"]) for t in d["top_launches"] if "tok_linear16" in t["kernel"]])
+PY
+done
+cp /tmp/lib_ship.so $L
