@@ -33,7 +33,8 @@ template <int K> struct Tl16Cfg {
   static constexpr int CHB = (NF + 1) * 1024;                  // + the bias piece
   static constexpr int SLOTS = 3;
   static constexpr int STG = 32 * 80;                          // per-wave transposition stage: 32 rows x (64 + 16) bytes
-  static constexpr int LDS = SLOTS * CHB + TL_NW * STG;
+  static constexpr int GB = SLOTS * CHB + TL_NW * STG;        // LN = 1: gamma, beta (2 K floats) parked for the row prologue
+  static constexpr int LDS = GB + 2 * K * 4;
 };
 
 struct Tl16Extra {
@@ -133,17 +134,33 @@ __global__ __launch_bounds__(TL_NW * 64, 2) void tok_linear16_kernel(const void*
         rstd[tg] = 1.0f / sqrtf(fmaxf(q / (float)K - dm * dm, 0.f) + eps);
       }
     }
-    // the two rows of a lane share a k-step's gamma / beta; at most two steps' loads in flight (K / 4 fragment registers fill up meanwhile)
+    // The row stream (151 MB of f32 per Hiera-L launch, from HBM) as a software pipeline: PFX k-steps of this lane's two rows in flight, the
+    // next one issued as soon as one is consumed.  gamma / beta come from LDS (parked below: their loads would otherwise sit in the same
+    // in-order vmcnt queue, younger than the rows they are needed with).  The grouped form this replaces (two k-steps loaded, waited for and
+    // converted at a time) exposed the HBM latency nine times per workgroup: ~30 of fc1's 178 us with nothing else on the CU (timing-only
+    // builds, profiles/r03_ab_runs.md) -- the launch is ONE round of 256 workgroups, so no other workgroup hides it.
+    constexpr int PFX = 4;
+    f32x4 xa[PFX][2][2];
 #pragma unroll
-    for (int k = 0; k < KS; ++k) {
-      if (k % 2 == 0) __builtin_amdgcn_sched_barrier(0);
-      const float* gp = gamma + 32 * k + 8 * g;
-      const float* bp = beta + 32 * k + 8 * g;
-      const f32x4 g0 = *reinterpret_cast<const f32x4*>(gp), g1 = *reinterpret_cast<const f32x4*>(gp + 4);
-      const f32x4 b0 = *reinterpret_cast<const f32x4*>(bp), b1 = *reinterpret_cast<const f32x4*>(bp + 4);
+    for (int k = 0; k < PFX; ++k)
 #pragma unroll
       for (int tg = 0; tg < 2; ++tg) {
-        const f32x4 a = *reinterpret_cast<const f32x4*>(xr[tg] + 32 * k + 8 * g), b = *reinterpret_cast<const f32x4*>(xr[tg] + 32 * k + 8 * g + 4);
+        xa[k][tg][0] = *reinterpret_cast<const f32x4*>(xr[tg] + 32 * k + 8 * g);
+        xa[k][tg][1] = *reinterpret_cast<const f32x4*>(xr[tg] + 32 * k + 8 * g + 4);
+      }
+    {                                                          // (behind the first row loads: the barrier's fence waits for every load in flight)
+      float* const gb = reinterpret_cast<float*>(smem + Cfg::GB);
+      for (int i = tid; i < K; i += TL_NW * 64) { gb[i] = gamma[i]; gb[K + i] = beta[i]; }
+      __syncthreads();
+    }
+    const float* const gl = reinterpret_cast<const float*>(smem + Cfg::GB) + 8 * g;
+#pragma unroll
+    for (int k = 0; k < KS; ++k) {
+      const f32x4 g0 = *reinterpret_cast<const f32x4*>(gl + 32 * k), g1 = *reinterpret_cast<const f32x4*>(gl + 32 * k + 4);
+      const f32x4 b0 = *reinterpret_cast<const f32x4*>(gl + K + 32 * k), b1 = *reinterpret_cast<const f32x4*>(gl + K + 32 * k + 4);
+#pragma unroll
+      for (int tg = 0; tg < 2; ++tg) {
+        const f32x4 a = xa[k % PFX][tg][0], b = xa[k % PFX][tg][1];
         f16x8 h;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -152,6 +169,14 @@ __global__ __launch_bounds__(TL_NW * 64, 2) void tok_linear16_kernel(const void*
         }
         xn[tg][k] = __builtin_bit_cast(u32x4, h);
       }
+      if (k + PFX < KS) {
+#pragma unroll
+        for (int tg = 0; tg < 2; ++tg) {
+          xa[k % PFX][tg][0] = *reinterpret_cast<const f32x4*>(xr[tg] + 32 * (k + PFX) + 8 * g);
+          xa[k % PFX][tg][1] = *reinterpret_cast<const f32x4*>(xr[tg] + 32 * (k + PFX) + 8 * g + 4);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);                       // (keeps hipcc from hoisting every load to the top: 210 spilled registers in a first r03 build)
     }
   } else {
 #pragma unroll
@@ -227,6 +252,8 @@ __global__ __launch_bounds__(TL_NW * 64, 2) void tok_linear16_kernel(const void*
           }
           *reinterpret_cast<f16x4*>(stage + (16 * tg + c16) * 80 + (16 * hh + 4 * g) * 2) = h4;
         }
+      // (measured r03, both no better than these 64-byte row pieces: 8-byte stores straight from the accumulator layout, +12 % on fc1; two
+      //  chunks staged and stored as 128-byte pieces, +-0)
       const int sr = lane >> 2, pc = lane & 3;
       const int c0 = 32 * j + pc * 8;
 #pragma unroll

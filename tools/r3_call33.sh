@@ -1,9 +1,9 @@
 #!/bin/bash
-# tok_linear16: counted wait that leaves the epilogue's two stores in flight (shipped) vs vmcnt(0) (-DCVMI_TL16_STOREWAIT=0 build): parity, A/B
+# tok_linear16 A/B: shipped library vs circuitvision_amd/libcvmi355_old.so (built from the previous source): parity, then interleaved bench runs
 TAG=${1:-r3sw}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/$TAG; mkdir -p $O
-timeout -k 10 900 python -m pytest tests/test_ops_gpu.py tests/test_sam2_gpu.py -x -q -m gpu -k "tok_linear or hiera or statistics or permutation or wrapper" > $O/pytest.log 2>&1 || { tail -40 $O/pytest.log; exit 1; }
+timeout -k 10 900 python -m pytest tests/test_ops_gpu.py tests/test_sam2_gpu.py -x -q -m gpu -k "tok_linear or hiera or statistics or permutation or wrapper or golden" > $O/pytest.log 2>&1 || { tail -40 $O/pytest.log; exit 1; }
 tail -2 $O/pytest.log
 L=circuitvision_amd/libcvmi355.so
 cp $L /tmp/lib_new.so
