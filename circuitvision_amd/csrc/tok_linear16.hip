@@ -18,6 +18,9 @@
 
 // CVMI_TL16_DIAG (compile time, timing-only builds -- tools/r3_call32.sh links them into alternative libraries; results are wrong): bit 0 = no
 // weight DMA behind the first chunks, bit 1 = no MFMAs (the ring reads stay), bit 2 = no epilogue (no GELU, no stores).  0 in the shipped library.
+#ifndef CVMI_TL16_PRIO
+#define CVMI_TL16_PRIO 0               /* A/B builds: 1 = static s_setprio 1 for the younger half (waves 4-7); 2 = s_setprio 1 in every epilogue phase */
+#endif
 #ifndef CVMI_TL16_DIAG
 #define CVMI_TL16_DIAG 0
 #endif
@@ -345,14 +348,18 @@ __global__ __launch_bounds__(TL_NW * 64, 2) void tok_linear16_kernel(const void*
   for (int hh = 0; hh < 2; ++hh)
 #pragma unroll
     for (int tg = 0; tg < 2; ++tg) acc.v[hh][tg] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  if (CVMI_TL16_PRIO == 1 && wv >= TL_NW / 2) __builtin_amdgcn_s_setprio(1);
+  if (CVMI_TL16_PRIO == 4 && wv < TL_NW / 2) __builtin_amdgcn_s_setprio(1);
   if (wv < TL_NW / 2) {
 #pragma unroll 1
     for (int j = 0; j < nch; ++j) {
       bar();
+      if (CVMI_TL16_PRIO == 2) __builtin_amdgcn_s_setprio(0); else if (CVMI_TL16_PRIO == 3) __builtin_amdgcn_s_setprio(1);
       if constexpr (RES) res_load(j);
       acc = mfma_seq(j);
       asm volatile("s_waitcnt vmcnt(0)" : "+v"(acc.v[0][0]), "+v"(acc.v[0][1]), "+v"(acc.v[1][0]), "+v"(acc.v[1][1]) :: "memory");
       bar();
+      if (CVMI_TL16_PRIO == 2) __builtin_amdgcn_s_setprio(1); else if (CVMI_TL16_PRIO == 3) __builtin_amdgcn_s_setprio(0);
       if (!(CVMI_TL16_DIAG & 1) && j + SLOTS - 1 < nch) issue_chunk(j + SLOTS - 1);
       if (!(CVMI_TL16_DIAG & 4)) epilogue(acc, j);
     }
@@ -360,10 +367,12 @@ __global__ __launch_bounds__(TL_NW * 64, 2) void tok_linear16_kernel(const void*
 #pragma unroll 1
     for (int j = 0; j < nch; ++j) {
       bar();
+      if (CVMI_TL16_PRIO == 2) __builtin_amdgcn_s_setprio(1); else if (CVMI_TL16_PRIO == 3) __builtin_amdgcn_s_setprio(0);
       if (!(CVMI_TL16_DIAG & 1) && j + SLOTS - 1 < nch) issue_chunk(j + SLOTS - 1);
       if (!(CVMI_TL16_DIAG & 4) && j > 0) epilogue(acc, j - 1);
       if constexpr (RES) res_load(j);
       bar();
+      if (CVMI_TL16_PRIO == 2) __builtin_amdgcn_s_setprio(0); else if (CVMI_TL16_PRIO == 3) __builtin_amdgcn_s_setprio(1);
       acc = mfma_seq(j);
       asm volatile("s_waitcnt vmcnt(0)" : "+v"(acc.v[0][0]), "+v"(acc.v[0][1]), "+v"(acc.v[1][0]), "+v"(acc.v[1][1]) :: "memory");
     }
