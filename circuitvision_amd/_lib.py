@@ -105,6 +105,7 @@ SIGNATURES = {
     "cvmi_tok_linear_supported": (_i, [_i]),
     "cvmi_tok_linear_packed_bytes": (C.c_size_t, [_i, _i]),
     "cvmi_tok_linear_format": (_i, [_i]),
+    "cvmi_tok_linear_stats_parts": (_i, [C.c_longlong, _i, _i]),
     "cvmi_tok_linear": (_i, [_vp, _i, _i, _vp, _vp, _f, _vp, _vp, _i, _i, C.c_longlong, _i, _i, _i, _i, _vp]),
     "cvmi_tok_linear_stats": (_i, [_vp, _i, _i, _vp, _vp, _f, _vp, _vp, _i, _i, C.c_longlong, _i, _i, _i, _i, _vp, _i, _vp, _f, _vp]),
     "cvmi_tok_linear_pool_stats": (_i, [_vp, _i, _vp, _vp, _f, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
@@ -120,9 +121,11 @@ SIGNATURES = {
     "cvmi_bilinear_f32": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _vp, _f, _vp]),
     "cvmi_mask_extent": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "cvmi_mask_postprocess": (_i, [_vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp]),
+    "cvmi_mask_postprocess_sizes": (_i, [_vp, _i, _i, _i, _vp, _f, _vp, _vp, _vp]),
     "cvmi_upsample_refine": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _vp, C.POINTER(_i), _i, _i, _vp]),
     "cvmi_sam2_transform": (_i, [_vp, _i, _i, _vp, _i, _i, _vp]),
     "cvmi_sam2_transform_batch": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _i, _vp]),
+    "cvmi_sam2_transform_rects": (_i, [_vp, C.c_longlong, _i, _i, _vp, _i, _vp, _i, _i, _i, _vp]),
 }
 
 _lib = None

@@ -532,6 +532,80 @@ __global__ __launch_bounds__(256) void sam2_transform_kernel(const uint8_t* __re
   }
 }
 
+// The same on a WINDOW of each source image (the crop between the two stages, circuit_analyzer.py:937-1284 as called at
+// analysis_pipeline.py:177, without a cropped copy): image b of the launch is the rectangle win[b] = {x0, y0, w, h} of source image b.  The
+// table travels by value in the kernel arguments (<= 64 images per launch).
+constexpr int RECT_MAX = 64;
+struct RectTable { int4 r[RECT_MAX]; };
+
+template <typename T>
+__global__ __launch_bounds__(256) void sam2_transform_rects_kernel(const uint8_t* __restrict__ src, long long image_stride, int W, const RectTable win,
+                                                                  T* __restrict__ dst, int R, int swap_rb) {
+  const int4 rc = win.r[blockIdx.y];                      // blockIdx.y = image
+  const int H0 = rc.w, W0 = rc.z;                         // the window's height, width: the resize sees nothing outside it
+  const float sy = (float)H0 / (float)R, sx = (float)W0 / (float)R;
+  src += (size_t)blockIdx.y * image_stride + ((size_t)rc.y * W + rc.x) * 3;
+  dst += (size_t)blockIdx.y * R * R * 3;
+  const int c0 = swap_rb ? 2 : 0, c2 = swap_rb ? 0 : 2;
+  const int total = R * R;
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+    const int oy = idx / R, ox = idx - oy * R;
+    int ymin, ysize, xmin, xsize;
+    float wy[AA_MAXTAPS], wx[AA_MAXTAPS];
+    aa_axis(oy, sy, H0, ymin, ysize, wy);
+    aa_axis(ox, sx, W0, xmin, xsize, wx);
+    float acc[3] = {0.f, 0.f, 0.f};
+    for (int j = 0; j < ysize; ++j) {
+      float row[3] = {0.f, 0.f, 0.f};
+      const uint8_t* sp = src + ((size_t)(ymin + j) * W + xmin) * 3;
+      for (int i = 0; i < xsize; ++i) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) row[c] += wx[i] * ((float)sp[i * 3 + (c == 0 ? c0 : c == 2 ? c2 : 1)] / 255.0f);
+      }
+#pragma unroll
+      for (int c = 0; c < 3; ++c) acc[c] += wy[j] * row[c];
+    }
+    const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) dst[(size_t)idx * 3 + c] = (T)((acc[c] - mean[c]) / stdv[c]);
+  }
+}
+
+// cvmi_mask_postprocess for planes that go back to DIFFERENT sizes (each image's own crop window): plane n is resized to sz.r[n] = {H, W} and
+// written at mask + sz.r[n].z (a byte offset the host laid out: planes packed back to back); extents pre-initialised by the kernel's first block.
+__global__ __launch_bounds__(256) void bilinear_sizes_kernel(const float* __restrict__ x, int h, int w, const RectTable sz, uint8_t* __restrict__ mask,
+                                                            long long mask_base, float thresh, int* __restrict__ ext) {
+  const int n = blockIdx.y;
+  const int H = sz.r[n].x, W = sz.r[n].y;
+  const float sy = (float)h / (float)H, sx = (float)w / (float)W;
+  const float* pl = x + (size_t)n * h * w;
+  uint8_t* mp = mask + mask_base + (((long long)(unsigned)sz.r[n].w << 32) | (unsigned)sz.r[n].z);
+  const int total = H * W;
+  int ex0 = W, ey0 = H, ex1 = -1, ey1 = -1;
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+    const int oy = idx / W, ox = idx - oy * W;
+    int y0, y1, x0, x1; float ly, lx;
+    bil_axis(oy, sy, h, y0, y1, ly);
+    bil_axis(ox, sx, w, x0, x1, lx);
+    const bool on = bil_sample(pl, w, y0, y1, ly, x0, x1, lx) > thresh;
+    mp[idx] = on ? 255 : 0;
+    if (on) { ex0 = min(ex0, ox); ex1 = max(ex1, ox); ey0 = min(ey0, oy); ey1 = max(ey1, oy); }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    ex0 = min(ex0, __shfl_xor(ex0, off)); ey0 = min(ey0, __shfl_xor(ey0, off));
+    ex1 = max(ex1, __shfl_xor(ex1, off)); ey1 = max(ey1, __shfl_xor(ey1, off));
+  }
+  if ((threadIdx.x & 63) == 0 && ex1 >= 0) {
+    atomicMin(ext + n * 4 + 0, ex0); atomicMin(ext + n * 4 + 1, ey0);
+    atomicMax(ext + n * 4 + 2, ex1); atomicMax(ext + n * 4 + 3, ey1);
+  }
+}
+__global__ void mask_extent_init_sizes_kernel(int* ext, int N, const RectTable sz) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < N) { ext[i * 4] = sz.r[i].y; ext[i * 4 + 1] = sz.r[i].x; ext[i * 4 + 2] = -1; ext[i * 4 + 3] = -1; }
+}
+
 inline int grid_for(long long total, int block = 256, int cap = 256 * 16) {
   long long g = (total + block - 1) / block;
   if (g > cap) g = cap;
@@ -830,6 +904,69 @@ extern "C" int CVMI_ENTRY(cvmi_sam2_transform_batch)(const uint8_t* src, int B, 
   CVMI_LAUNCH_CHECK();
   return 0;
 }
+#ifndef CVMI_OPERAND_BF16
+extern "C" int cvmi_sam2_transform_rects_bf16(const uint8_t* src, long long src_image_stride, int H, int W, const int* rects, int B, void* dst, int R,
+                                              int dst_dtype, int swap_rb, cvmi_stream_t stream_);
+#endif
+extern "C" int CVMI_ENTRY(cvmi_sam2_transform_rects)(const uint8_t* src, long long src_image_stride, int H, int W, const int* rects, int B, void* dst, int R,
+                                                     int dst_dtype, int swap_rb, cvmi_stream_t stream_) {
+#ifndef CVMI_OPERAND_BF16
+  if (dst_dtype == CVMI_BF16) return cvmi_sam2_transform_rects_bf16(src, src_image_stride, H, W, rects, B, dst, R, dst_dtype, swap_rb, stream_);
+#endif
+  CVMI_CHECK(src && dst && rects && B >= 1 && H > 0 && W > 0 && R > 0 && src_image_stride >= 0, "sam2_transform_rects: bad arguments");
+  CVMI_CHECK(dst_dtype == CVMI_T16 || dst_dtype == CVMI_F32, "sam2_transform_rects: bad dtype");
+  hipStream_t s = (hipStream_t)stream_;
+  for (int b0 = 0; b0 < B; b0 += RECT_MAX) {
+    const int nb = B - b0 < RECT_MAX ? B - b0 : RECT_MAX;
+    RectTable t;
+    for (int b = 0; b < nb; ++b) {
+      const int* r = rects + 4 * (size_t)(b0 + b);
+      CVMI_CHECK(r[0] >= 0 && r[1] >= 0 && r[2] > 0 && r[3] > 0 && (long long)r[0] + r[2] <= W && (long long)r[1] + r[3] <= H,
+                 "sam2_transform_rects: window %d = (x %d, y %d, w %d, h %d) leaves the %d x %d image", b0 + b, r[0], r[1], r[2], r[3], W, H);
+      const float sy = (float)r[3] / (float)R, sx = (float)r[2] / (float)R;
+      CVMI_CHECK(2.f * (sy > 1.f ? sy : 1.f) + 2.f <= AA_MAXTAPS && 2.f * (sx > 1.f ? sx : 1.f) + 2.f <= AA_MAXTAPS,
+                 "sam2_transform_rects: down-scale factor of window %d too large", b0 + b);
+      t.r[b] = make_int4(r[0], r[1], r[2], r[3]);
+    }
+    for (int b = nb; b < RECT_MAX; ++b) t.r[b] = make_int4(0, 0, 1, 1);
+    const dim3 g(grid_for((long long)R * R), nb), blk(256);
+    const uint8_t* sp = src + (size_t)b0 * src_image_stride;
+    const size_t dofs = (size_t)b0 * R * R * 3;
+    if (dst_dtype == CVMI_T16) hipLaunchKernelGGL(sam2_transform_rects_kernel<f16>, g, blk, 0, s, sp, src_image_stride, W, t, (f16*)dst + dofs, R, swap_rb ? 1 : 0);
+    else hipLaunchKernelGGL(sam2_transform_rects_kernel<float>, g, blk, 0, s, sp, src_image_stride, W, t, (float*)dst + dofs, R, swap_rb ? 1 : 0);
+    CVMI_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
+#ifndef CVMI_OPERAND_BF16
+extern "C" int cvmi_mask_postprocess_sizes(const float* x, int N, int h, int w, const int* sizes, float thresh, uint8_t* mask_u8, int* extent,
+                                           cvmi_stream_t stream_) {
+  CVMI_CHECK(x && mask_u8 && extent && sizes && N > 0 && h > 0 && w > 0, "mask_postprocess_sizes: bad arguments");
+  hipStream_t s = (hipStream_t)stream_;
+  long long off = 0;
+  for (int n0 = 0; n0 < N; n0 += RECT_MAX) {
+    const int nb = N - n0 < RECT_MAX ? N - n0 : RECT_MAX;
+    RectTable t;
+    long long maxhw = 1, rel = 0;
+    for (int n = 0; n < nb; ++n) {
+      const int H = sizes[2 * (size_t)(n0 + n)], W = sizes[2 * (size_t)(n0 + n) + 1];
+      CVMI_CHECK(H > 0 && W > 0 && (long long)H * W < (1ll << 31), "mask_postprocess_sizes: plane %d has size %d x %d", n0 + n, H, W);
+      t.r[n] = make_int4(H, W, (int)(unsigned)(rel & 0xffffffffll), (int)(unsigned)(rel >> 32));
+      rel += (long long)H * W;
+      if ((long long)H * W > maxhw) maxhw = (long long)H * W;
+    }
+    for (int n = nb; n < RECT_MAX; ++n) t.r[n] = make_int4(1, 1, 0, 0);
+    hipLaunchKernelGGL(mask_extent_init_sizes_kernel, dim3(1), dim3(64), 0, s, extent + 4 * (size_t)n0, nb, t);
+    hipLaunchKernelGGL(bilinear_sizes_kernel, dim3(grid_for(maxhw, 256, 1024), nb), dim3(256), 0, s, x + (size_t)n0 * h * w, h, w, t, mask_u8, off, thresh,
+                       extent + 4 * (size_t)n0);
+    CVMI_LAUNCH_CHECK();
+    off += rel;
+  }
+  return 0;
+}
+#endif
+
 #ifndef CVMI_OPERAND_BF16
 extern "C" int cvmi_sam2_transform(const uint8_t* src, int H, int W, void* dst, int R, int dst_dtype, cvmi_stream_t stream_) {
   return cvmi_sam2_transform_batch(src, 1, H, W, dst, R, dst_dtype, 0, stream_);

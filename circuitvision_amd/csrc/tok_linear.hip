@@ -508,6 +508,12 @@ static int tl_format(int K) {
 
 #ifndef CVMI_OPERAND_BF16
 extern "C" int cvmi_tok_linear_format(int K) { return tl_format(K); }
+int CVMI_ENTRY(cvmi_tok_linear16_splits)(long long rows, int N);
+extern "C" int cvmi_tok_linear_stats_parts(long long rows, int K, int N) {
+  if (rows <= 0 || rows % 256 || N <= 0 || tl_format(K) != 16) return 0;
+  const int ns = CVMI_ENTRY(cvmi_tok_linear16_splits)(rows, N);
+  return ns > 1 ? ns : 0;
+}
 
 // diagnostic: read and clear the segment sums of the CVMI_TOKLIN_STAMP build.  Ping-pong schedule: [0 .. 8] = wave 0 {b1 wait, MFMAs, vmcnt wait,
 // b2 wait, epilogue, prefetch issue, total, chunks, launches}, [12 .. 20] = wave 4 {b1 wait, epilogue, b2 wait, MFMAs, vmcnt wait, prefetch issue,
@@ -561,6 +567,7 @@ extern "C" int CVMI_ENTRY(cvmi_tok_linear_stats)(const void* in, int in_ld, int 
   hipStream_t s = (hipStream_t)stream_;
   const int ln = in_f32_layernorm;
   const bool res = out_f32_residual != 0;
+  CVMI_CHECK(ln != 2 || tl_format(K) != 16, "tok_linear: plain f32 input (in_f32_layernorm = 2) is built for K = 144 and 288");
   if (tl_format(K) == 16)
     return CVMI_ENTRY(cvmi_tok_linear16_launch)(K, ln, res, act == CVMI_ACT_GELU, in, in_ld, gamma, beta, eps, w_packed, out, out_ld, rows, N, 0, 0, ln_stats_in,
                                                 ln_stats_in_parts, ln_stats_out, ln_stats_eps, s);

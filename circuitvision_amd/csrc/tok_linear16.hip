@@ -72,7 +72,12 @@ __global__ __launch_bounds__(TL_NW * 64, 2) void tok_linear16_kernel(const void*
       row[tg] = b * 4 * ex.pool_hw2 + (long long)(2 * py + ((c16 >> 1) & 1)) * ex.pool_w + 2 * px + (c16 & 1);
     }
   }
-  const int nch = (N + 31) / 32;
+  // Output-channel chunks of this workgroup: gridDim.y workgroups share a 256-row block when the launch has fewer row blocks than the chip
+  // has CUs (the per-rank batch of an 8-GPU job: 8 images = 128 row blocks), each walks its own range [j0, j1) of the 32-channel chunks.  The
+  // siblings (x, y) have linear ids x + gridDim.x * y: the host only splits when gridDim.x is a multiple of 8, so they share an XCD's L2 for
+  // the rows they both read.
+  const int nch_all = (N + 31) / 32, cps = (nch_all + (int)gridDim.y - 1) / (int)gridDim.y;
+  const int j0 = (int)blockIdx.y * cps, nch = j0 + cps < nch_all ? j0 + cps : nch_all;
 
   auto issue_chunk = [&](int j) {
     const char* src = wp + (size_t)j * CHB + lane * 16;
@@ -86,7 +91,7 @@ __global__ __launch_bounds__(TL_NW * 64, 2) void tok_linear16_kernel(const void*
     }
   };
 #pragma unroll
-  for (int j = 0; j < SLOTS - 1; ++j)
+  for (int j = j0; j < j0 + SLOTS - 1; ++j)
     if (j < nch) issue_chunk(j);
 
   // ---- B fragments
@@ -230,7 +235,7 @@ __global__ __launch_bounds__(TL_NW * 64, 2) void tok_linear16_kernel(const void*
           f32x4 v = r4[hh][tg];
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] += acc.v[hh][tg][e];
-          if (stats && j == 0 && hh == 0) st_shift[tg] = __shfl(v[0], c16);      // the row's first updated value (lane g = 0): the variance shift
+          if (stats && j == j0 && hh == 0) st_shift[tg] = __shfl(v[0], c16);      // the row's first updated value (lane g = 0): the variance shift
           const int ch = 32 * j + 16 * hh + 4 * g;
           if (ch < N) {
             *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(out) + row[tg] * (long long)out_ld + ch) = v;
@@ -274,9 +279,15 @@ __global__ __launch_bounds__(TL_NW * 64, 2) void tok_linear16_kernel(const void*
           float ss = st_s[tg], qq = st_q[tg];
           ss += __shfl_xor(ss, 16); qq += __shfl_xor(qq, 16);
           ss += __shfl_xor(ss, 32); qq += __shfl_xor(qq, 32);
-          const float dm = ss / (float)N;
-          const float var = fmaxf(qq / (float)N - dm * dm, 0.f);
-          if (g == 0) *reinterpret_cast<float2*>(ex.stats_out + 2 * row[tg]) = make_float2(st_shift[tg] + dm, 1.0f / sqrtf(var + ex.stats_eps));
+          if (gridDim.y == 1) {
+            const float dm = ss / (float)N;
+            const float var = fmaxf(qq / (float)N - dm * dm, 0.f);
+            if (g == 0) *reinterpret_cast<float2*>(ex.stats_out + 2 * row[tg]) = make_float2(st_shift[tg] + dm, 1.0f / sqrtf(var + ex.stats_eps));
+          } else {                                              // split rows: this workgroup's slice as (mean, sum of squared deviations) -- the
+            const float n = (float)(32 * (nch - j0));           // `ln_stats_in_parts` format (host: whole chunks, equal slices), Chan et al. in the consumer
+            const float dm = ss / n;
+            if (g == 0) *reinterpret_cast<float2*>(ex.stats_out + 2 * (row[tg] * (long long)gridDim.y + blockIdx.y)) = make_float2(st_shift[tg] + dm, fmaxf(qq - ss * dm, 0.f));
+          }
         }
       }
     }
@@ -352,7 +363,7 @@ __global__ __launch_bounds__(TL_NW * 64, 2) void tok_linear16_kernel(const void*
   if (CVMI_TL16_PRIO == 4 && wv < TL_NW / 2) __builtin_amdgcn_s_setprio(1);
   if (wv < TL_NW / 2) {
 #pragma unroll 1
-    for (int j = 0; j < nch; ++j) {
+    for (int j = j0; j < nch; ++j) {
       bar();
       if (CVMI_TL16_PRIO == 2) __builtin_amdgcn_s_setprio(0); else if (CVMI_TL16_PRIO == 3) __builtin_amdgcn_s_setprio(1);
       if constexpr (RES) res_load(j);
@@ -365,11 +376,11 @@ __global__ __launch_bounds__(TL_NW * 64, 2) void tok_linear16_kernel(const void*
     }
   } else {
 #pragma unroll 1
-    for (int j = 0; j < nch; ++j) {
+    for (int j = j0; j < nch; ++j) {
       bar();
       if (CVMI_TL16_PRIO == 2) __builtin_amdgcn_s_setprio(1); else if (CVMI_TL16_PRIO == 3) __builtin_amdgcn_s_setprio(0);
       if (!(CVMI_TL16_DIAG & 1) && j + SLOTS - 1 < nch) issue_chunk(j + SLOTS - 1);
-      if (!(CVMI_TL16_DIAG & 4) && j > 0) epilogue(acc, j - 1);
+      if (!(CVMI_TL16_DIAG & 4) && j > j0) epilogue(acc, j - 1);
       if constexpr (RES) res_load(j);
       bar();
       if (CVMI_TL16_PRIO == 2) __builtin_amdgcn_s_setprio(0); else if (CVMI_TL16_PRIO == 3) __builtin_amdgcn_s_setprio(1);
@@ -381,6 +392,20 @@ __global__ __launch_bounds__(TL_NW * 64, 2) void tok_linear16_kernel(const void*
   stats_tail();
 }
 
+// Row-block sharing (see the kernel): how many workgroups split the chunks of one 256-row block.  1 unless the launch would leave CUs idle
+// (fewer than 256 row blocks, a multiple of 8 of them); then the divisor of the chunk count that fills most of one round of 256 CUs.
+// With LayerNorm statistics out (RES form) the slices must be whole, equal chunk ranges (N % 32 == 0).
+int tl16_splits(long long rows, int N, bool stats_out) {
+  static const int on = getenv("CVMI_TL16_SPLIT") ? atoi(getenv("CVMI_TL16_SPLIT")) : 1;      // A/B runs only
+  const long long wg = rows / 256;
+  const int nch = (N + 31) / 32;
+  if (!on || wg >= 256 || wg % 8 != 0 || (stats_out && N % 32 != 0)) return 1;
+  int best = 1;
+  for (int ns = 2; ns <= 8 && ns <= nch; ++ns)
+    if (nch % ns == 0 && wg * ns <= 256) best = ns;            // one round of at most 256 workgroups, as full as the divisors of nch allow
+  return best;
+}
+
 template <int K, int LN, bool RES, bool GELU, bool POOL>
 int launch16(const void* in, int in_ld, const float* gamma, const float* beta, float eps, const void* wp, void* out, int out_ld, long long rows, int N,
              hipStream_t s, const Tl16Extra& ex) {
@@ -388,13 +413,17 @@ int launch16(const void* in, int in_ld, const float* gamma, const float* beta, f
   static hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&tok_linear16_kernel<K, LN, RES, GELU, POOL>), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
   CVMI_HIP(attr);
   cvmi_note_kernel("tok_linear16_kernel<%d, %d, %s, %s, %s>", K, LN, CVMI_BOOLNAME(RES), CVMI_BOOLNAME(GELU), CVMI_BOOLNAME(POOL));
-  hipLaunchKernelGGL((tok_linear16_kernel<K, LN, RES, GELU, POOL>), dim3((unsigned)(rows / 256)), dim3(TL_NW * 64), Cfg::LDS, s, in, in_ld, gamma, beta, eps,
+  const int ns = tl16_splits(rows, N, RES && ex.stats_out != nullptr);
+  hipLaunchKernelGGL((tok_linear16_kernel<K, LN, RES, GELU, POOL>), dim3((unsigned)(rows / 256), (unsigned)ns), dim3(TL_NW * 64), Cfg::LDS, s, in, in_ld, gamma, beta, eps,
                      (const char*)wp, out, out_ld, rows, N, ex);
   CVMI_LAUNCH_CHECK();
   return 0;
 }
 
 }  // namespace
+
+// cvmi_tok_linear_stats_splits (tok_linear.hip): the slice count of the statistics a residual-form launch of this shape writes
+int CVMI_ENTRY(cvmi_tok_linear16_splits)(long long rows, int N) { return tl16_splits(rows, N, true); }
 
 // Called by the cvmi_tok_linear* entry points (tok_linear.hip) for the K served in the 16x16x32 format (cvmi_tok_linear_format).  Arguments are
 // already validated there.  pool_w > 0 selects the POOL form.

@@ -200,12 +200,64 @@ class YOLO:
                 done.record(self.stream)
         return PendingDetections(done, det_h, idx_h, cnt_h, (H, W), (h0, w0), self.names, src)
 
+    def predict_chunks_async(self, images, chunk, conf=0.25, iou=0.7, max_det=300, imgsz=None):
+        """A batch pipeline's form of `predict_async`: ONE pinned staging pass and ONE H2D copy for all equally sized `images`, then one
+        letterbox launch + graph replay + D2H of the detections per `chunk` images -- so the host can take chunk 0's boxes (and start what
+        depends on them: the crop window, the segmenter) while the GPU still runs the later chunks.  Returns one handle per chunk; handle.src
+        is that chunk's u8 [b, h, w, 3] DEVICE image block (valid once `.result()` has returned: the segmenter's transform reads its crop
+        windows straight out of it, no second H2D)."""
+        imgsz = self.imgsz if imgsz is None else self._check_imgsz(imgsz)
+        if not images:
+            raise ValueError("predict needs at least one image")
+        for im in images:
+            if not (isinstance(im, np.ndarray) and im.ndim == 3 and im.shape[2] == 3 and im.dtype == np.uint8):
+                raise TypeError("predict expects uint8 HxWx3 numpy images")
+        h0, w0 = images[0].shape[:2]
+        if any(im.shape[:2] != (h0, w0) for im in images):
+            raise ValueError("a batch must share one image size")
+        nw, nh, top, bottom, left, right = letterbox_geometry(h0, w0, imgsz)
+        H, W = nh + top + bottom, nw + left + right
+        lib = _lib.load()
+        n, chunk = len(images), max(1, int(chunk))
+        out = []
+        with self._lock, torch.cuda.device(self.device):
+            st = self._staging.get((n, h0, w0))
+            if st is None:
+                st = self._staging[(n, h0, w0)] = [torch.empty(n, h0, w0, 3, dtype=torch.uint8, pin_memory=True), None]
+            if st[1] is not None:
+                st[1].synchronize()
+            host = st[0].numpy()
+            for b, im in enumerate(images):
+                host[b] = im
+            sp = self.stream.cuda_stream
+            with torch.cuda.stream(self.stream):
+                src = st[0].to(self.device, non_blocking=True)
+                st[1] = torch.cuda.Event()
+                st[1].record(self.stream)
+                for c0 in range(0, n, chunk):
+                    B = min(chunk, n - c0)
+                    p = self.plan(B, H, W, conf, iou, max_det)
+                    det_h = torch.empty(B, p.max_det, 6, dtype=torch.float32, pin_memory=True)
+                    idx_h = torch.empty(B, p.max_det, dtype=torch.int32, pin_memory=True)
+                    cnt_h = torch.empty(B, dtype=torch.int32, pin_memory=True)
+                    _lib.check(lib.cvmi_letterbox_batch(src[c0].data_ptr(), B, h0, w0, p.x_in.t.data_ptr(), p.x_in.t[0].numel(), H, W, nh, nw, top, left,
+                                                        self.dtype, 1, sp), "letterbox")
+                    p.plan.run()
+                    det_h.copy_(p.det, non_blocking=True)
+                    idx_h.copy_(p.det_idx, non_blocking=True)
+                    cnt_h.copy_(p.det_count, non_blocking=True)
+                    done = torch.cuda.Event()
+                    done.record(self.stream)
+                    out.append(PendingDetections(done, det_h, idx_h, cnt_h, (H, W), (h0, w0), self.names, src, src=src[c0:c0 + B]))
+        return out
+
 
 class PendingDetections:
     """Detections in flight (YOLO.predict_async).  `.result()` -> [Results], one per image."""
 
-    def __init__(self, done, det, idx, cnt, lb_shape, orig_shape, names, keep):
+    def __init__(self, done, det, idx, cnt, lb_shape, orig_shape, names, keep, src=None):
         self.done, self.det, self.idx, self.cnt, self.lb_shape, self.orig_shape, self.names, self._keep = done, det, idx, cnt, lb_shape, orig_shape, names, keep
+        self.src = src                       # (predict_chunks_async) the chunk's u8 device images, for whoever crops from them
         self._out = None
 
     def result(self):

@@ -601,11 +601,18 @@ class PackedTokLinear:
         self.param_bytes = N * K * 2
 
 
+def tok_linear_stats_parts(rows, K, N):
+    """Slices P of the LayerNorm statistics a residual-form op_tok_linear of this shape writes: 0 = [rows, 2] of (mean, rstd); P > 0 = [rows, P, 2]
+    of per-slice (mean, sum of squared deviations), to be consumed with stats_parts = P (small launches share row blocks: cvmi355.h)."""
+    return int(_lib.load().cvmi_tok_linear_stats_parts(rows, K, N))
+
+
 def op_tok_linear(plan, label, pt, src, dst, ln=None, act=_lib.ACT_NONE, residual=False, kind="gemm", stats_in=None, stats_out=None, stats_eps=1e-6,
                   stats_parts=0):
     """src: f32 View with ln = (gamma, beta, eps) or ln = "cast" (f32 rows converted as they are, K <= 288), or an fp16 View.
     dst: fp16 View, or (residual=True) the f32 View updated in place.
-    stats_out (residual=True): f32 tensor [rows, 2] that receives each updated row's (mean, rstd) for the NEXT LayerNorm (eps = stats_eps);
+    stats_out (residual=True): f32 tensor [rows, 2] that receives each updated row's (mean, rstd) for the NEXT LayerNorm (eps = stats_eps) --
+    or [rows, P, 2] per-slice pairs when tok_linear_stats_parts(rows, K, N) = P > 0;
     stats_in (ln = (gamma, beta, eps)): such a tensor written by the launch that produced src -- the prologue then reads src once.
     stats_parts = P > 0: stats_in is instead f32 [rows, P, 2] of per-slice (mean, sum of squared deviations) (op_conv(row_stats=...))."""
     lib = _lib.load()
@@ -617,7 +624,8 @@ def op_tok_linear(plan, label, pt, src, dst, ln=None, act=_lib.ACT_NONE, residua
     assert not cast or ln == "cast", label
     assert stats_in is None or (ln is not None and not cast), label
     assert stats_out is None or residual, label
-    assert stats_out is None or (stats_out.dtype == torch.float32 and stats_out.numel() == 2 * src.rows and stats_out.is_contiguous()), label
+    out_parts = tok_linear_stats_parts(src.rows, pt.K, pt.N) if stats_out is not None else 0        # (the library decides: include/cvmi355.h)
+    assert stats_out is None or (stats_out.dtype == torch.float32 and stats_out.numel() == 2 * src.rows * max(out_parts, 1) and stats_out.is_contiguous()), label
     assert stats_in is None or (stats_in.dtype == torch.float32 and stats_in.numel() == 2 * src.rows * max(stats_parts, 1) and stats_in.is_contiguous()), label
     gam, bet, eps = ln if (ln is not None and not cast) else (None, None, 0.0)
     args = (src.ptr, src.ld, 2 if cast else 1 if ln is not None else 0, gam.data_ptr() if gam is not None else None, bet.data_ptr() if bet is not None else None,

@@ -6,8 +6,11 @@ What it restates, batched and on the device, is the chain the reference runs per
         CircuitAnalyzer.bboxes         src/circuit_analyzer.py:267-287   (YOLO.predict -> dicts, python round(), persistent uid)
         non_max_suppression_by_confidence(iou 0.6)                       src/utils.py:346-361
     run_segmentation_and_cropping      src/analysis_pipeline.py:168-225
-        crop_image_and_adjust_bboxes   src/circuit_analyzer.py:937-1284  (host heuristics on <= 300 boxes; stays the caller's:
-                                                                          pass it as `crop_fn`, default = no crop)
+        crop_image_and_adjust_bboxes   src/circuit_analyzer.py:937-1284  (`crop=True`: this package's mirror, crop.py, padding 80 as at
+                                                                          analysis_pipeline.py:177 -- the window is decided on the host
+                                                                          from <= 300 boxes and handed to the segmenter's transform as a
+                                                                          source rectangle of the u8 image already in HBM; `crop_fn`: any
+                                                                          other callable with the reference's signature)
         CircuitAnalyzer.segment_with_sam2                                src/circuit_analyzer.py:321-386
 
 `prompts="learned"` is the reference's own segmentation (one mask per image from the wrapper's learned prompts);
@@ -24,6 +27,7 @@ from collections import defaultdict
 import numpy as np
 import torch
 
+from .crop import adjust_bboxes, crop_image_and_adjust_bboxes, crop_window
 from .detector import non_max_suppression_by_confidence
 from .distributed import gather_rows, shard_range
 
@@ -45,12 +49,18 @@ class CircuitPipeline:
     """detector: `circuitvision_amd.detector.YOLO`-like (`predict(list of uint8 HxWx3) -> [Results]`);
     segmenter: `SAM2Model`-like (`infer_masks(x, boxes=None)`, `.image_size`); transforms: `SAM2Transforms`-like."""
 
-    def __init__(self, detector, segmenter, transforms, stage2_iou=0.6, max_prompts=32, crop_fn=None, swap_channels=True, seg_batch=16):
-        """swap_channels: segment_with_sam2 applies cv2.COLOR_BGR2RGB to whatever it is given (circuit_analyzer.py:343), and the
+    def __init__(self, detector, segmenter, transforms, stage2_iou=0.6, max_prompts=32, crop_fn=None, swap_channels=True, seg_batch=16, crop=False,
+                 crop_padding=80):
+        """crop=True: the reference's chain -- detector -> stage-2 NMS -> crop window from the boxes (crop.py) -> segmenter on the window
+        (analysis_pipeline.py:177 -> :206); False: the segmenter sees the whole image.  crop_fn overrides the built-in crop.
+        swap_channels: segment_with_sam2 applies cv2.COLOR_BGR2RGB to whatever it is given (circuit_analyzer.py:343), and the
         pipeline hands it RGB (analysis_pipeline.py:199-203) -- i.e. the reference's segmenter sees the channels reversed.
         seg_batch: images per segmenter launch (BASELINE configs[2] runs SAM 2.1-L at 16)."""
         self.det, self.seg, self.tr = detector, segmenter, transforms
-        self.stage2_iou, self.max_prompts, self.crop_fn, self.swap = stage2_iou, max_prompts, crop_fn, swap_channels
+        self.stage2_iou, self.max_prompts, self.swap = stage2_iou, max_prompts, swap_channels
+        self.crop_padding = int(crop_padding)
+        self.builtin_crop = bool(crop) and crop_fn is None
+        self.crop_fn = crop_fn if crop_fn is not None else ((lambda im, bb: crop_image_and_adjust_bboxes(im, bb, padding=self.crop_padding)) if crop else None)
         self.seg_batch = max(1, int(seg_batch))
         self.seg_slots = 2                         # segmenter plan instances (each with its own stream) the overlapped path alternates between
         self.timings = defaultdict(float)          # wall seconds per phase, accumulated over calls (bench.py prints them per step)
@@ -80,16 +90,20 @@ class CircuitPipeline:
     def segment(self, images, bboxes, prompts="learned"):
         if prompts not in ("learned", "boxes"):
             raise ValueError("prompts must be 'learned' or 'boxes'")
-        crops, boxes_adj = [], []
+        crops, boxes_adj, infos = [], [], []
         for im, bb in zip(images, bboxes):
+            info = None
             if self.crop_fn is not None:
-                im, bb, _ = self.crop_fn(im, [dict(b) for b in bb])
+                im, bb, info = self.crop_fn(im, [dict(b) for b in bb])
             crops.append(im)
             boxes_adj.append(bb)
+            infos.append(info)
         out = []
         for c0 in range(0, len(crops), self.seg_batch):                   # one segmenter launch per seg_batch images
             sl = slice(c0, c0 + self.seg_batch)
             out += self._segment_chunk(crops[sl], boxes_adj[sl], prompts)
+        for r, info in zip(out, infos):
+            r["crop_debug_info"] = info
         return out
 
     def _product_objects(self):
@@ -149,7 +163,9 @@ class CircuitPipeline:
         mine = list(images[lo:hi])
         if not mine:
             return []
-        if prompts == "learned" and self.crop_fn is None and self._product_objects():
+        if prompts == "learned" and self.builtin_crop and self._product_objects():
+            res = self._run_cropped(mine)
+        elif prompts == "learned" and self.crop_fn is None and self._product_objects():
             res = self._run_overlapped(mine)
         else:
             bboxes = self.detect(mine)
@@ -187,15 +203,57 @@ class CircuitPipeline:
         self._tick("wait: segmenter (GPU time not hidden behind host work) + extents to the host", t)
         return out
 
-    def _enqueue_learned(self, imgs, slot=0):
+    # ---- learned prompts WITH the reference's crop: the segmenter's input depends on the detector's boxes (analysis_pipeline.py:177 -> :206).
+    #      What keeps the GPU busy across that dependency: the detector runs in chunks (one H2D for all images, a graph replay per chunk); as soon
+    #      as chunk k's boxes are on the host, the glue + stage-2 NMS + crop window of its images run there and segmenter chunk k is enqueued --
+    #      its transform reads each window out of the u8 block the detector's letterbox read -- while the GPU is still in detector chunks k + 1 ..
+    #      and segmenter chunks < k.  Only chunk 0's detector pass + glue is not hidden.
+    def _run_cropped(self, images):
+        t = time.perf_counter()
+        groups = {}
+        for i, im in enumerate(images):
+            groups.setdefault(im.shape[:2], []).append(i)
+        work = []                                                          # (image indices of the chunk, detector handle)
+        for idxs in groups.values():
+            hs = self.det.predict_chunks_async([images[i] for i in idxs], self.seg_batch)
+            work += [(idxs[k * self.seg_batch:(k + 1) * self.seg_batch], h) for k, h in enumerate(hs)]
+        t = self._tick("enqueue: detector chunks (stage u8 + ONE H2D + per chunk: letterbox + YOLO11 graph + NMS + D2H launches)", t)
+        out, pend = [None] * len(images), []
+        for k, (idxs, h) in enumerate(work):
+            res = h.result()
+            t = self._tick("wait: detector chunk on the host" if k else "wait: detector chunk 0 on the host (not hidden: the segmenter needs its boxes)", t)
+            wins, metas = [], []
+            for i, r in zip(idxs, res):
+                bb = non_max_suppression_by_confidence(results_to_bboxes(r), iou_threshold=self.stage2_iou)
+                win, info = crop_window(bb, images[i].shape[:2], self.crop_padding)
+                wins.append(win)
+                metas.append((adjust_bboxes(bb, win), info))
+            t = self._tick("glue (dicts + round + uid + stage-2 NMS + crop window + box shift)" + (", overlapped with the GPU" if k else ", chunk 0: not hidden"), t)
+            pend.append((idxs, wins, metas, self._enqueue_learned(None, k % self.seg_slots, src=h.src, windows=wins, det_stream=self.det.stream)))
+            t = self._tick("enqueue: segmenter chunk (transform from the windows of the detector's u8 block + SAM 2.1 graph + post-process)", t)
+        for idxs, wins, metas, fin in pend:
+            u8s, exts, iou = fin()
+            for b, i in enumerate(idxs):
+                im, wnd = images[i], wins[b]
+                view = im if wnd is None else im[wnd[1]:wnd[3], wnd[0]:wnd[2]]              # (a numpy view, as the reference's slice)
+                out[i] = {"image": view, "bboxes": metas[b][0], "mask": u8s[b], "extent": exts[b], "iou": iou[b], "window": wnd,
+                          "crop_debug_info": metas[b][1]}
+        self._tick("wait: segmenter (GPU time not hidden behind host work) + extents to the host", t)
+        return out
+
+    def _enqueue_learned(self, imgs, slot=0, src=None, windows=None, det_stream=None):
         """transform -> SAM 2.1 (learned prompts) -> resize / threshold / u8 / extent for one chunk, enqueued on the stream of segmenter plan
         `slot` (consecutive chunks alternate between two plan instances on two streams: independent images, and two segmenter graphs side by
         side fill each other's kernel tails).  Returns a closure that waits for it: -> (u8 masks [H,W] per image, extent tuples, iou [B,1])."""
         from . import _lib
         seg, tr = self.seg, self.tr
         lib = _lib.load()
-        B, R = len(imgs), seg.image_size
-        sizes = [tuple(im.shape[:2]) for im in imgs]
+        if src is not None:                                             # windows of a u8 device block (the cropped chain)
+            B, R = src.shape[0], seg.image_size
+            sizes = [tuple(src.shape[1:3]) if w is None else (w[3] - w[1], w[2] - w[0]) for w in windows]
+        else:
+            B, R = len(imgs), seg.image_size
+            sizes = [tuple(im.shape[:2]) for im in imgs]
         same = all(sz == sizes[0] for sz in sizes)
         with seg._lock, torch.cuda.device(seg.dev):
             p = seg.plan(B, slot=slot)
@@ -207,12 +265,22 @@ class CircuitPipeline:
             if same:
                 u8 = torch.empty(B, sizes[0][0], sizes[0][1], dtype=torch.uint8, device=seg.dev)
                 u8s = [u8[b] for b in range(B)]
-            else:
-                u8s = [torch.empty(h, w, dtype=torch.uint8, device=seg.dev) for h, w in sizes]
+            else:                                                           # planes of different sizes, packed back to back: one launch
+                offs = np.concatenate(([0], np.cumsum([h * w for h, w in sizes], dtype=np.int64)))
+                u8 = torch.empty(int(offs[-1]), dtype=torch.uint8, device=seg.dev)
+                u8s = [u8[int(offs[b]):int(offs[b + 1])].view(h, w) for b, (h, w) in enumerate(sizes)]
+                sz_np = np.asarray(sizes, dtype=np.int32)
             sst.wait_stream(torch.cuda.current_stream())
+            if det_stream is not None:
+                sst.wait_stream(det_stream)                                 # (the u8 block's H2D copy: already complete -- result() waited -- but stated)
+            for t_ in (iou, ext, u8) + ((src,) if src is not None else ()):
+                t_.record_stream(sst)                                       # written / read on sst: the allocator must not hand them out before sst is past them
             with torch.cuda.stream(sst):
                 sp = sst.cuda_stream
-                tr.forward_batch(imgs, swap_rb=self.swap, out=p.x_in.t, out_dtype=seg.dtype)
+                if src is not None:
+                    tr.forward_windows(src, windows, swap_rb=self.swap, out=p.x_in.t, out_dtype=seg.dtype)
+                else:
+                    tr.forward_batch(imgs, swap_rb=self.swap, out=p.x_in.t, out_dtype=seg.dtype)
                 p.plan.run()
                 iou.copy_(p.iou, non_blocking=True)
                 hi = p.high_res                                             # f32 [B,1,R,R]
@@ -220,9 +288,8 @@ class CircuitPipeline:
                     _lib.check(lib.cvmi_mask_postprocess(hi.data_ptr(), B, R, R, sizes[0][0], sizes[0][1], float(tr.mask_threshold), u8.data_ptr(),
                                                          ext.data_ptr(), sp), "mask_postprocess")
                 else:
-                    for b, (h, w) in enumerate(sizes):
-                        _lib.check(lib.cvmi_mask_postprocess(hi[b].data_ptr(), 1, R, R, h, w, float(tr.mask_threshold), u8s[b].data_ptr(),
-                                                             ext[b].data_ptr(), sp), "mask_postprocess")
+                    _lib.check(lib.cvmi_mask_postprocess_sizes(hi.data_ptr(), B, R, R, sz_np.ctypes.data, float(tr.mask_threshold), u8.data_ptr(),
+                                                               ext.data_ptr(), sp), "mask_postprocess_sizes")
                 ext_h.copy_(ext, non_blocking=True)
                 done = torch.cuda.Event()
                 done.record(sst)

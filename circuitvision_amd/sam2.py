@@ -31,7 +31,7 @@ from . import _lib
 from ._lib import ACT_GELU, ACT_NONE, ACT_RELU, ACT_SIGMOID, BF16, F16, F32
 from .engine import (ESIZE, TORCH_DTYPE, is16, Buf, PackedConv, PackedHieraMlp, PackedTokLinear, Plan, Rows, hiera_mlp_supported, make_attn_desc, op_attention,
                      op_call, op_cast, op_conv, op_hiera_mlp, op_layernorm, op_maxpool2, op_tok_linear, op_tok_linear_pool, require_gpu, row_stats_supported,
-                     tok_linear_supported)
+                     tok_linear_stats_parts, tok_linear_supported)
 
 LOG2E = 1.4426950408889634
 HIERA_L = dict(embed_dim=144, num_heads=2, stages=(2, 6, 36, 4), global_att_blocks=(23, 33, 43), window_spec=(8, 4, 16, 8))
@@ -558,7 +558,8 @@ class Sam2Plan:
         # norm2's statistics travel from the launch that writes x to the launch that normalises it (fc1 then reads x once, not twice)
         fwd = (tok_out and f"b{i}.proj" in wt.tl and f"b{i}" not in wt.mlp and f"b{i}.fc1" in wt.tl
                and os.environ.get("CVMI_SAM_LNSTATS", "1") != "0")
-        stats = torch.empty(B * OH * OW, 2, dtype=torch.float32, device=self.dev) if fwd else None
+        sparts = tok_linear_stats_parts(B * OH * OW, dout, dout) if fwd else 0     # (a launch with fewer row blocks than CUs writes its statistics in slices)
+        stats = torch.empty(B * OH * OW, max(sparts, 1), 2, dtype=torch.float32, device=self.dev) if fwd else None
         if tok_out and f"b{i}.proj" in wt.tl:
             op_tok_linear(self.plan, f"b{i}.proj", wt.tl[f"b{i}.proj"], ao.view(), short.view(), residual=True, stats_out=stats, stats_eps=1e-6)
         else:
@@ -573,7 +574,7 @@ class Sam2Plan:
         else:
             hid = self.buf(OH, OW, 4 * dout, tag="hid")
             if tok_out and f"b{i}.fc1" in wt.tl:                   # norm2 fused into fc1 (+ GELU)
-                op_tok_linear(self.plan, f"b{i}.fc1", wt.tl[f"b{i}.fc1"], x.view(), hid.view(), ln=(gam, bet, 1e-6), act=ACT_GELU, stats_in=stats)
+                op_tok_linear(self.plan, f"b{i}.fc1", wt.tl[f"b{i}.fc1"], x.view(), hid.view(), ln=(gam, bet, 1e-6), act=ACT_GELU, stats_in=stats, stats_parts=sparts)
             else:
                 xn2 = self.buf(OH, OW, dout, tag="xn")
                 op_layernorm(self.plan, f"b{i}.norm2", x.view(), gam, bet, xn2.view(), 1e-6)

@@ -270,6 +270,46 @@ class SAM2Transforms:
                            "sam2_transform")
         return res.permute(0, 3, 1, 2) if out is None else res
 
+    def forward_windows(self, src, windows, swap_rb=False, out=None, out_dtype=F32):
+        """`forward_batch` on a WINDOW of each image of a u8 [B, H, W, 3] DEVICE tensor (e.g. the block the detector's letterbox read:
+        `PendingDetections.src`): windows = [(x0, y0, x1, y1) | None] per image, None = the whole image.  What the reference does with a host
+        crop + a new transform (circuit_analyzer.py:1254 `image[y0:y1, x0:x1]`, then :347) is here a source rectangle of the resize kernel: no
+        cropped copy, no second H2D, bit-identical to transforming a contiguous copy of the window."""
+        require_gpu()
+        lib = _lib.load()
+        if not (torch.is_tensor(src) and src.is_cuda and src.dtype == torch.uint8 and src.dim() == 4 and src.shape[3] == 3 and src.is_contiguous()):
+            raise TypeError("forward_windows expects a contiguous uint8 [B,H,W,3] device tensor")
+        B, H, W = src.shape[:3]
+        if len(windows) != B:
+            raise ValueError("one window (or None) per image")
+        R = self.resolution
+        rects = np.empty((B, 4), dtype=np.int32)
+        for b, wnd in enumerate(windows):
+            x0, y0, x1, y1 = (0, 0, W, H) if wnd is None else wnd
+            rects[b] = (x0, y0, x1 - x0, y1 - y0)
+        res = torch.empty(B, R, R, 3, dtype=torch.float32, device=src.device) if out is None else out
+        _lib.check(lib.cvmi_sam2_transform_rects(src.data_ptr(), H * W * 3, H, W, rects.ctypes.data, B, res.data_ptr(), R, out_dtype, 1 if swap_rb else 0,
+                                                 torch.cuda.current_stream().cuda_stream), "sam2_transform_rects")
+        return res.permute(0, 3, 1, 2) if out is None else res
+
+    def postprocess_to_masks_sized(self, masks, sizes):
+        """postprocess_to_mask_async for planes that return to DIFFERENT sizes (every image its own crop window): masks f32 [N,1,h,w] on the
+        device, sizes = [(H, W)] per plane -> ([u8 [H_n, W_n] views of ONE packed buffer], extent int32 [N,4]); one launch, nothing copied to
+        the host."""
+        require_gpu()
+        lib = _lib.load()
+        m = masks.float().contiguous()
+        N, h, w = m.shape[0] * m.shape[1], m.shape[-2], m.shape[-1]
+        if len(sizes) != N:
+            raise ValueError("one (H, W) per mask plane")
+        sz = np.asarray(sizes, dtype=np.int32).reshape(N, 2)
+        offs = np.concatenate(([0], np.cumsum(sz[:, 0].astype(np.int64) * sz[:, 1])))
+        u8 = torch.empty(int(offs[-1]), dtype=torch.uint8, device=m.device)
+        ext = torch.empty(N, 4, dtype=torch.int32, device=m.device)
+        _lib.check(lib.cvmi_mask_postprocess_sizes(m.data_ptr(), N, h, w, sz.ctypes.data, float(self.mask_threshold), u8.data_ptr(), ext.data_ptr(),
+                                                   torch.cuda.current_stream().cuda_stream), "mask_postprocess_sizes")
+        return [u8[int(offs[n]):int(offs[n + 1])].view(int(sz[n, 0]), int(sz[n, 1])) for n in range(N)], ext
+
     def mask_extent(self, mask_u8):
         """Bounding boxes of binary masks [N,H,W] / [B,C,H,W] (u8 on the device): list of (x0, y0, x1, y1) or None per
         plane, with the reference's convention (circuit_analyzer.py:364-370: boundingRect of the external contours)."""

@@ -300,6 +300,12 @@ int cvmi_tok_linear_stats(const void* in, int in_ld, int in_f32_layernorm, const
                           const void* w_packed, void* out, int out_ld, int out_f32_residual, long long rows, int K, int N, int act,
                           int dtype, const float* ln_stats_in, int ln_stats_in_parts, float* ln_stats_out, float ln_stats_eps,
                           cvmi_stream_t stream);
+/* The layout of ln_stats_out for a residual-form launch of this shape.  0: float[rows][2] of (mean, rstd) as above.  P > 0: the launch has
+ * fewer 256-row blocks than the chip has CUs (the per-rank batch of an 8-GPU job: SAM 2.1-L at 8 images), so P workgroups share a row block,
+ * each writing its output-channel slice, and ln_stats_out is float[rows][P][2] of per-slice (mean, sum of squared deviations) -- exactly what
+ * the consumer takes with ln_stats_in_parts = P.  Depends on (rows, K, N) only; K = 576 (the 16x16x32 format) is the only K that splits.
+ * Requirements of that format beyond the ones above: 16-bit output needs N % 8 == 0 and out_ld % 8 == 0; in_f32_layernorm = 2 is not built. */
+int cvmi_tok_linear_stats_parts(long long rows, int K, int N);
 
 /* Shortcut path of a Hiera q-pooling block in ONE launch: out[b, y, x, :] = max over the 2 x 2 token block of
  * ( LayerNorm(in[b, 2y + dy, 2x + dx, :]) W^T + bias )  = `do_pool(self.proj(norm1(x)))` of sam2 hieradet MultiScaleBlock.forward (behind
@@ -369,6 +375,10 @@ int cvmi_bilinear_f32(const float* x, int N, int h, int w, float* y, int H, int 
  * are written.  extent[n] = {min x, min y, max x, max y} or {W, H, -1, -1} for an empty mask. */
 int cvmi_mask_postprocess(const float* x, int N, int h, int w, int H, int W, float thresh, uint8_t* mask_u8,
                           int* extent, cvmi_stream_t stream);
+/* The same for planes that return to DIFFERENT sizes (each image's own crop window): sizes is a HOST array of N x {H_n, W_n}; plane n is
+ * written at mask_u8 + sum over m < n of H_m * W_m (planes packed back to back); extent[n] as above in plane n's own coordinates. */
+int cvmi_mask_postprocess_sizes(const float* x, int N, int h, int w, const int* sizes, float thresh, uint8_t* mask_u8, int* extent,
+                                cvmi_stream_t stream);
 
 /* Extent of N binary u8 planes [N,H,W]: extent[n] = {min x, min y, max x, max y} over the non-zero pixels, or
  * {W, H, -1, -1} for an empty plane.  Replaces cv2.findContours(RETR_EXTERNAL) + cv2.boundingRect on the SAM 2 mask
@@ -391,6 +401,14 @@ int cvmi_sam2_transform(const uint8_t* src, int H, int W, void* dst, int R, int 
  * is handed, which on the device is an index, not a pass over the image. */
 int cvmi_sam2_transform_batch(const uint8_t* src, int B, int H, int W, void* dst, int R, int dst_dtype, int swap_rb,
                               cvmi_stream_t stream);
+/* The same on a WINDOW of each source image: the crop the reference takes between the detector and the segmenter
+ * (CircuitAnalyzer.crop_image_and_adjust_bboxes, circuit_analyzer.py:937-1284, called with padding = 80 at analysis_pipeline.py:177; the
+ * cropped image is what segment_with_sam2 :206 then resizes), WITHOUT a cropped copy: image b is the window rects[b] = {x0, y0, w, h} of the
+ * u8 [H, W, 3] image at src + b * src_image_stride BYTES (0: every window comes from one image), and exactly the pixels of the window take
+ * part in the antialiased resize -- bit-identical to cvmi_sam2_transform on a contiguous copy of the window.  rects is a HOST array
+ * (B x 4 ints, read during the call; it travels in the kernel arguments).  The source may be the buffer the detector's letterbox read. */
+int cvmi_sam2_transform_rects(const uint8_t* src, long long src_image_stride, int H, int W, const int* rects, int B, void* dst, int R,
+                              int dst_dtype, int swap_rb, cvmi_stream_t stream);
 
 #ifdef __cplusplus
 }
