@@ -63,6 +63,10 @@ def parse():
     ap.add_argument("--prompts", type=int, default=32, help="box prompts per image (sam2l_box)")
     ap.add_argument("--batch", type=int, default=None, help="images per GPU per stage launch (default 32 YOLO / 16 SAM)")
     ap.add_argument("--total-images", type=int, default=64, help="pipeline workload: images in the whole job")
+    ap.add_argument("--seg-batch", type=int, default=16, help="pipeline workload: images per segmenter launch (a rank's share is cut into such batches)")
+    ap.add_argument("--scaling-proxy", type=int, default=0, metavar="N",
+                    help="pipeline workload, 1 GPU: also measure ONE rank's share of an N-GPU job (total-images / N images) and report "
+                         "`strong_scaling_proxy` = its images/s per GPU over this run's -- the only strong-scaling evidence a 1-GPU box can give")
     ap.add_argument("--dtype", default="f16", choices=["f16", "f32", "bf16"], help="operand storage type (bf16: SAM 2 workloads, BASELINE configs[4])")
     ap.add_argument("--attn", default="16", choices=["16", "fp8"], help="fp8: the AV products of Hiera's 256-key windows / global blocks on the block-scaled fp8 MFMA (BASELINE configs[4])")
     ap.add_argument("--streams", type=int, default=3, choices=[1, 2, 3, 4],
@@ -433,24 +437,35 @@ class SamStage:
         return torch.stack([osam.sam2_transform(circuit_image(768, 1024, seed=s), 1024) for s in self.seeds[:1]])
 
 
+# Label map of the host-inclusive pipeline: the crop decision (circuit_analyzer.py:937-1284) reads class names.  Component, junction, text and
+# ignored classes in the proportions of a circuit label set.  NOTE: the seeded random detector of this bench returns ~25 boxes per image after the
+# stage-2 NMS, all of ONE class (33) and each ~480 px wide (checked on the CPU oracle): the crop code runs (clustering, scoring, basis) and then
+# declines -- "basis covers > 90 % of the page" -- so every window of this bench is the whole image.  The dependency (segmenter chunk k waits
+# for detector chunk k's boxes on the host) and the glue's cost are real; non-trivial windows are exercised by tests/test_crop_gpu.py.
+PIPE_NAMES = {i: (f"component{i}" if i % 10 in (0, 3) else "junction" if i % 10 == 1 else "text" if i % 10 == 2 else "explanatory") for i in range(62)}
+
+
 class HostPipeline:
     """The pipeline as a caller runs it: `CircuitPipeline.run_batch` on u8 HOST images of this rank's shard, sharing the packed weights of
-    the graph-only stages (analysis_pipeline.py:97-115 + :168-225 per image in the reference).  Everything the reference chains between
-    the two models is inside the timed call: H2D, letterbox, detector, D2H of the detections, dicts + round() + uid + stage-2 NMS,
-    channel swap + transform, segmenter, post-process (resize, threshold, u8, extent), D2H of the u8 masks."""
+    the graph-only stages (analysis_pipeline.py:97-115 + :168-225 per image in the reference), WITH the reference's data dependency
+    (crop=True): the segmenter's input is a window of the image that the detector's boxes decide (analysis_pipeline.py:177 -> :206).
+    Inside the timed call: H2D, letterbox, detector, D2H of the detections, dicts + round() + uid + stage-2 NMS, crop window + box shift,
+    channel swap + transform of the window, segmenter, post-process (resize to the window's size, threshold, u8, extent), D2H of the u8 masks.
+    crop=False is the round-3 measurement (no dependency: segmenter and detector enqueued together), kept beside it."""
 
-    def __init__(self, a, ystage, sstage, n, seed0):
+    def __init__(self, a, ystage, sstage, n, seed0, crop=True):
         import torch
         from circuitvision_amd.detector import YOLO
         from circuitvision_amd.pipeline import CircuitPipeline
         from circuitvision_amd.sam2 import HIERA_L
         from circuitvision_amd.sam2_infer import SAM2Model, SAM2Transforms
         from synth import circuit_image
-        det = YOLO.from_weights(ystage.wt, {i: f"class{i}" for i in range(ystage.nc)}, dtype=a.dtype, graph_lanes=0)     # the stage's (bias-shifted) packed weights
+        det = YOLO.from_weights(ystage.wt, PIPE_NAMES, dtype=a.dtype, graph_lanes=0)     # the stage's (bias-shifted) packed weights
         seg = SAM2Model(HIERA_L, 1024, dtype=a.dtype, use_refinement=True)
         seg.weights, seg.params = sstage.wt, sstage.params
         tr = SAM2Transforms(resolution=1024, mask_threshold=0, max_hole_area=0, max_sprinkle_area=0)
-        self.pipe = CircuitPipeline(det, seg, tr, seg_batch=16)
+        self.pipe = CircuitPipeline(det, seg, tr, seg_batch=a.seg_batch, crop=crop, crop_padding=80)
+        self.crop = crop
         self.images = [circuit_image(640, 640, seed=seed0 + i) for i in range(n)]
         self.n = n
         self.torch = torch
@@ -473,10 +488,22 @@ class HostPipeline:
         self.torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / steps
         nb = sum(len(r["bboxes"]) for _, r in res)
-        return {"images_per_s": round(self.n / dt, 2), "ms_per_step": round(dt * 1e3, 3), "steps": steps,
+        info = {"images_per_s": round(self.n / dt, 2), "ms_per_step": round(dt * 1e3, 3), "steps": steps,
                 "mean_boxes_after_stage2_nms": round(nb / max(1, len(res)), 1),
                 "phases_ms_per_step": {k: round(v / steps * 1e3, 3) for k, v in self.pipe.timings.items()},
-                "what": "CircuitPipeline.run_batch(images u8 HxWx3 on the host, prompts='learned') + .cpu() of the u8 masks, wall clock around the calls"}
+                "what": "CircuitPipeline.run_batch(images u8 HxWx3 on the host, prompts='learned'" + (", crop=True, padding 80" if self.crop else "") +
+                        ") + .cpu() of the u8 masks, wall clock around the calls"}
+        if self.crop:
+            wins = [r["window"] for _, r in res]
+            fr = [((w[2] - w[0]) * (w[3] - w[1])) / float(self.images[i].shape[0] * self.images[i].shape[1]) for i, w in enumerate(wins) if w is not None]
+            reasons = {}
+            for _, r in res:
+                k = r["crop_debug_info"]["reason_for_no_crop"] or "cropped"
+                reasons[k] = reasons.get(k, 0) + 1
+            info["crop"] = {"images_cropped": len(fr), "of": len(wins), "mean_window_area_fraction": round(sum(fr) / len(fr), 3) if fr else None,
+                            "decisions": reasons,
+                            "dependency": "segmenter chunk k is enqueued only after detector chunk k's boxes are on the host and its crop windows computed"}
+        return info
 
 
 # ---- main ---------------------------------------------------------------------------------------------------------------------
@@ -490,6 +517,18 @@ def main():
         raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}; launch with torchrun --nproc-per-node {a.gpus} or drop the torchrun environment")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    proxy = None
+    if a.scaling_proxy > 1 and a.workload == "pipeline" and world == 1:
+        # one rank's share of an N-GPU run of the same job, measured in a child process BEFORE this one touches the GPU
+        share = a.total_images // a.scaling_proxy
+        if a.total_images % a.scaling_proxy or share % 2:
+            raise SystemExit("--scaling-proxy N: total-images / N must be a whole, even number of images")
+        cmd = [sys.executable, os.path.abspath(__file__), "--workload", "pipeline", "--total-images", str(share), "--seg-batch", str(a.seg_batch),
+               "--dtype", a.dtype, "--streams", str(a.streams), "--steps", str(a.steps * 4), "--warmup", str(a.warmup * 2), "--no-cpu-baseline", "--no-profile-pass"]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise SystemExit(f"bench.py: the --scaling-proxy child failed:\n{r.stderr[-2000:]}")
+        proxy = json.loads(r.stdout.strip().splitlines()[-1])
 
     import torch
     import torch.distributed as dist
@@ -517,27 +556,28 @@ def main():
                                         lanes=0 if a.streams > 1 else None))]
         stages += [(f"sam2l[{j}]", SamStage(a, bs, rank, local_rank, world, sam_streams[j % 2], seed0 + j * bs)) for j in range(nsam)]
         images_per_step = by
-        name = (f"YOLO11-n 640x640 batch={by} fp16 forward+decode+NMS (BASELINE configs[1]) + SAM2.1 Hiera-L 1024x1024 {nsam} x batch={bs} fp16 "
+        name = (f"YOLO11-n 640x640 batch={by} {a.dtype} forward+decode+NMS (BASELINE configs[1]) + SAM2.1 Hiera-L 1024x1024 {nsam} x batch={bs} {a.dtype} "
                 "learned-prompt wrapper forward (configs[2]) on the same images, per GPU and step")
     elif w in ("yolo11n", "yolo11l"):
         B = a.batch or 32
         stages = [(w, YoloStage(a, w[-1], B, rank, local_rank, world, stream, 20250704 + rank * B))]
         images_per_step = B
-        name = f"YOLO11-{w[-1]} 640x640 batch={B}/GPU fp16 forward+decode+NMS" + (" (BASELINE configs[1])" if w == "yolo11n" else "")
+        name = f"YOLO11-{w[-1]} 640x640 batch={B}/GPU {a.dtype} forward+decode+NMS" + (" (BASELINE configs[1])" if w == "yolo11n" else "")
     elif w in ("sam2l", "sam2l_box"):
         B = a.batch or 16
         P = a.prompts if w == "sam2l_box" else 0
         stages = [(w, SamStage(a, B, rank, local_rank, world, stream, 20250704 + rank * B, prompts=P))]
         images_per_step = B
-        name = (f"SAM2.1 Hiera-L 1024x1024 batch={B}/GPU learned-prompt wrapper forward (BASELINE configs[2])" if not P else
-                f"SAM2.1 Hiera-L 1024x1024 batch={B}/GPU, {P} box prompts per image, fp16 (one GPU's share of BASELINE configs[4])")
+        attn = " + fp8 AV attention" if a.attn == "fp8" else ""
+        name = (f"SAM2.1 Hiera-L 1024x1024 batch={B}/GPU {a.dtype}{attn} learned-prompt wrapper forward (BASELINE configs[2])" if not P else
+                f"SAM2.1 Hiera-L 1024x1024 batch={B}/GPU, {P} box prompts per image, {a.dtype}{attn} (one GPU's share of BASELINE configs[4])")
     else:                                                        # pipeline: configs[3], strong scaling over a fixed total
         from circuitvision_amd.distributed import shard_range
         lo, hi = shard_range(a.total_images, rank, world)
         n = hi - lo
         if a.total_images % world or n % 2:
             raise SystemExit("--total-images must split evenly (and into an even share) over the ranks")
-        bs = min(16, n)
+        bs = min(a.seg_batch, n)
         sam_sizes = [bs] * (n // bs) + ([n % bs] if n % bs else [])          # EVERY image of the shard goes through the segmenter
         assert sum(sam_sizes) == n
         seed0 = 20250704 + lo
@@ -551,11 +591,12 @@ def main():
             off += b_
         images_per_step = n
         scaling = "strong"
-        host_pipe = HostPipeline(a, stages[0][1], stages[1][1], n, seed0)
+        host_pipe = HostPipeline(a, stages[0][1], stages[1][1], n, seed0, crop=True)
+        host_pipe_nocrop = HostPipeline(a, stages[0][1], stages[1][1], n, seed0, crop=False)
         name = (f"full pipeline YOLO11-l 640x640 + SAM2.1 Hiera-L 1024x1024, {a.total_images} circuit images per step sharded over {world} GPU(s) "
-                f"({n} per GPU: detector batch {n}, segmenter batches {sam_sizes}), fp16 (BASELINE configs[3]); `value` = graph replays on "
-                "resident tensors, `host_inclusive` = CircuitPipeline.run_batch on u8 host images (H2D, letterbox, detector, D2H + glue + "
-                "stage-2 NMS, transform, segmenter, post-process, D2H of the u8 masks)")
+                f"({n} per GPU: detector batch {n}, segmenter batches {sam_sizes}), {a.dtype} (BASELINE configs[3]); `value` = graph replays on "
+                "resident tensors, `host_inclusive` = CircuitPipeline.run_batch(crop=True) on u8 host images (H2D, letterbox, detector, D2H + glue + "
+                "stage-2 NMS + crop window, transform of the window, segmenter, post-process, D2H of the u8 masks)")
 
     def run_step():
         for _, st in stages:
@@ -591,6 +632,9 @@ def main():
             host_info["ms_per_step"] = round(float(t.item()), 3)
             host_info["images_per_s"] = round(world * images_per_step / float(t.item()) * 1e3, 2)
         host_info["ratio_vs_graph_only"] = round(host_info["images_per_s"] / value, 4)
+        nc_info = host_pipe_nocrop.measure(max(2, a.steps // 2), 1)
+        host_info["without_crop_dependency"] = {"images_per_s": nc_info["images_per_s"], "ms_per_step": nc_info["ms_per_step"],
+                                                "what": "the round-3 measurement: no crop, segmenter enqueued before the detector's boxes are on the host (rank-local)"}
 
     # ---- per-stage timing (graph replays alone) + per-launch timing pass (un-captured, event pairs on the engine stream)
     stage_info, rooflines, cpu_parts = {}, {}, {}
@@ -654,6 +698,18 @@ def main():
         }
         if host_info is not None:
             line["host_inclusive"] = host_info
+        if proxy is not None:
+            hp, hi = proxy.get("host_inclusive", {}), host_info or {}
+            line["strong_scaling_proxy"] = {
+                "ranks_simulated": a.scaling_proxy, "images_per_rank": a.total_images // a.scaling_proxy,
+                "graph_only": {"images_per_s_per_gpu_at_share": proxy["value"], "images_per_s_per_gpu_at_full": round(value, 3),
+                               "ratio": round(proxy["value"] / value, 4)},
+                "host_inclusive": {"images_per_s_per_gpu_at_share": hp.get("images_per_s"), "images_per_s_per_gpu_at_full": hi.get("images_per_s"),
+                                   "ratio": round(hp["images_per_s"] / hi["images_per_s"], 4) if hp.get("images_per_s") and hi.get("images_per_s") else None},
+                "what": f"ONE GPU running one rank's share ({a.total_images // a.scaling_proxy} images) of a {a.scaling_proxy}-GPU run of this {a.total_images}-image job, "
+                        "against the same GPU running the whole job: images/s per GPU, share over full = the strong-scaling efficiency the sharded job "
+                        "can reach when nothing else (host contention, RCCL start-up) is lost; measured on ONE GPU, no multi-GPU hardware curve exists",
+                "share_run": {k: proxy.get(k) for k in ("value", "ms_per_step", "steps", "config")}, "share_host_inclusive": hp}
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -800,3 +800,77 @@ def test_gemm_row_statistics_feed_the_next_layernorm(dt):
     xb.t.copy_(x0.view(1, 1, M, N)); parts.zero_()
     run(plan)
     assert torch.equal(parts, first[0]) and torch.equal(oa, first[1])
+
+
+@pytest.mark.parametrize("dt", [F16, BF16])
+def test_tok_linear16_row_blocks_shared_between_workgroups(dt):
+    """A K = 576 launch with fewer 256-row blocks than the chip has CUs (SAM 2.1-L at 8 images per rank = 128 blocks; here 8) gives each row
+    block to several workgroups, each walking its own range of output-channel chunks (tok_linear16.hip, gridDim.y).  Every form of the kernel at
+    such a shape vs fp32 torch: LayerNorm + GELU (fc1, 8 sharers), LayerNorm plain (qkv, 6), residual with statistics out (proj, 6: the
+    statistics then arrive as per-slice (mean, sum of squared deviations) pairs, `cvmi_tok_linear_stats_parts`), their consumption by the next
+    LayerNorm launch, a ragged last chunk (N = 40, 2 sharers), the pooled projection; reruns are bit-identical."""
+    import torch.nn.functional as TF
+    from circuitvision_amd.engine import TORCH_DTYPE, Buf, PackedTokLinear, Rows, op_tok_linear, op_tok_linear_pool, tok_linear_stats_parts
+    td = TORCH_DTYPE[dt]
+    tol = 1.0 if dt == F16 else 8.0
+    K, rows = 576, 2048
+    P = tok_linear_stats_parts(rows, K, K)
+    assert P == 6 and tok_linear_stats_parts(65536, K, K) == 0 and tok_linear_stats_parts(32768, K, K) == 2 and tok_linear_stats_parts(rows, 288, 288) == 0
+    g = torch.Generator().manual_seed(11)
+    mk = lambda n: (quant(torch.randn(n, K, generator=g) / K ** 0.5, dt), torch.randn(n, generator=g) * 0.3)
+    (wp, bp), (w1, b1), (wq, bq), (ws, bs) = mk(K), mk(2304), mk(1728), mk(40)
+    gam, bet = torch.rand(K, generator=g) + 0.5, torch.randn(K, generator=g) * 0.2
+    a = quant(torch.randn(rows, K, generator=g), dt)
+    x0 = torch.randn(rows, K, generator=g) * 1.5 + 3.0
+    x0[:, 7] += 50.0
+    xd = x0.cuda()
+    stats = torch.zeros(rows, P, 2, device="cuda")
+    hid = torch.empty(rows, 2304, dtype=td, device="cuda"); hid2 = torch.empty_like(hid)
+    qkv = torch.empty(rows, 1728, dtype=td, device="cuda")
+    small = torch.randn(rows, 40, generator=g).cuda(); small0 = small.clone()
+    pk = lambda w, b: PackedTokLinear(w, b, dtype=dt)
+    plan = Plan(stream())
+    op_tok_linear(plan, "proj", pk(wp, bp), Rows(a.to(td).cuda(), rows, K), Rows(xd, rows, K), residual=True, stats_out=stats, stats_eps=1e-6)
+    op_tok_linear(plan, "fc1_fwd", pk(w1, b1), Rows(xd, rows, K), Rows(hid, rows, 2304), ln=(gam.cuda(), bet.cuda(), 1e-6), act=ACT_GELU, stats_in=stats, stats_parts=P)
+    op_tok_linear(plan, "fc1_own", pk(w1, b1), Rows(xd, rows, K), Rows(hid2, rows, 2304), ln=(gam.cuda(), bet.cuda(), 1e-6), act=ACT_GELU)
+    op_tok_linear(plan, "qkv", pk(wq, bq), Rows(xd, rows, K), Rows(qkv, rows, 1728), ln=(gam.cuda(), bet.cuda(), 1e-6))
+    op_tok_linear(plan, "ragged", pk(ws, bs), Rows(a.to(td).cuda(), rows, K), Rows(small, rows, 40), residual=True)
+    run(plan)
+    x1 = x0 + a @ wp.t() + bp
+    torch.testing.assert_close(xd.cpu(), x1, rtol=3e-3 * tol, atol=3e-3 * tol)
+    x1d = xd.cpu().double()                                                 # statistics are those of the rows as WRITTEN, per 96-column slice
+    sl = x1d.view(rows, P, K // P)
+    exp = torch.stack((sl.mean(2), sl.var(2, unbiased=False) * (K // P)), 2).float()
+    torch.testing.assert_close(stats.cpu(), exp, rtol=1e-4, atol=1e-3)
+    xn = quant(TF.layer_norm(x1d.float(), (K,), gam, bet, 1e-6), dt)
+    ya, yb = hid.float().cpu(), hid2.float().cpu()
+    torch.testing.assert_close(ya, yb, rtol=2e-3 * tol, atol=2e-3 * tol)
+    torch.testing.assert_close(ya, TF.gelu(xn @ w1.t() + b1), rtol=6e-3 * tol, atol=6e-3 * tol)
+    torch.testing.assert_close(qkv.float().cpu(), xn @ wq.t() + bq, rtol=6e-3 * tol, atol=6e-3 * tol)
+    torch.testing.assert_close(small.cpu(), small0.cpu() + a @ ws.t() + bs, rtol=3e-3 * tol, atol=3e-3 * tol)
+    first = (xd.clone(), hid.clone(), qkv.clone(), stats.clone())
+    xd.copy_(x0); small.copy_(small0)
+    run(plan)
+    assert all(torch.equal(u, v) for u, v in zip(first, (xd, hid, qkv, stats)))
+    # pooled projection (the 3 -> 4 stage transition's shortcut), 2048 rows of the token grid
+    B, H, W, N = 2, 32, 32, 1152
+    wpo, bpo = quant(torch.randn(N, K, generator=g) / K ** 0.5, dt), torch.randn(N, generator=g) * 0.3
+    xg = torch.randn(B, H, W, K, generator=g) * 1.5 + 0.7
+    ref = TF.max_pool2d((quant(TF.layer_norm(xg, (K,), gam, bet, 1e-6), dt) @ wpo.t() + bpo).permute(0, 3, 1, 2), 2, 2).permute(0, 2, 3, 1)
+    src = Buf(B, H, W, K, F32); src.t.copy_(xg)
+    dst = Buf(B, H // 2, W // 2, N, F32)
+    plan = Plan(stream())
+    op_tok_linear_pool(plan, "pool", pk(wpo, bpo), src.view(), dst.view(), (gam.cuda(), bet.cuda(), 1e-6))
+    run(plan)
+    torch.testing.assert_close(dst.t.float().cpu(), ref, rtol=4e-3 * tol, atol=4e-3 * tol)
+
+
+def test_tok_linear_plain_f32_input_is_rejected_at_k576():
+    """in_f32_layernorm = 2 (f32 rows converted as they are) is built for K = 144 / 288 only; K = 576 must fail cleanly at the C ABI instead of
+    running the LayerNorm form with NULL gamma / beta."""
+    lib = _lib.load()
+    x = torch.zeros(256, 576, device="cuda")
+    y = torch.zeros(256, 64, dtype=torch.float16, device="cuda")
+    w = torch.zeros(lib.cvmi_tok_linear_packed_bytes(576, 64) // 2, dtype=torch.float16, device="cuda")
+    rc = lib.cvmi_tok_linear(x.data_ptr(), 576, 2, None, None, 0.0, w.data_ptr(), y.data_ptr(), 64, 0, 256, 576, 64, ACT_NONE, F16, None)
+    assert rc != 0 and b"K = 144 and 288" in lib.cvmi_last_error()
