@@ -267,3 +267,52 @@ def test_gather_detections_uneven_shards_gloo_world2():
     out = mgr.dict()
     mp.spawn(_uneven_gather_worker, args=(world, port, out), nprocs=world, join=True)
     assert out[1] is None and out[0] == ([3, 2], [0, 1, 2, 3, 4], [0.0, 1.0, 2.0, 3.0, 4.0])
+
+
+def _world8_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from circuitvision_amd.pipeline import CircuitPipeline, gather_results
+    images = _pipeline_images(64)
+    pipe = CircuitPipeline(_FakeDetector(), _FakeSegmenter(), _FakeTransforms(), crop=True, crop_padding=4)     # the reference's chain: detector -> crop -> segmenter
+    res = pipe.run_batch(images, "learned", rank, world)
+    # crops differ in size per image: gather the extents (same shape everywhere) and the window-sized masks padded into the page
+    for i, r in res:
+        full = torch.zeros(images[i].shape[:2], dtype=torch.uint8)
+        w = r["crop_debug_info"]["final_crop_window_abs"] if r["crop_debug_info"]["crop_applied"] else (0, 0, images[i].shape[1], images[i].shape[0])
+        full[w[1]:w[3], w[0]:w[2]] = r["mask"][0, 0] if r["mask"].dim() == 4 else r["mask"]
+        r["page_mask"] = full
+    masks = gather_results(res, "page_mask", dst=3)                 # (a destination other than rank 0)
+    out[rank] = ([i for i, _ in res], [[b["persistent_uid"] for b in r["bboxes"]] for _, r in res], [r["crop_debug_info"]["final_crop_window_abs"] for _, r in res],
+                 {k: v.clone() for k, v in masks.items()} if masks is not None else None)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_configs3_shape_64_images_over_8_ranks_gloo_world8():
+    """BASELINE configs[3] as named: 64 circuit images, image-parallel over 8 ranks (8 each), the reference's chain per image (detector ->
+    stage-2 NMS -> crop window -> segmenter on the window), no collective on the data path; one gather of the results on one rank.  The union
+    of the 8 shards equals the single-process run image for image (boxes, crop windows, masks)."""
+    from circuitvision_amd.distributed import shard_range
+    from circuitvision_amd.pipeline import CircuitPipeline
+    assert [shard_range(64, r, 8) for r in range(8)] == [(8 * r, 8 * r + 8) for r in range(8)]
+    world, port = 8, 37000 + os.getpid() % 2000
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_world8_worker, args=(world, port, out), nprocs=world, join=True)
+    images = _pipeline_images(64)
+    ref = CircuitPipeline(_FakeDetector(), _FakeSegmenter(), _FakeTransforms(), crop=True, crop_padding=4).run_batch(images, "learned")
+    got = dict(out)
+    assert [got[r][0] for r in range(8)] == [list(range(8 * r, 8 * r + 8)) for r in range(8)]
+    uids = [u for r in range(8) for u in got[r][1]]
+    wins = [w for r in range(8) for w in got[r][2]]
+    assert uids == [[b["persistent_uid"] for b in r["bboxes"]] for _, r in ref]
+    assert wins == [r["crop_debug_info"]["final_crop_window_abs"] for _, r in ref] and sum(w is not None for w in wins) >= 32
+    gathered = got[3][3]
+    assert all(got[r][3] is None for r in range(8) if r != 3) and sorted(gathered) == list(range(64))
+    for i, r in ref:
+        w = r["crop_debug_info"]["final_crop_window_abs"] if r["crop_debug_info"]["crop_applied"] else (0, 0, images[i].shape[1], images[i].shape[0])
+        m = r["mask"][0, 0] if r["mask"].dim() == 4 else r["mask"]
+        assert torch.equal(gathered[i][w[1]:w[3], w[0]:w[2]], m), i

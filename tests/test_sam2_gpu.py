@@ -241,48 +241,51 @@ def _assert_logits(name, got, ref, max_rel, rms_rel):
 
 def test_sam2_wrapper_hiera_l_f16_matches_oracle():
     """BASELINE config 3 shape at B=1: SAM 2.1 Hiera-L, 1024^2, fp16 operands / fp32 residual stream.
-    Tolerances written here: low-res mask logits within 25 % of their standard deviation (max) and 4 % (rms) of the fp32 oracle
-    after 48 fp16 blocks (logit std ~0.4: the r1 bound of 5e-2 x max|logit| was the same 0.1 absolute), binary masks IoU >= 0.99."""
+    Tolerances written here, ~3x the measured error (r03 / r04: 8e-3 std max, 1.6e-3 std rms after 48 fp16 blocks): low-res mask logits
+    within 0.03 std (max) / 0.006 std (rms) of the fp32 oracle -- a kernel regression that makes the fp16 path 4x worse fails --,
+    binary masks IoU >= 0.998, predicted IoU within 5e-3."""
     from circuitvision_amd.sam2 import HIERA_L, LORA_TARGETS_REFERENCE
     sp, (hi, lo, iou, inter) = _run_wrapper(HIERA_L, LORA_TARGETS_REFERENCE, _hiera_l_oracle, 1024, F16, B=1)
     got = sp.low_res.cpu()
-    _assert_logits("Hiera-L f16 low-res logits", got, lo, 0.25, 0.04)
-    _assert_logits("Hiera-L f16 feat_s1", sp.feat_s1.t.float().permute(0, 3, 1, 2).cpu(), inter["s1"], 0.10, 0.015)
+    _assert_logits("Hiera-L f16 low-res logits", got, lo, 0.03, 0.006)
+    _assert_logits("Hiera-L f16 feat_s1", sp.feat_s1.t.float().permute(0, 3, 1, 2).cpu(), inter["s1"], 0.03, 0.004)
     a, b = sp.high_res.cpu() > 0, hi > 0
     inter_, union = (a & b).sum().item(), (a | b).sum().item()
-    assert union == 0 or inter_ / union >= 0.99
-    torch.testing.assert_close(sp.iou.cpu(), iou, rtol=0, atol=2e-2)
+    print(f"Hiera-L f16: binary-mask IoU vs the fp32 oracle {inter_ / max(1, union):.5f}, max |iou pred - oracle| {float((sp.iou.cpu() - iou).abs().max()):.2e}")
+    assert union == 0 or inter_ / union >= 0.998
+    torch.testing.assert_close(sp.iou.cpu(), iou, rtol=0, atol=5e-3)
 
 
 def test_sam2_hiera_l_bf16_matches_oracle():
     """BASELINE configs[4] operand type at the configs[2] shape, B = 1: SAM 2.1 Hiera-L in bf16 (bf16 MFMA operands incl. attention,
-    f32 residual streams / statistics / softmax).  Tolerance (measured r02: 5.9e-2 / 1.2e-2 of the logits' std, mask IoU 0.9987): low-res
-    mask logits within 0.25 std (max) / 0.05 std (rms) of the fp32 oracle, binary-mask IoU >= 0.99."""
+    f32 residual streams / statistics / softmax).  Tolerance = 2x measured (r02 - r04: 5.9e-2 / 1.2e-2 of the logits' std, mask IoU 0.9987): low-res
+    mask logits within 0.12 std (max) / 0.025 std (rms) of the fp32 oracle, binary-mask IoU >= 0.997."""
     from circuitvision_amd.sam2 import HIERA_L, LORA_TARGETS_REFERENCE
     sp, (hi, lo, iou, inter) = _run_wrapper(HIERA_L, LORA_TARGETS_REFERENCE, _hiera_l_oracle, 1024, BF16, B=1)
-    _assert_logits("Hiera-L bf16 low-res logits", sp.low_res.cpu(), lo, 0.25, 0.05)
+    _assert_logits("Hiera-L bf16 low-res logits", sp.low_res.cpu(), lo, 0.12, 0.025)
     a, b = sp.high_res.cpu() > 0, hi > 0
     iou_m = (a & b).sum().item() / max(1, (a | b).sum().item())
     print(f"Hiera-L bf16: binary-mask IoU vs the fp32 oracle {iou_m:.4f}")
-    assert iou_m >= 0.99
+    assert iou_m >= 0.997
 
 
 @pytest.mark.parametrize("dtype", [BF16, F16])
 def test_sam2_hiera_l_fp8_attention_matches_oracle(dtype):
     """BASELINE configs[4] "bf16 + fp8 MFMA attention" at B = 1: SAM 2.1 Hiera-L with the AV products of its 32 sixteen-by-sixteen-window blocks
     and 3 global blocks on the block-scaled fp8 MFMA (P e4m3 x 2^8, V e4m3; `attn="fp8"`), everything else in the plan's 16-bit type, vs the
-    fp32 oracle.  Reported: logit error in units of the logits' std and the binary-mask IoU.  Bounds (e4m3 keeps 3 mantissa bits of V in 35 of
-    48 blocks): low-res logits within 0.25 std (max) / 0.05 std (rms) -- the bf16 test's bounds -- and mask IoU >= 0.99.  Measured r03:
-    fp16 + fp8 1.9e-2 / 3.3e-3 std, IoU 0.9996 (fp16 alone 8e-3 / 1.6e-3); bf16 + fp8 4.9e-2 / 1.1e-2 std, IoU 0.9988 (bf16 alone 5.9e-2 / 1.2e-2)."""
+    fp32 oracle.  Reported: logit error in units of the logits' std and the binary-mask IoU.  Bounds = 2x measured, per operand type (e4m3
+    keeps 3 mantissa bits of V in 35 of 48 blocks).  Measured r03: fp16 + fp8 1.9e-2 / 3.3e-3 std, IoU 0.9996 (fp16 alone 8e-3 / 1.6e-3) ->
+    0.04 / 0.007, IoU >= 0.999; bf16 + fp8 4.9e-2 / 1.1e-2 std, IoU 0.9988 (bf16 alone 5.9e-2 / 1.2e-2) -> 0.10 / 0.022, IoU >= 0.997."""
     from circuitvision_amd.sam2 import HIERA_L, LORA_TARGETS_REFERENCE
     sp, (hi, lo, iou, inter) = _run_wrapper(HIERA_L, LORA_TARGETS_REFERENCE, _hiera_l_oracle, 1024, dtype, B=1, attn="fp8")
     kinds = [op[0] for op in sp.plan.ops if op[1] in ("attn_window", "attn_global")]
     assert len(kinds) == 48
-    _assert_logits(f"Hiera-L {'bf16' if dtype == BF16 else 'f16'} + fp8 attention low-res logits", sp.low_res.cpu(), lo, 0.25, 0.05)
+    mx, rms, miou = (0.10, 0.022, 0.997) if dtype == BF16 else (0.04, 0.007, 0.999)
+    _assert_logits(f"Hiera-L {'bf16' if dtype == BF16 else 'f16'} + fp8 attention low-res logits", sp.low_res.cpu(), lo, mx, rms)
     a, b = sp.high_res.cpu() > 0, hi > 0
     iou_m = (a & b).sum().item() / max(1, (a | b).sum().item())
     print(f"Hiera-L {'bf16' if dtype == BF16 else 'f16'} + fp8 attention: binary-mask IoU vs the fp32 oracle {iou_m:.4f}")
-    assert iou_m >= 0.99
+    assert iou_m >= miou
 
 
 def test_boundary_get_modified_sam2_and_transforms():
@@ -446,13 +449,24 @@ def test_config1_sample_image_yolo11n_plus_sam2_tiny(tmp_path):
     from helpers import assert_same_detections
     assert ref.shape[0] >= 20
     assert_same_detections("config 1 detector", r.anchor_idx.cpu().tolist(), ref_idx.tolist(), pred=opred[0])
-    if r.anchor_idx.cpu().tolist() == ref_idx.tolist():
-        assert r.boxes.cls.cpu().tolist() == ref[:, 5].tolist()
-        np.testing.assert_allclose(r.boxes.xyxy.cpu().numpy(), ref[:, :4].numpy(), atol=0.05)
+    # every anchor BOTH sides kept: same class, same box within 0.05 px (unconditional: a tie-flipped anchor elsewhere in the list does not
+    # switch these checks off)
+    gi, ri = r.anchor_idx.cpu().tolist(), ref_idx.tolist()
+    gpos, rpos = {a: k for k, a in enumerate(gi)}, {a: k for k, a in enumerate(ri)}
+    both = [a for a in gi if a in rpos]
+    assert len(both) >= 0.97 * len(ri)
+    gk, rk = [gpos[a] for a in both], [rpos[a] for a in both]
+    assert r.boxes.cls.cpu()[gk].tolist() == ref[rk, 5].tolist()
+    np.testing.assert_allclose(r.boxes.xyxy.cpu().numpy()[gk], ref[rk, :4].numpy(), atol=0.05)
+    np.testing.assert_allclose(r.boxes.conf.cpu().numpy()[gk], ref[rk, 4].numpy(), atol=1e-3)
     got_d = onms.boxes_to_dicts(r.boxes.xyxy.cpu().numpy().tolist(), r.boxes.conf.cpu().numpy().tolist(), r.boxes.cls.cpu().numpy().tolist(), r.names)
     ref_d = onms.boxes_to_dicts(ref[:, :4].tolist(), ref[:, 4].tolist(), ref[:, 5].tolist(), r.names)
-    if [b["persistent_uid"] for b in got_d] == [b["persistent_uid"] for b in ref_d]:     # (a coordinate within 0.05 px of x.5 may round apart)
-        assert [b["persistent_uid"] for b in non_max_suppression_by_confidence(got_d, 0.6)] == [b["persistent_uid"] for b in onms.nms_by_confidence(ref_d, 0.6)]
+    # stage-2 NMS (utils.py:346-361): product mirror == oracle on the SAME list, always; and the two chains' outputs agree up to the few boxes
+    # whose rounded coordinates differ (a coordinate within 0.05 px of x.5 may round apart: the uid string then differs)
+    uid = lambda bs: [b["persistent_uid"] for b in bs]
+    assert uid(non_max_suppression_by_confidence(got_d, 0.6)) == uid(onms.nms_by_confidence(got_d, 0.6))
+    assert uid(non_max_suppression_by_confidence(ref_d, 0.6)) == uid(onms.nms_by_confidence(ref_d, 0.6))
+    assert_same_detections("config 1 stage-2 NMS", uid(non_max_suppression_by_confidence(got_d, 0.6)), uid(onms.nms_by_confidence(ref_d, 0.6)), top=5, min_overlap=0.9)
     # --- segmenter (circuit_analyzer.py:321-356)
     p = SamSyntheticParams(seed=2, lora_targets=_tiny_targets(), std=0.05)
     model = SAM2Model(HIERA_T, 1024, dtype="f32", use_refinement=True).load_params(p)
@@ -637,30 +651,31 @@ def test_infer_masks_boxes_boundary_and_graph_replay():
 
 def test_sam2_box_prompts_hiera_l_f16_match_oracle():
     """BASELINE configs[4] shape at B=1: SAM 2.1 Hiera-L 1024^2 with 32 box prompts per image (the config's prompt count),
-    fp16 operands / f32 streams.  Tolerance: mask logits within 25 % (max) / 4 % (rms) of their standard deviation vs the fp32
-    oracle, binary-mask IoU >= 0.99 over the prompt set."""
+    fp16 operands / f32 streams.  Tolerance (~3x the wrapper test's measured error; the decoder adds little): mask logits within 0.04 (max) /
+    0.008 (rms) of their standard deviation vs the fp32 oracle, binary-mask IoU >= 0.995 over the prompt set."""
     from circuitvision_amd.sam2 import HIERA_L, LORA_TARGETS_REFERENCE
     B, P = 1, 32
     sp, (hi, lo, iou) = _run_boxes(HIERA_L, LORA_TARGETS_REFERENCE, _hiera_l_oracle, 1024, F16, B, P)
     got = sp.low_res.view(B, P, 256, 256).cpu()
-    _assert_logits("Hiera-L f16 32 boxes low-res logits", got, lo, 0.25, 0.04)
+    _assert_logits("Hiera-L f16 32 boxes low-res logits", got, lo, 0.04, 0.008)
     assert float((lo[:, 0] - lo[:, 1]).abs().max()) > 1e-2                          # the prompts do change the masks
     a, b = sp.high_res.view(B, P, 1024, 1024).cpu() > 0, hi > 0
     inter_, union = (a & b).sum().item(), (a | b).sum().item()
-    assert union == 0 or inter_ / union >= 0.99
-    torch.testing.assert_close(sp.iou.view(B, P).cpu(), iou, rtol=0, atol=2e-2)
+    print(f"Hiera-L f16 32 boxes: binary-mask IoU vs the fp32 oracle {inter_ / max(1, union):.4f}")
+    assert union == 0 or inter_ / union >= 0.995
+    torch.testing.assert_close(sp.iou.view(B, P).cpu(), iou, rtol=0, atol=1e-2)
 
 
 def test_sam2_box_prompts_hiera_l_bf16_match_oracle():
     """BASELINE configs[4] as named -- SAM 2.1 Hiera-L 1024^2, 32 box prompts per image, **bf16** operands -- at B = 1: the bf16 build of the
     box decoder (layer-0 sharing through the attention batch divisors, cvmi_repeat_images, res_rep broadcast residuals, prompt tokens) vs
-    the fp32 oracle.  Tolerance = the bf16 wrapper test's: mask logits within 0.25 std (max) / 0.05 std (rms), binary-mask IoU over the
-    prompt set >= 0.985 (8 mantissa bits: measured value printed), predicted IoU within 5e-2."""
+    the fp32 oracle.  Tolerance = the bf16 wrapper test's x 1.5 (32 small masks): mask logits within 0.18 std (max) / 0.04 std (rms), binary-mask
+    IoU over the prompt set >= 0.985 (8 mantissa bits: measured value printed), predicted IoU within 5e-2."""
     from circuitvision_amd.sam2 import HIERA_L, LORA_TARGETS_REFERENCE
     B, P = 1, 32
     sp, (hi, lo, iou) = _run_boxes(HIERA_L, LORA_TARGETS_REFERENCE, _hiera_l_oracle, 1024, BF16, B, P)
     got = sp.low_res.view(B, P, 256, 256).cpu()
-    _assert_logits("Hiera-L bf16 32 boxes low-res logits", got, lo, 0.25, 0.05)
+    _assert_logits("Hiera-L bf16 32 boxes low-res logits", got, lo, 0.18, 0.04)
     a, b = sp.high_res.view(B, P, 1024, 1024).cpu() > 0, hi > 0
     inter_, union = (a & b).sum().item(), (a | b).sum().item()
     print(f"Hiera-L bf16 32 boxes: binary-mask IoU vs the fp32 oracle {inter_ / max(1, union):.4f}")
@@ -687,15 +702,16 @@ def test_wrapper_graph_replay_with_new_images():
         torch.testing.assert_close(hi.cpu(), rhi, rtol=1e-3, atol=1e-3)
 
 
-def test_sam2_hiera_l_baseline_size_permutation_and_replay_properties():
-    """BASELINE configs[2] at full size (SAM 2.1 Hiera-L, 16 x 1024 x 1024, fp16 / f32 streams, captured graph):
-    permuting the batch permutes every output bit-exactly (per-image independence of every kernel, including the
+@pytest.mark.parametrize("B", [16, 8])
+def test_sam2_hiera_l_baseline_size_permutation_and_replay_properties(B):
+    """BASELINE configs[2] at full size (SAM 2.1 Hiera-L, 16 x 1024 x 1024, fp16 / f32 streams, captured graph) and at ONE RANK'S SHARE of
+    configs[3] (8 images: 64 images over 8 GPUs -- other tile shapes: row blocks shared between workgroups in tok_linear16, fc2 off the
+    persistent kernel): permuting the batch permutes every output bit-exactly (per-image independence of every kernel, including the
     counted-DMA GEMMs, the 64-key-tile / 16-token-window attention kernels and the stability counters); replays are
     bit-identical; all outputs finite; iou predictions inside (0, 1)."""
     from circuitvision_amd.sam2 import HIERA_L, LORA_TARGETS_REFERENCE, Sam2Plan, Sam2Weights, SamSyntheticParams
     from synth import circuit_image
     lib = _lib.load()
-    B = 16
     wt = Sam2Weights(SamSyntheticParams(seed=0, lora_targets=LORA_TARGETS_REFERENCE), HIERA_L, 1024, F16)
     st = torch.cuda.Stream()
     sp = Sam2Plan(wt, B, st)
@@ -718,6 +734,88 @@ def test_sam2_hiera_l_baseline_size_permutation_and_replay_properties():
     assert torch.isfinite(l0).all() and torch.isfinite(h0).all()
     assert float(i0.min()) > 0.0 and float(i0.max()) < 1.0
     assert float((l0[0] - l0[1]).abs().max()) > 1e-3               # different images do give different masks
+    if B == 8:
+        # the same 8 images inside a batch of 16 (other launch shapes, other summation orders of the LayerNorm statistics): not bit-identical,
+        # but the same masks -- logits within 2e-2 std, every binary mask IoU >= 0.999
+        sp16 = Sam2Plan(wt, 16, st)
+        sp16.x_in.t[:8].copy_(xs); sp16.x_in.t[8:].copy_(xs)
+        torch.cuda.synchronize()
+        sp16.plan.run()
+        torch.cuda.synchronize()
+        assert torch.equal(sp16.low_res[:8], sp16.low_res[8:])
+        _assert_logits("Hiera-L f16, 8 images alone vs inside a batch of 16", l0.cpu(), sp16.low_res[:8].cpu(), 0.02, 0.004)
+        a, b = h0 > 0, sp16.high_res[:8] > 0
+        ious = ((a & b).flatten(1).sum(1).float() / (a | b).flatten(1).sum(1).clamp(min=1).float())
+        assert float(ious.min()) >= 0.999, ious.tolist()
+
+
+@pytest.mark.parametrize("attn", ["16", "fp8"])
+def test_sam2_configs4_full_size_box_prompt_properties(attn):
+    """BASELINE configs[4] at one GPU's share, full size: SAM 2.1 Hiera-L, 16 images x 32 box prompts, bf16 operands, 16-bit and fp8 AV
+    attention (captured graph, 512 (image, prompt) pairs).  Size-independent properties: replays are bit-identical; permuting the IMAGES
+    (with their prompts) permutes every output bit-exactly; permuting the 32 PROMPTS of each image permutes that image's masks bit-exactly
+    (a prompt's mask does not depend on its neighbours -- layer 0 of the decoder is shared per image, the rest per pair); all logits finite,
+    predicted IoUs inside (0, 1); different prompts give different masks."""
+    from circuitvision_amd.sam2 import HIERA_L, LORA_TARGETS_REFERENCE, Sam2Plan, Sam2Weights, SamSyntheticParams
+    from synth import circuit_image
+    lib = _lib.load()
+    B, P = 16, 32
+    wt = Sam2Weights(SamSyntheticParams(seed=0, lora_targets=LORA_TARGETS_REFERENCE), HIERA_L, 1024, BF16)
+    st = torch.cuda.Stream()
+    sp = Sam2Plan(wt, B, st, prompts=P, high_res=False, attn=attn)
+    xs = torch.empty(B, 1024, 1024, 3, dtype=torch.bfloat16, device="cuda")
+    for b in range(B):
+        img = torch.from_numpy(circuit_image(600 + 20 * b, 800, seed=40 + b)).cuda()
+        _lib.check(lib.cvmi_sam2_transform(img.data_ptr(), img.shape[0], img.shape[1], xs[b].data_ptr(), 1024, BF16, None), "transform")
+    boxes = _boxes(B, P, 1024, seed=9).cuda()
+    torch.cuda.synchronize()
+    g = torch.Generator().manual_seed(6)
+    perm_b = torch.randperm(B, generator=g).cuda()
+    perm_p = torch.stack([torch.randperm(P, generator=g) for _ in range(B)]).cuda()
+    bx_pp = torch.gather(boxes, 1, perm_p[:, :, None].expand(B, P, 4))
+    outs = []
+    for inp, bx in ((xs, boxes), (xs[perm_b], boxes[perm_b]), (xs, bx_pp), (xs, boxes)):
+        sp.x_in.t.copy_(inp)
+        sp.coords[:, :2].copy_(bx.reshape(B * P, 2, 2))
+        sp.labels.copy_(torch.tensor([2, 3, -1], dtype=torch.int32).expand(B * P, 3))
+        torch.cuda.synchronize()
+        sp.plan.run()
+        torch.cuda.synchronize()
+        outs.append((sp.low_res.view(B, P, 256, 256).clone(), sp.iou.view(B, P).clone()))
+    (l0, i0), (l1, i1), (l2, i2), (l3, i3) = outs
+    assert torch.equal(l0, l3) and torch.equal(i0, i3), "replay"
+    assert torch.equal(l0[perm_b], l1) and torch.equal(i0[perm_b], i1), "image permutation"
+    assert torch.equal(torch.gather(l0, 1, perm_p[:, :, None, None].expand(B, P, 256, 256)), l2) and torch.equal(torch.gather(i0, 1, perm_p), i2), "prompt permutation"
+    assert torch.isfinite(l0).all() and float(i0.min()) > 0.0 and float(i0.max()) < 1.0
+    assert float((l0[:, 0] - l0[:, 1]).abs().amax()) > 1e-2 and float((l0[0] - l0[1]).abs().max()) > 1e-2
+
+
+HIERA_L_WIDTH = dict(embed_dim=144, num_heads=2, stages=(1, 1, 3, 1), global_att_blocks=(3,), window_spec=(8, 4, 16, 8))
+
+
+def test_sam2_hiera_l_width_f32_matches_oracle_at_1e3():
+    """The north_star's 1e-3 bound at the HEADLINE width and resolution: a trunk with Hiera-L's widths, head counts, windows and grids
+    (1024^2 input; stage 3 = 576 channels, 8 heads of 72, 64 x 64 tokens, one q-pooled block, one 16 x 16-window block (256 keys), one global
+    block over 4096 keys; stage 4 = 1152) but 6 blocks instead of 48, in f32 mode (exact-f32 MFMA GEMMs, f32 attention) vs the fp32 oracle:
+    neck features, low-res / high-res mask logits and the IoU prediction within 1e-3 absolute.  (The full-depth f32 comparison is the
+    Hiera-T test; the full-depth Hiera-L comparisons run the 16-bit kernel set, with tolerances in units of the logits' std.)"""
+    from circuitvision_amd.sam2 import LORA_TARGETS_REFERENCE
+    targets = [t for t in LORA_TARGETS_REFERENCE if ".trunk." not in t] + [f"image_encoder.trunk.blocks.{i}.attn.qkv" for i in (2, 3, 4)] + \
+              ["image_encoder.trunk.blocks.3.mlp.layers.0", "image_encoder.trunk.blocks.4.proj"]
+
+    def oracle_fn(p):
+        core = osam.SAM2Core(HIERA_L_WIDTH, lora=True, lora_trunk={2: ("attn.qkv",), 3: ("attn.qkv", "mlp.layers.0"), 4: ("attn.qkv", "proj")}, image_size=1024)
+        w = osam.SAM2ImageWrapper(core).eval()
+        w.load_state_dict({("sam2_model." + k if not (k.startswith("dense_") or k.startswith("sparse_") or k.startswith("refinement_")) else k): v
+                           for k, v in p.state_dict().items()}, strict=True)
+        return w
+    sp, (hi, lo, iou, inter) = _run_wrapper(HIERA_L_WIDTH, targets, oracle_fn, 1024, F32, B=1)
+    for name, buf, ref in (("feat_s0", sp.feat_s0, inter["s0"]), ("feat_s1", sp.feat_s1, inter["s1"])):
+        torch.testing.assert_close(buf.t.float().permute(0, 3, 1, 2).cpu(), ref, rtol=0, atol=1e-3, msg=lambda m: f"{name}: {m}")
+    print(f"Hiera-L width f32: max |low-res logit - oracle| {float((sp.low_res.cpu() - lo).abs().max()):.2e}, logits std {float(lo.std()):.3f}")
+    torch.testing.assert_close(sp.low_res.cpu(), lo, rtol=0, atol=1e-3)
+    torch.testing.assert_close(sp.high_res.cpu(), hi, rtol=0, atol=1e-3)
+    torch.testing.assert_close(sp.iou.cpu(), iou, rtol=0, atol=1e-3)
 
 
 def test_mask_extent_matches_bounding_rect_of_nonzero_pixels():

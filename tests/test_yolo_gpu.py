@@ -175,9 +175,10 @@ def _match_detections(name, plan, ref_det, ref_idx, exact, pred=None):
 
 
 # (dtype, scale, B, H, W): the small shape for every (mode, scale) incl. YOLO11-l in fp16 (configs[3]'s detector), and the
-# BASELINE 640 x 640 input for YOLO11-n in both modes
+# BASELINE 640 x 640 input for YOLO11-n and YOLO11-l in both modes
 WHOLE_MODEL_CASES = [(F32, "n", 2, 96, 160), (F16, "n", 2, 96, 160), (F32, "l", 2, 96, 160), (F16, "l", 2, 96, 160),
-                     (F32, "n", 2, 640, 640), (F16, "n", 2, 640, 640)]
+                     (F32, "n", 2, 640, 640), (F16, "n", 2, 640, 640),
+                     (F32, "l", 2, 640, 640), (F16, "l", 2, 640, 640)]          # the detector the reference ships (app.py:89) at the BASELINE input size
 
 
 @pytest.mark.parametrize("dtype,scale,B,H,W", WHOLE_MODEL_CASES)
