@@ -5,6 +5,7 @@ kernel launches over pre-allocated buffers for one input shape; it runs either l
 (parity tests, per-kernel timing) or as one captured HIP graph (throughput path).
 """
 import ctypes as C
+import os
 import threading
 
 import torch
@@ -212,11 +213,22 @@ class Plan:
         return [(l, k, e0.elapsed_time(e1), b, f) for l, k, e0, e1, b, f, _ in evs]
 
     def __del__(self):
+        # A captured graph WITH side lanes is never destroyed.  Measured on this runtime (ROCm 7.2, r04): hipGraphExecDestroy of one
+        # multi-branch graph leaves ANOTHER multi-branch graph exec with dangling parallel-stream pointers -- its next hipGraphLaunch
+        # dies in hip::Graph::UpdateStreams (rocgdb backtrace; order-dependent: a detector plan collected between two tests killed a
+        # later detector's replay).  Linear graphs (no internal streams) are destroyed as before; the others are parked until the
+        # process exits -- a few KB each, one per (model, input shape).
         try:
             if self.graph is not None:
-                _lib.load().cvmi_graph_destroy(self.graph)
+                if self._lane_streams or os.environ.get("CVMI_KEEP_GRAPHS") == "1":
+                    _PARKED_GRAPHS.append((self.graph, self._lane_streams))
+                else:
+                    _lib.load().cvmi_graph_destroy(self.graph)
         except Exception:
             pass
+
+
+_PARKED_GRAPHS = []
 
 
 # ---- op wrappers (each appends one launch to a plan) --------------------------------------------

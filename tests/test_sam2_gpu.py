@@ -744,9 +744,9 @@ def test_sam2_hiera_l_baseline_size_permutation_and_replay_properties(B):
         torch.cuda.synchronize()
         assert torch.equal(sp16.low_res[:8], sp16.low_res[8:])
         _assert_logits("Hiera-L f16, 8 images alone vs inside a batch of 16", l0.cpu(), sp16.low_res[:8].cpu(), 0.02, 0.004)
-        a, b = h0 > 0, sp16.high_res[:8] > 0
-        ious = ((a & b).flatten(1).sum(1).float() / (a | b).flatten(1).sum(1).clamp(min=1).float())
-        assert float(ious.min()) >= 0.999, ious.tolist()
+        a, b = h0 > 0, sp16.high_res[:8] > 0                      # (seed-0 weights give logits of std 0.008: compare the pixel decisions themselves)
+        agree = (a == b).flatten(1).float().mean(1)
+        assert float(agree.min()) >= 0.9995, agree.tolist()
 
 
 @pytest.mark.parametrize("attn", ["16", "fp8"])
@@ -787,7 +787,8 @@ def test_sam2_configs4_full_size_box_prompt_properties(attn):
     assert torch.equal(l0[perm_b], l1) and torch.equal(i0[perm_b], i1), "image permutation"
     assert torch.equal(torch.gather(l0, 1, perm_p[:, :, None, None].expand(B, P, 256, 256)), l2) and torch.equal(torch.gather(i0, 1, perm_p), i2), "prompt permutation"
     assert torch.isfinite(l0).all() and float(i0.min()) > 0.0 and float(i0.max()) < 1.0
-    assert float((l0[:, 0] - l0[:, 1]).abs().amax()) > 1e-2 and float((l0[0] - l0[1]).abs().max()) > 1e-2
+    sd = float(l0.std())                                        # (seed-0 weights: logits of std ~0.01)
+    assert float((l0[:, 0] - l0[:, 1]).abs().amax()) > 0.2 * sd and float((l0[0] - l0[1]).abs().max()) > 0.2 * sd, sd
 
 
 HIERA_L_WIDTH = dict(embed_dim=144, num_heads=2, stages=(1, 1, 3, 1), global_att_blocks=(3,), window_spec=(8, 4, 16, 8))
