@@ -20,28 +20,34 @@
 // C = 144 (stage 1): 8 waves / workgroup, two waves per SIMD (the GELU VALU of one overlaps the MFMAs of the other).
 // C = 288 (stage 2): the Y^T accumulator (144 registers) + Xn (76) leave room for one wave per SIMD only: 4 waves.
 #include "common.hpp"
+#include <stdlib.h>
 
 namespace {
 
-template <int C> struct MlpCfg {
+// VAR bit 0: 4-wave workgroups, two waves per SIMD coming from two INDEPENDENT workgroups (C = 144: instead of one 8-wave workgroup; C = 288:
+// instead of one wave per SIMD, at 256 registers with ~20 spilled).  SLOTS: depth of the weight ring.  Both measured in r04 (profiles/r04_ab_runs.md).
+template <int C, int VAR = 0, int SLOTS_ = 2> struct MlpCfg {
   static constexpr int KS = C / 16;                 // k-steps of fc1
   static constexpr int KS1 = KS + 1;                // + the bias step
   static constexpr int NT = (C + 31) / 32;          // 32-channel output tiles of fc2
   static constexpr int NCH = 4 * C / 32;            // hidden chunks
   static constexpr int FR = KS1 + 2 * NT;           // 1 KiB fragments per chunk
   static constexpr int CHB = FR * 1024;             // bytes per chunk
-  static constexpr int NW = C <= 144 ? 8 : 4;       // waves per workgroup
-  static constexpr int WPS = C <= 144 ? 2 : 1;      // waves per SIMD the register budget is set for
-  static constexpr int LDS = 2 * CHB;
+  static constexpr int NW = VAR == 1 ? 4 : (C <= 144 ? 8 : 4);       // waves per workgroup
+  static constexpr int WPS = VAR == 1 ? 2 : (C <= 144 ? 2 : 1);      // waves per SIMD the register budget is set for
+  static constexpr int SLOTS = SLOTS_;
+  static constexpr int CNT = (FR + NW - 1) / NW;    // LDS-DMA instructions every wave issues per chunk (the same count in every wave: counted waits)
+  static constexpr int LDS = SLOTS * CHB + 1024;    // + a dump piece for the padding instructions of the waves with fewer real pieces
 };
 
-template <int C>
-__global__ __launch_bounds__(MlpCfg<C>::NW * 64, MlpCfg<C>::WPS) void hiera_mlp_kernel(float* __restrict__ x, int x_ld, const float* __restrict__ gamma,
+template <int C, int VAR = 0, int SLOTS = 2>
+__global__ __launch_bounds__((MlpCfg<C, VAR, SLOTS>::NW * 64), (MlpCfg<C, VAR, SLOTS>::WPS)) void hiera_mlp_kernel(float* __restrict__ x, int x_ld, const float* __restrict__ gamma,
                                                                                       const float* __restrict__ beta, float eps,
                                                                                       const char* __restrict__ wp, const float* __restrict__ b2,
                                                                                       long long rows, float* __restrict__ stats_out, float stats_eps) {
-  using Cfg = MlpCfg<C>;
-  constexpr int KS = Cfg::KS, KS1 = Cfg::KS1, NT = Cfg::NT, NCH = Cfg::NCH, FR = Cfg::FR, CHB = Cfg::CHB, NW = Cfg::NW;
+  using Cfg = MlpCfg<C, VAR, SLOTS>;
+  constexpr int KS = Cfg::KS, KS1 = Cfg::KS1, NT = Cfg::NT, NCH = Cfg::NCH, FR = Cfg::FR, CHB = Cfg::CHB, NW = Cfg::NW, CNT = Cfg::CNT;
+  static_assert(SLOTS == 2 || SLOTS == 3, "ring depth");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int lr = lane & 31, lh = lane >> 5;
@@ -49,19 +55,21 @@ __global__ __launch_bounds__(MlpCfg<C>::NW * 64, MlpCfg<C>::WPS) void hiera_mlp_
   const bool row_ok = row_raw < rows;
   float* const xr = x + (row_ok ? row_raw : rows - 1) * (long long)x_ld;
 
-  // ---- weight stream: chunk j -> ring slot j & 1; wave w moves fragments w, w + NW, ...
+  // ---- weight stream: chunk j -> ring slot j % SLOTS; wave w moves fragments w, w + NW, ...  Every wave issues exactly CNT instructions per
+  // chunk (a wave without a last real piece re-loads piece 0 into the dump area behind the ring), so that one immediate vmcnt count fits all.
   auto issue_chunk = [&](int j) {
     const char* src = wp + (size_t)j * CHB + lane * 16;
-    char* dst = smem + (j & 1) * CHB;
+    char* dst = smem + (j % SLOTS) * CHB;
 #pragma unroll
-    for (int f = 0; f < (FR + NW - 1) / NW; ++f) {
+    for (int f = 0; f < CNT; ++f) {
       const int fi = f * NW + wv;
-      if (fi < FR)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)fi * 1024),
-                                         (__attribute__((address_space(3))) void*)(dst + fi * 1024), 16, 0, 0);
+      const bool real = fi < FR;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)(real ? fi : 0) * 1024),
+                                       (__attribute__((address_space(3))) void*)(real ? dst + fi * 1024 : smem + SLOTS * CHB), 16, 0, 0);
     }
   };
-  issue_chunk(0);
+#pragma unroll
+  for (int j = 0; j < SLOTS - 1; ++j) issue_chunk(j);
 
   // ---- LayerNorm of this lane's half row -> B fragments of fc1 (lane (token lr, half lh) holds channels 16 s + 8 lh .. + 7)
   u32x4 xn[KS1];
@@ -113,10 +121,14 @@ __global__ __launch_bounds__(MlpCfg<C>::NW * 64, MlpCfg<C>::WPS) void hiera_mlp_
     // Every wave waits for its OWN DMA pieces (hipcc puts no vmcnt wait in front of a barrier for LDS-DMA writes: without this
     // explicit wait the chunk is read before it has landed -- rare, load-dependent wrong results), then the barrier publishes
     // chunk j to the workgroup and retires the reads of slot (j + 1) & 1.
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // Ring of SLOTS chunks: chunk j + SLOTS - 1 is issued here, after the barrier that retires the reads of chunk j - 1 (its slot); with three
+    // slots a chunk has TWO chunk times to land (measured r04: with two slots and one wave per SIMD the loop waited ~1600 of ~2800 cycles per
+    // chunk on this wait), and the wait counts: all but the youngest chunk's CNT instructions of this wave.
+    if (SLOTS == 2 || j == NCH - 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CNT) : "memory");
     __syncthreads();
-    if (j + 1 < NCH) issue_chunk(j + 1);
-    const char* const buf = smem + (j & 1) * CHB + lane * 16;
+    if (j + SLOTS - 1 < NCH) issue_chunk(j + SLOTS - 1);
+    const char* const buf = smem + (j % SLOTS) * CHB + lane * 16;
     // The chunk's FR operand fragments are consumed in one fixed order (fc1's KS1, then fc2's 2 NT); a ring of PF registers
     // keeps PF ds_read_b128 in flight ahead of the MFMA that consumes them -- across the GELU as well, so that fc2's first
     // operands arrive while the VALU works.  (Left to itself hipcc emits read -> lgkmcnt(0) -> MFMA per step.)
@@ -197,15 +209,15 @@ __global__ __launch_bounds__(MlpCfg<C>::NW * 64, MlpCfg<C>::WPS) void hiera_mlp_
   }
 }
 
-template <int C>
+template <int C, int VAR = 0, int SLOTS = 2>
 int launch_mlp(float* x, int x_ld, const float* gamma, const float* beta, float eps, const void* wp, const float* b2, long long rows, hipStream_t s,
                float* stats_out, float stats_eps) {
-  using Cfg = MlpCfg<C>;
-  static hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&hiera_mlp_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
+  using Cfg = MlpCfg<C, VAR, SLOTS>;
+  static hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&hiera_mlp_kernel<C, VAR, SLOTS>), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
   CVMI_HIP(attr);
   const long long per = (long long)Cfg::NW * 32;
-  cvmi_note_kernel("hiera_mlp_kernel<%d>", C);
-  hipLaunchKernelGGL((hiera_mlp_kernel<C>), dim3((unsigned)((rows + per - 1) / per)), dim3(Cfg::NW * 64), Cfg::LDS, s, x, x_ld, gamma, beta, eps,
+  cvmi_note_kernel("hiera_mlp_kernel<%d, %d, %d>", C, VAR, SLOTS);
+  hipLaunchKernelGGL((hiera_mlp_kernel<C, VAR, SLOTS>), dim3((unsigned)((rows + per - 1) / per)), dim3(Cfg::NW * 64), Cfg::LDS, s, x, x_ld, gamma, beta, eps,
                      (const char*)wp, b2, rows, stats_out, stats_eps);
   CVMI_LAUNCH_CHECK();
   return 0;
@@ -242,8 +254,20 @@ extern "C" int CVMI_ENTRY(cvmi_hiera_mlp_stats)(void* x, int x_ld, const float* 
              "hiera_mlp: pointers / ld must be 16-byte aligned");
   hipStream_t s = (hipStream_t)stream_;
   float* xf = (float*)x;
-  if (C == 144) return launch_mlp<144>(xf, x_ld, gamma, beta, eps, w_packed, b2, rows, s, ln_stats_out, ln_stats_eps);
-  return launch_mlp<288>(xf, x_ld, gamma, beta, eps, w_packed, b2, rows, s, ln_stats_out, ln_stats_eps);
+  // A/B switches (measured r04, profiles/r04_ab_runs.md): CVMI_MLP_VAR bit 0 -> C = 144, bit 1 -> C = 288 in 4-wave workgroups at two waves per
+  // SIMD; CVMI_MLP_SLOTS = 2 | 3, the ring depth
+  static const int var = getenv("CVMI_MLP_VAR") ? atoi(getenv("CVMI_MLP_VAR")) : 1;
+  static const int slots = getenv("CVMI_MLP_SLOTS") ? atoi(getenv("CVMI_MLP_SLOTS")) : 2;
+#define CVMI_MLP_GO(CC, VV, SS) return launch_mlp<CC, VV, SS>(xf, x_ld, gamma, beta, eps, w_packed, b2, rows, s, ln_stats_out, ln_stats_eps)
+  if (C == 144) {
+    if (var & 1) { if (slots == 3) CVMI_MLP_GO(144, 1, 3); CVMI_MLP_GO(144, 1, 2); }
+    if (slots == 3) CVMI_MLP_GO(144, 0, 3);
+    CVMI_MLP_GO(144, 0, 2);
+  }
+  if (var & 2) CVMI_MLP_GO(288, 1, 2);                  // (two workgroups per CU leave room for two slots of 37 KiB each only)
+  if (slots == 3) CVMI_MLP_GO(288, 0, 3);
+  CVMI_MLP_GO(288, 0, 2);
+#undef CVMI_MLP_GO
 }
 
 extern "C" int CVMI_ENTRY(cvmi_hiera_mlp)(void* x, int x_ld, const float* gamma, const float* beta, float eps, const void* w_packed, const float* b2,
