@@ -132,18 +132,26 @@ def crop_window(bboxes, image_hw, padding=20):
     return win, info
 
 
+def _copy_box(b):
+    """deepcopy(b) as the reference takes it (:1257), without its cost on the flat dicts bboxes() builds (strings and numbers only)."""
+    for v in b.values():
+        if isinstance(v, (list, dict, set, tuple, np.ndarray)):
+            return deepcopy(b)
+    return dict(b)
+
+
 def adjust_bboxes(bboxes, window):
     """:1256-1277: every box in the window's coordinates, clipped to it; a box with no positive area left is dropped.  Copies (the
     persistent_uid travels with them)."""
     if window is None:
-        return [deepcopy(b) for b in bboxes]
+        return [_copy_box(b) for b in bboxes]
     x0, y0, x1, y1 = window
     w, h = x1 - x0, y1 - y0
     out = []
     for b in bboxes:
         nx0, ny0, nx1, ny1 = max(0, b["xmin"] - x0), max(0, b["ymin"] - y0), min(w, b["xmax"] - x0), min(h, b["ymax"] - y0)
         if nx1 > nx0 and ny1 > ny0:
-            nb = deepcopy(b)
+            nb = _copy_box(b)
             nb["xmin"], nb["ymin"], nb["xmax"], nb["ymax"] = nx0, ny0, nx1, ny1
             out.append(nb)
     return out

@@ -304,12 +304,32 @@ def calculate_iou(b1, b2):
 
 
 def non_max_suppression_by_confidence(bboxes, iou_threshold=0.5):
-    """Host-side mirror of utils.py:346-361 (<= 300 integer boxes; stays on the CPU in the
-    reference too -- the caller, analysis_pipeline.py:106, is untouched and keeps using its own)."""
-    rest = sorted(bboxes, key=lambda b: b["confidence"], reverse=True)
+    """Host-side mirror of utils.py:346-361 (<= 300 boxes; stays on the CPU in the reference too -- the caller, analysis_pipeline.py:106, is
+    untouched and keeps using its own).  Same greedy pass -- most confident first (a STABLE descending sort: equal confidences keep their list
+    order), a box survives iff its IoU with every kept box is < iou_threshold -- with the inner "filter the rest" step over numpy float64 arrays
+    (the reference's Python loop is O(n^2) dict look-ups: 20 ms for the 200 boxes of a busy schematic, 1.7 ms for 60).  Integer pixel boxes are
+    exact in float64 and the operations are the reference's in the reference's order (`calculate_iou` above), so the kept list is identical --
+    pinned by tests/golden/nms_stage2.json, incl. ties, IoU == threshold and zero-area boxes."""
+    n = len(bboxes)
+    if n == 0:
+        return []
+    conf = np.array([b["confidence"] for b in bboxes], dtype=np.float64)
+    order = np.argsort(-conf, kind="stable")
+    xy = np.array([[b["xmin"], b["ymin"], b["xmax"], b["ymax"]] for b in bboxes], dtype=np.float64)[order]
+    area = (xy[:, 2] - xy[:, 0]) * (xy[:, 3] - xy[:, 1])
+    alive = np.ones(n, dtype=bool)
     kept = []
-    while rest:
-        top = rest.pop(0)
-        kept.append(top)
-        rest = [b for b in rest if calculate_iou(top, b) < iou_threshold]
+    for i in range(n):
+        if not alive[i]:
+            continue
+        kept.append(bboxes[int(order[i])])
+        r = np.flatnonzero(alive[i + 1:]) + i + 1
+        if r.size == 0:
+            break
+        iw = np.maximum(np.minimum(xy[i, 2], xy[r, 2]) - np.maximum(xy[i, 0], xy[r, 0]), 0)
+        ih = np.maximum(np.minimum(xy[i, 3], xy[r, 3]) - np.maximum(xy[i, 1], xy[r, 1]), 0)
+        inter = iw * ih
+        union = (area[i] + area[r]) - inter
+        iou = np.divide(inter, union, out=np.zeros_like(inter), where=union > 0)
+        alive[r[~(iou < iou_threshold)]] = False
     return kept
