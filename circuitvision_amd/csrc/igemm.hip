@@ -1886,7 +1886,10 @@ int launch_typed(ConvKArgs& a, hipStream_t stream) {
       const long long tiles192 = (long long)cdiv(M, 256) * cdiv(N, 192);
       // (measured: K = 2304 309 -> 226 us; at K = 576 the 128 x 64 kernel's two workgroups per CU hide the f32 + residual epilogue better)
       static const int g192_mink = getenv("CVMI_G192_MINK") ? atoi(getenv("CVMI_G192_MINK")) : 1024;   // tuning experiments only
-      if (use_g192 && N % 192 == 0 && a.K >= g192_mink && tiles192 >= 256 && (double)tiles192 / (double)(cdiv(tiles192, 256) * 256) >= 0.8)
+      // (the last round of tiles at least 3/4 used: 384 tiles -- SAM 2.1-L stage-3 fc2 at 8 images, one rank's share of an 8-GPU job -- run 119 us
+      //  here against 140 us on the 128 x 64 kernel, r04; the 128 x 192 variant of that kernel: 145 us)
+      static const double g192_eff = getenv("CVMI_G192_EFF") ? atof(getenv("CVMI_G192_EFF")) : 0.75;     // tuning experiments only
+      if (use_g192 && N % 192 == 0 && a.K >= g192_mink && tiles192 >= 256 && (double)tiles192 / (double)(cdiv(tiles192, 256) * 256) >= g192_eff)
         return launch_g256x192<TO>(a, stream);
     }
   }
@@ -1896,6 +1899,10 @@ int launch_typed(ConvKArgs& a, hipStream_t stream) {
   if (use_glds && (a.plain || a.rows2) && a.K % (16 / (int)sizeof(T)) == 0 && (a.Kpad * (int)sizeof(T)) % 128 == 0 && a.K * (int)sizeof(T) >= 256 &&
       ((a.K * (int)sizeof(T)) % 128 == 0 || a.K >= 256) && N >= (a.rows2 ? 64 : 96) &&
       (long long)cdiv(M, 128) * cdiv(N, 128) >= glds_min_tiles) {                      // large GEMMs only: small grids need the smaller tiles below
+    static const int glds_bn = getenv("CVMI_GLDS_BN") ? atoi(getenv("CVMI_GLDS_BN")) : 0;      // tuning experiments only
+    if constexpr (sizeof(T) == 2 && sizeof(TO) == 4) {
+      if (glds_bn == 192 && N % 192 == 0 && a.plain) return launch_glds<T, TO, 128, 192, 4, 2>(a, stream);
+    }
     if (use_glds == 2 || N <= 640) return launch_glds<T, TO, 128, 64, 2, 2>(a, stream);      // measured: wins up to N = 576
     return launch_glds<T, TO, 128, 128, 2, 2>(a, stream);
   }

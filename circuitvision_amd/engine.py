@@ -235,14 +235,14 @@ _PARKED_GRAPHS = []
 def row_stats_supported(M, N, K):
     """True when cvmi_conv2d sends a plain 16-bit GEMM [M, K] x [K, N] with f32 output + residual to the 256 x 192 kernel, the one that can write
     cvmi_conv_desc.row_stats (mirrors launch_typed in igemm.hip: N a multiple of 192 that 256-wide tiles would waste, K >= 1024, at least one
-    tile per CU and >= 80 % of the last round of tiles used)."""
+    tile per CU and >= 75 % of the last round of tiles used)."""
     if N % 192 or N < 384 or K < 1024 or K % 64:
         return False
     t256 = -(-M // 256) * -(-N // 256)
     if t256 >= 256 and N / (-(-N // 256) * 256) >= 0.8 and t256 / (-(-t256 // 256) * 256) >= 0.8:
         return False                                  # the 256 x 256 kernel takes it
     t192 = -(-M // 256) * (N // 192)
-    return t192 >= 256 and t192 / (-(-t192 // 256) * 256) >= 0.8
+    return t192 >= 256 and t192 / (-(-t192 // 256) * 256) >= 0.75
 
 
 def op_conv(plan, label, pc, srcs, dst, stride=1, pad=None, act=_lib.ACT_NONE, res=None, out_hw=None,

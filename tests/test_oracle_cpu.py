@@ -168,10 +168,11 @@ def test_product_fails_loudly_without_gpu():
 def test_row_stats_predicate_mirrors_the_gemm_dispatch():
     """`engine.row_stats_supported` decides on the host whether cvmi_conv2d will take the 256 x 192 GEMM -- the only kernel that writes
     cvmi_conv_desc.row_stats (LayerNorm statistics for the next launch).  It must say yes exactly for shapes igemm.hip::launch_typed sends
-    there: N a multiple of 192 that 256-wide tiles would waste, K >= 1024, >= 256 tiles with >= 80 % of the last round used."""
+    there: N a multiple of 192 that 256-wide tiles would waste, K >= 1024, >= 256 tiles with >= 75 % of the last round used."""
     from circuitvision_amd.engine import row_stats_supported as ok
     assert ok(65536, 576, 2304)                  # Hiera-L stage-3 fc2 at B = 16: 256 x 3 tiles
-    assert not ok(32768, 576, 2304)              # B = 8: 384 tiles = 75 % of the second round -> the 128-row kernels take it
+    assert ok(32768, 576, 2304)                  # B = 8 (one rank's share of configs[3]): 384 tiles = 75 % of two rounds (r04: 119 us against 140 on the 128-row kernel)
+    assert not ok(24576, 576, 2304)              # B = 6: 288 tiles = 56 % of two rounds -> the 128-row kernels take it
     assert not ok(8192, 576, 2304)               # B = 2: 96 tiles, less than one per CU
     assert not ok(65536, 1152, 4608)             # stage 4: 1152 = 4.5 x 256, 90 % column use -> the 256 x 256 kernel
     assert not ok(65536, 576, 576)               # K below the 256 x 192 kernel's threshold
