@@ -33,15 +33,17 @@ from .distributed import gather_rows, shard_range
 
 
 def results_to_bboxes(r):
-    """circuit_analyzer.py:267-287 on one `Results`: lists via .cpu().numpy().tolist(), python round() (half-to-even), uid string."""
+    """circuit_analyzer.py:267-287 on one `Results`: lists via .cpu().numpy().tolist(), python round() (half-to-even), uid string.
+    (The four `round()` per box run as ONE np.rint over the float64 copy of the coordinates: the same half-to-even rounding of the same doubles.)"""
     ids = r.boxes.cls.cpu().numpy().tolist()
-    names = [r.names[int(i)] for i in ids]
     conf = r.boxes.conf.cpu().numpy().tolist()
+    xy = np.rint(r.boxes.xyxy.cpu().numpy().astype(np.float64)).astype(np.int64).tolist()
+    names = r.names
     out = []
-    for i, (xmin, ymin, xmax, ymax) in enumerate(r.boxes.xyxy.cpu().numpy().tolist()):
-        out.append({"class": names[i], "_yolo_class_id_temp": int(ids[i]), "confidence": conf[i],
-                    "xmin": round(xmin), "ymin": round(ymin), "xmax": round(xmax), "ymax": round(ymax),
-                    "persistent_uid": f"{names[i]}_{round(xmin)}_{round(ymin)}_{round(xmax)}_{round(ymax)}"})
+    for i, (x0, y0, x1, y1) in enumerate(xy):
+        nm = names[int(ids[i])]
+        out.append({"class": nm, "_yolo_class_id_temp": int(ids[i]), "confidence": conf[i], "xmin": x0, "ymin": y0, "xmax": x1, "ymax": y1,
+                    "persistent_uid": f"{nm}_{x0}_{y0}_{x1}_{y1}"})
     return out
 
 
