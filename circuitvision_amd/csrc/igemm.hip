@@ -40,8 +40,12 @@ struct ConvKArgs {
   int per_xcd;                           // gemm256x192r: tiles per XCD
   int diag;                              // gemm256x192r, CVMI_G192_DIAG, timing experiments ONLY (results are wrong): bit 0 = no DMA behind the prologue, bit 1 = no MFMAs, bit 2 = no residual loads
   float* stats;                          // gemm256x192 (f32 out): per row and 96-column slice (mean, sum of squared deviations from it) of the values written, or null
+  int im2col_shift;                      // gemm256_kernel<.., IM2COL = true>: log2(K-tiles of 64 channels per 3 x 3 tap) = log2(Cin / 64)
   FastDiv div_ctot, div_kw;
 };
+
+// 16 zero bytes for every lane of an LDS-DMA instruction whose 3 x 3 tap falls outside the image (gemm256_kernel, IM2COL)
+__device__ __attribute__((aligned(256))) unsigned char cvmi_zero_page[256];
 
 template <typename T> struct Mma;
 template <> struct Mma<f16> {
@@ -648,7 +652,13 @@ int launch_glds(ConvKArgs& a, hipStream_t stream) {
 //   RAW  every wave waits vmcnt before its first barrier of (t,4); readers of (t+1,1) have passed the barrier after it.
 //   WAR  reads are retired (lgkmcnt(0)) BEFORE the phase's first barrier, so a region read in phase p is free once
 //        every wave is past that barrier: any wave issuing phase p+1's DMA is.
-template <typename TO, bool STAGGER>
+// IM2COL (r04): the A operand is a 3 x 3 convolution's im2col matrix instead of a plain row-major one -- YOLO11-l's large stride-2 / stride-1
+// convs (256 - 512 channels; 250 - 375 TFLOP/s on the register-staged 128 x 128 kernel above).  K runs tap-major (k = tap * Cin + c, as the
+// weights are packed), Cin is a power-of-two multiple of 64, so a K-tile of 64 channels lies inside ONE tap: the lane's source row pointer
+// (the output pixel's top-left input pixel, computed once) moves by a wave-uniform tap offset per K-tile, and a lane whose tap falls outside
+// the image (zero padding) points its DMA at 16 zero bytes instead -- one bit test and one select per DMA instruction, nothing else changes:
+// W rows, LDS image, swizzle, phases, counted waits and the epilogue are those of the plain GEMM.
+template <typename TO, bool STAGGER, bool IM2COL = false>
 __global__ __launch_bounds__(512, 1) void gemm256_kernel(const ConvKArgs p) {
   using T = f16;
   constexpr int BM = 256, BN = 256, BKB = 128;
@@ -669,7 +679,7 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(const ConvKArgs p) {
   // DMA sources / LDS destinations: half-tile h (0 XA, 1 WA, 2 WB, 3 XB) = 16 pieces of 8 rows, 2 per wave
   const int nk = (p.K + 63) / 64, krem = p.K & 63;
   const char* src[4][2];
-  int dst[4][2], adj[4][2];
+  int dst[4][2], adj[4][2], vmask[4][2];
 #pragma unroll
   for (int h = 0; h < 4; ++h)
 #pragma unroll
@@ -680,10 +690,22 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(const ConvKArgs p) {
       const int row = row0 + (lane >> 3);
       const int slot = (lane & 7) ^ ((row >> 1) & 7);
       adj[h][i] = 0;
+      vmask[h][i] = 0;
       if (row < BM) {
         int m = m0 + row;
         m = m < p.M ? m : p.M - 1;
         src[h][i] = p.x0 + ((size_t)m * p.x0_ld + slot * 8) * 2;
+        if constexpr (IM2COL) {                              // row m = output pixel (b, oy, ox): pointer to its tap (0, 0) input pixel + which taps exist
+          const int ohow = p.OH * p.OW;
+          const int b = m / ohow, r = m - b * ohow, oy = r / p.OW, ox = r - oy * p.OW;
+          const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
+          src[h][i] = p.x0 + ((((long long)b * p.H + iy0) * p.W + ix0) * p.x0_ld + slot * 8) * 2;
+          int vm = 0;
+#pragma unroll
+          for (int t = 0; t < 9; ++t)
+            if ((unsigned)(iy0 + t / 3) < (unsigned)p.H && (unsigned)(ix0 + t % 3) < (unsigned)p.W) vm |= 1 << t;
+          vmask[h][i] = vm;
+        }
         // K not a multiple of 64: in the LAST K-tile the chunks at columns >= K would leave the pixel row (and, for the
         // last row, the tensor); they re-read the previous tile's chunk instead -- any finite value will do, the weight
         // columns [K, Kpad) are zero
@@ -698,9 +720,18 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(const ConvKArgs p) {
 #define G256_ISSUE(h, stage, kt)                                                                                         \
   do {                                                                                                                   \
     const long long last_ = (kt) == nk - 1 ? 1 : 0;                                                                      \
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[h][0] + (long long)(kt) * BKB + last_ * adj[h][0]), \
+    const char *s0_ = src[h][0] + (long long)(kt) * BKB + last_ * adj[h][0], *s1_ = src[h][1] + (long long)(kt) * BKB + last_ * adj[h][1]; \
+    if (IM2COL && ((h) == 0 || (h) == 3)) {                 /* X half-tiles: tap offset (wave-uniform), zero page outside the image */ \
+      const int tap_ = (kt) >> p.im2col_shift, c64_ = (kt) & ((1 << p.im2col_shift) - 1);                               \
+      const int ky_ = (tap_ * 11) >> 5, kx_ = tap_ - 3 * ky_;                                                            \
+      const long long off_ = ((long long)(ky_ * p.W + kx_) * p.x0_ld + c64_ * 64) * 2;                                   \
+      const char* z_ = reinterpret_cast<const char*>(cvmi_zero_page) + (lane & 7) * 16;                                  \
+      s0_ = ((vmask[h][0] >> tap_) & 1) ? src[h][0] + off_ : z_;                                                          \
+      s1_ = ((vmask[h][1] >> tap_) & 1) ? src[h][1] + off_ : z_;                                                          \
+    }                                                                                                                    \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)s0_,                                 \
                                      (__attribute__((address_space(3))) void*)(smem + (stage) * STAGE + dst[h][0]), 16, 0, 0); \
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[h][1] + (long long)(kt) * BKB + last_ * adj[h][1]), \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)s1_,                                 \
                                      (__attribute__((address_space(3))) void*)(smem + (stage) * STAGE + dst[h][1]), 16, 0, 0); \
   } while (0)
 
@@ -1768,7 +1799,7 @@ int launch_g256x192(ConvKArgs& a, hipStream_t stream) {
 }
 
 template <typename TO>
-int launch_g256(ConvKArgs& a, hipStream_t stream, int stagger) {
+int launch_g256(ConvKArgs& a, hipStream_t stream, int stagger, bool im2col = false) {
   constexpr int lds = 2 * 512 * 128;                     // two stages; the epilogue tile (256 x 528 B) is larger: 135168
   constexpr int epi = 256 * ((sizeof(TO) == 4 ? 128 : 256) * (int)sizeof(TO) + 16);
   constexpr int bytes = lds > epi ? lds : epi;
@@ -1776,11 +1807,18 @@ int launch_g256(ConvKArgs& a, hipStream_t stream, int stagger) {
   if (!attr_done) {
     CVMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<TO, true>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
     CVMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<TO, false>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    CVMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<TO, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
     attr_done = true;
   }
   a.nb_n = cdiv(a.N, 256);
   const long long blocks = (long long)cdiv(a.M, 256) * a.nb_n;
   CVMI_CHECK(blocks > 0 && blocks < (1ll << 31), "conv2d: bad grid %lld", blocks);
+  if (im2col) {
+    cvmi_note_kernel("gemm256_kernel<%s, true, true>", sizeof(TO) == 2 ? CVMI_F16NAME : "float");
+    hipLaunchKernelGGL((gemm256_kernel<TO, true, true>), dim3((unsigned)blocks), dim3(512), bytes, stream, a);
+    CVMI_LAUNCH_CHECK();
+    return 0;
+  }
   cvmi_note_kernel("gemm256_kernel<%s, %s>", sizeof(TO) == 2 ? CVMI_F16NAME : "float", CVMI_BOOLNAME(stagger));
   if (stagger) hipLaunchKernelGGL((gemm256_kernel<TO, true>), dim3((unsigned)blocks), dim3(512), bytes, stream, a);
   else hipLaunchKernelGGL((gemm256_kernel<TO, false>), dim3((unsigned)blocks), dim3(512), bytes, stream, a);
@@ -1866,6 +1904,19 @@ int launch_typed(ConvKArgs& a, hipStream_t stream) {
   static const int use_glds = getenv("CVMI_GLDS") ? atoi(getenv("CVMI_GLDS")) : 1;           // tuning experiments only
   static const int use_g256 = getenv("CVMI_G256") ? atoi(getenv("CVMI_G256")) : 1;           // 0 off, 1 staggered, 2 lock-step
   if constexpr (sizeof(T) == 2) {
+    // large 3 x 3 convolutions over >= 64 channels (YOLO11-l: model.3 / .5 / .7 / .17 / .20, the 256-channel bottlenecks): the counted-DMA
+    // 256 x 256 pipeline with an im2col source (gemm256_kernel<.., IM2COL>); at least half a round of tiles and >= 75 % of the column tiles used
+    static const int use_i2c = getenv("CVMI_G256_IM2COL") ? atoi(getenv("CVMI_G256_IM2COL")) : 1;      // A/B runs only
+    const int tpt = a.ctot / 64;
+    if (use_g256 && use_i2c && !a.plain && !a.rows2 && a.x1 == nullptr && a.up0 == 0 && !a.scalar_gather && a.KW == 3 && a.K == 9 * a.ctot &&
+        a.ctot % 64 == 0 && (tpt & (tpt - 1)) == 0 && a.Kpad == a.K && N % 8 == 0 && a.shuf_c == 0 && a.res_rep <= 1 && !a.stats && a.res_mod == 0) {
+      const long long tiles = (long long)cdiv(M, 256) * cdiv(N, 256);
+      if ((double)N / (cdiv(N, 256) * 256) >= 0.75 && tiles >= 128) {
+        a.im2col_shift = 0;
+        while ((1 << a.im2col_shift) < tpt) ++a.im2col_shift;
+        return launch_g256<TO>(a, stream, 1, true);
+      }
+    }
     // big plain f16 GEMMs: >= one 256^2 tile per CU and little column-tile waste (N = 576 -> 3 tiles, 75 % used)
     // measured on Hiera-L shapes: wins when >= 80 % of the column tiles and of the last round of 256 tiles is used
     // (N = 576 -> 75 % of 3 column tiles: ties / loses against the 128-row kernels below)
@@ -1983,6 +2034,7 @@ extern "C" int CVMI_ENTRY(cvmi_conv2d)(const cvmi_conv_desc* d, cvmi_stream_t st
   a.act = d->act; a.scalar_gather = d->scalar_gather; a.nb_n = 1;
   a.res_mod = d->res_mod; a.act_after_res = d->act_after_res; a.shuf_c = d->shuffle_cout; a.res_rep = d->res_rep;
   a.stats = d->row_stats;
+  a.im2col_shift = 0;
   CVMI_CHECK(!d->row_stats || (d->out_f32 && d->res && !d->act_after_res && d->N % 192 == 0 && ((uintptr_t)d->row_stats & 7) == 0),
              "conv2d: row_stats needs the f32-output residual form with N a multiple of 192");
   a.plain = (d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0 && d->c1 == 0 && d->up0 == 0 && !d->scalar_gather &&

@@ -62,6 +62,22 @@ def test_conv2d(dtype, cfg):
     _conv_case(dtype, *cfg)
 
 
+@pytest.mark.parametrize("cfg", [
+    # B, Cin, H, W, Cout, k, s, act, res
+    (2, 64, 128, 128, 256, 3, 1, ACT_SILU, False),    # 128 tiles, ONE K-tile per tap (Cin = 64), stride 1: every border tap of every edge pixel
+    (4, 128, 131, 129, 512, 3, 2, ACT_SILU, True),    # stride 2 on odd sizes (the last row / column sees 2 of 3 taps), two column tiles, residual
+    (1, 256, 182, 180, 200, 3, 1, ACT_RELU, False),   # ragged Cout (200 of 256 columns: clamped weight rows), ragged M, 4 K-tiles per tap
+    (4, 512, 129, 129, 512, 3, 2, ACT_SILU, False),   # YOLO11-l model.5 / .7 / .20 geometry: 512 -> 512 channels, stride 2, 72 K-tiles
+])
+def test_conv2d_3x3_im2col_on_the_256_tile_dma_pipeline(cfg):
+    """Large 3 x 3 convolutions (>= 64 channels, a power-of-two multiple of 64; >= 128 tiles of 256 x 256) run on the counted-DMA GEMM with an im2col
+    source: per-tap source offsets, DMA from a zero page for taps outside the image.  vs torch conv2d on fp16-rounded operands; the kernel that
+    ran is checked, and a rerun is bit-identical."""
+    lib = _lib.load()
+    _conv_case(F16, *cfg)
+    assert lib.cvmi_last_kernel().decode() == "gemm256_kernel<_Float16, true, true>", lib.cvmi_last_kernel()
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_conv2d_direct_to_lds_gemm(dtype):
     """Plain GEMMs with K a multiple of one 128-byte tile take the global_load_lds kernel (swizzled LDS image)."""
