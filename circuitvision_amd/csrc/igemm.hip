@@ -1897,6 +1897,25 @@ int launch_cfg(ConvKArgs& a, hipStream_t stream) {
   return plain ? launch_cfg2<T, TO, BM, BN, WM, WN, 64, true>(a, stream) : launch_cfg2<T, TO, BM, BN, WM, WN, 64, false>(a, stream);
 }
 
+// Large 3 x 3 convolutions over >= 64 channels (YOLO11-l: model.1 / .3 / .5 / .7 / .17 / .20, the 256-channel bottlenecks) take the counted-DMA
+// 256 x 256 pipeline with an im2col source (gemm256_kernel<.., IM2COL>): Cin a power-of-two multiple of 64 (a K-tile inside one tap), at least half
+// a round of tiles, at least half of the column tiles used (measured r04, YOLO11-l B = 64: model.3 1353 -> 529 us, model.5 1285 -> 526, .7 / .20
+// 360 / 379 -> 129, model.1 -- N = 128, half of every tile's columns idle -- 957 -> see profiles/r04_ab_runs.md).
+bool im2col_256_ok(const ConvKArgs& a) {
+  static const int use_g256 = getenv("CVMI_G256") ? atoi(getenv("CVMI_G256")) : 1;
+  static const int use_i2c = getenv("CVMI_G256_IM2COL") ? atoi(getenv("CVMI_G256_IM2COL")) : 1;      // A/B runs only
+  static const double i2c_eff = getenv("CVMI_G256_I2C_EFF") ? atof(getenv("CVMI_G256_I2C_EFF")) : 0.75;     // tuning experiments only
+  const int tpt = a.ctot / 64;
+  if (!(use_g256 && use_i2c && !a.plain && !a.rows2 && a.x1 == nullptr && a.up0 == 0 && !a.scalar_gather && a.KW == 3 && a.K == 9 * a.ctot &&
+        a.ctot % 64 == 0 && tpt >= 1 && (tpt & (tpt - 1)) == 0 && a.Kpad == a.K && a.N % 8 == 0 && a.shuf_c == 0 && a.res_rep <= 1 && !a.stats && a.res_mod == 0))
+    return false;
+  const long long tiles = (long long)cdiv(a.M, 256) * cdiv(a.N, 256);
+  // (N = 128 fills half of every tile's columns: still a gain over conv_tile_kernel for the 64-channel model.1, 957 -> 633 us, a loss against the
+  //  128 x 128 kernel for the 128-channel bottlenecks: YOLO11-l step 12.69 -> 12.82 ms with all of them rerouted)
+  const double eff = (double)a.N / (cdiv(a.N, 256) * 256);
+  return (eff >= i2c_eff || (tpt == 1 && eff >= 0.5)) && tiles >= 128;
+}
+
 template <typename T, typename TO>
 int launch_typed(ConvKArgs& a, hipStream_t stream) {
   const long long M = a.M;
@@ -1904,24 +1923,17 @@ int launch_typed(ConvKArgs& a, hipStream_t stream) {
   static const int use_glds = getenv("CVMI_GLDS") ? atoi(getenv("CVMI_GLDS")) : 1;           // tuning experiments only
   static const int use_g256 = getenv("CVMI_G256") ? atoi(getenv("CVMI_G256")) : 1;           // 0 off, 1 staggered, 2 lock-step
   if constexpr (sizeof(T) == 2) {
-    // large 3 x 3 convolutions over >= 64 channels (YOLO11-l: model.3 / .5 / .7 / .17 / .20, the 256-channel bottlenecks): the counted-DMA
-    // 256 x 256 pipeline with an im2col source (gemm256_kernel<.., IM2COL>); at least half a round of tiles and >= 75 % of the column tiles used
-    static const int use_i2c = getenv("CVMI_G256_IM2COL") ? atoi(getenv("CVMI_G256_IM2COL")) : 1;      // A/B runs only
-    const int tpt = a.ctot / 64;
-    if (use_g256 && use_i2c && !a.plain && !a.rows2 && a.x1 == nullptr && a.up0 == 0 && !a.scalar_gather && a.KW == 3 && a.K == 9 * a.ctot &&
-        a.ctot % 64 == 0 && (tpt & (tpt - 1)) == 0 && a.Kpad == a.K && N % 8 == 0 && a.shuf_c == 0 && a.res_rep <= 1 && !a.stats && a.res_mod == 0) {
-      const long long tiles = (long long)cdiv(M, 256) * cdiv(N, 256);
-      if ((double)N / (cdiv(N, 256) * 256) >= 0.75 && tiles >= 128) {
-        a.im2col_shift = 0;
-        while ((1 << a.im2col_shift) < tpt) ++a.im2col_shift;
-        return launch_g256<TO>(a, stream, 1, true);
-      }
+    if (im2col_256_ok(a)) {
+      const int tpt = a.ctot / 64;
+      a.im2col_shift = 0;
+      while ((1 << a.im2col_shift) < tpt) ++a.im2col_shift;
+      return launch_g256<TO>(a, stream, 1, true);
     }
     // big plain f16 GEMMs: >= one 256^2 tile per CU and little column-tile waste (N = 576 -> 3 tiles, 75 % used)
     // measured on Hiera-L shapes: wins when >= 80 % of the column tiles and of the last round of 256 tiles is used
     // (N = 576 -> 75 % of 3 column tiles: ties / loses against the 128-row kernels below)
     static const int g256_mink = getenv("CVMI_G256_MINK") ? atoi(getenv("CVMI_G256_MINK")) : 128;     // tuning experiments only
-    static const int g256_minn = getenv("CVMI_G256_MINN") ? atoi(getenv("CVMI_G256_MINN")) : 384;
+    static const int g256_minn = getenv("CVMI_G256_MINN") ? atoi(getenv("CVMI_G256_MINN")) : 256;      // (r04: 384 -> 256, YOLO11-l model.2.cv2 654 -> 424 us; Hiera unaffected)
     if (use_g256 && a.plain && a.K % 8 == 0 && a.K >= g256_mink && a.Kpad % 64 == 0 && N % 8 == 0 && N >= g256_minn && a.shuf_c == 0 && a.res_rep <= 1) {
       const long long tiles = (long long)cdiv(M, 256) * cdiv(N, 256);
       const double col_eff = (double)N / (cdiv(N, 256) * 256), wave_eff = (double)tiles / (double)(cdiv(tiles, 256) * 256);
@@ -2052,7 +2064,7 @@ extern "C" int CVMI_ENTRY(cvmi_conv2d)(const cvmi_conv_desc* d, cvmi_stream_t st
   a.div_ctot.init((unsigned)ctot); a.div_kw.init((unsigned)d->KW);
   hipStream_t stream = (hipStream_t)stream_;
 #ifndef CVMI_OPERAND_BF16
-  if (d->KH > 1 && d->y_ld >= d->N) {
+  if (d->KH > 1 && d->y_ld >= d->N && !(d->KH == 3 && d->dtype == CVMI_T16 && im2col_256_ok(a))) {      // (64 -> >= 128 channels at a large M: the 256-tile pipeline)
     const int rc = cvmi_conv_tile_try(d, stream);
     if (rc >= 0) return rc;
   }
