@@ -1913,7 +1913,8 @@ bool im2col_256_ok(const ConvKArgs& a) {
   // (N = 128 fills half of every tile's columns: still a gain over conv_tile_kernel for the 64-channel model.1, 957 -> 633 us, a loss against the
   //  128 x 128 kernel for the 128-channel bottlenecks: YOLO11-l step 12.69 -> 12.82 ms with all of them rerouted)
   const double eff = (double)a.N / (cdiv(a.N, 256) * 256);
-  return (eff >= i2c_eff || (tpt == 1 && eff >= 0.5)) && tiles >= 128;
+  static const int i2c_tiles = getenv("CVMI_G256_I2C_TILES") ? atoi(getenv("CVMI_G256_I2C_TILES")) : 128;      // tuning experiments only
+  return (eff >= i2c_eff || (tpt == 1 && eff >= 0.5)) && tiles >= i2c_tiles;
 }
 
 template <typename T, typename TO>
