@@ -993,14 +993,14 @@ __global__ __launch_bounds__(QT * 128, 4) void attn_res64_kernel(const AttnArgs 
   const int item = item_raw < nitems ? item_raw : nitems - 1;
   const int qt = wv;
   const bool live = item_raw < nitems && qt < p.qtiles;
-  const int b = item / p.heads, h = item - b * p.heads;
+  const int b = (int)p.div_heads.div((unsigned)item), h = item - b * p.heads;      // (host-computed multipliers: as attn_res256_kernel, r04)
   const int qwin = p.q_pool ? p.win / 2 : p.win;
 
   // ---- DMA the window's K and V: chunk L -> (key row L / 9, 16-byte chunk L % 9); 36 wave-instructions per matrix
   {
     long long korg, vorg;
     if (p.win > 0) {
-      const long long pix0 = tok_off(b, 0, 1, 1, p.win, p.grid_h, p.grid_w);
+      const long long pix0 = tok_off_fast(p, b, 0, 1, p.win, p.grid_h, p.grid_w, p.div_win);
       korg = pix0 * p.k_st; vorg = pix0 * p.v_st;
     } else {
       korg = (long long)b * p.k_sb; vorg = (long long)b * p.v_sb;
@@ -1028,8 +1028,8 @@ __global__ __launch_bounds__(QT * 128, 4) void attn_res64_kernel(const AttnArgs 
   {
     const int qc = q_ok ? qi : 0;
     int t = qc;
-    if (p.q_pool) { const int py = qc / qwin, px = qc - py * qwin; t = (2 * py) * p.win + 2 * px; }
-    qoff0 = tok_off(b, t, p.q_sb, p.q_st, p.win, p.grid_h, p.grid_w) + (long long)h * p.q_sh;
+    if (p.q_pool) { const int py = (int)p.div_ow.div((unsigned)qc), px = qc - py * qwin; t = (2 * py) * p.win + 2 * px; }
+    qoff0 = (p.win > 0 ? tok_off_fast(p, b, t, p.q_st, p.win, p.grid_h, p.grid_w, p.div_win) : (long long)b * p.q_sb + (long long)t * p.q_st) + (long long)h * p.q_sh;
   }
   u32x4 qf[QS];
 #pragma unroll
@@ -1125,7 +1125,7 @@ __global__ __launch_bounds__(QT * 128, 4) void attn_res64_kernel(const AttnArgs 
     long long obase;
     if (p.win > 0) {
       const int ow = p.q_pool ? p.win / 2 : p.win, ogh = p.q_pool ? p.grid_h / 2 : p.grid_h, ogw = p.q_pool ? p.grid_w / 2 : p.grid_w;
-      obase = tok_off(b, qi, p.o_sb, p.o_st, ow, ogh, ogw);
+      obase = tok_off_fast(p, b, qi, p.o_st, ow, ogh, ogw, p.div_ow);
     } else {
       obase = (long long)b * p.o_sb + (long long)qi * p.o_st;
     }
