@@ -1775,8 +1775,14 @@ int launch_g256x192(ConvKArgs& a, hipStream_t stream) {
   a.rev_m = rev;
   if constexpr (sizeof(TO) == 4) {
     static const int persist = getenv("CVMI_G192_PERSIST") ? atoi(getenv("CVMI_G192_PERSIST")) : 1;     // A/B runs only
+    static const int ncu = [] {                                  // one persistent workgroup per CU of THIS device (MI355X: 256 = 8 XCDs x 32)
+      int dev = 0;
+      hipDeviceProp_t prop;
+      if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
+      return prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }();
     if (persist && m16 && a.res && a.act == CVMI_ACT_NONE && !a.act_after_res && a.res_mod == 0 && a.M % 256 == 0 && a.N % 192 == 0 &&
-        a.K % 256 == 0 && a.K / 256 >= 9 && blocks % 256 == 0) {             // whole rounds of 256 tiles: one workgroup per CU
+        a.K % 256 == 0 && a.K / 256 >= 9 && ncu % 8 == 0 && blocks % ncu == 0) {  // whole rounds of tiles: one workgroup per CU
       static bool attr_r = false;
       if (!attr_r) {
         CVMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256x192r_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
@@ -1786,7 +1792,7 @@ int launch_g256x192(ConvKArgs& a, hipStream_t stream) {
       a.per_xcd = (int)(blocks / 8);
       static const int diag = getenv("CVMI_G192_DIAG") ? atoi(getenv("CVMI_G192_DIAG")) : 0;
       a.diag = diag;
-      hipLaunchKernelGGL(gemm256x192r_kernel, dim3(256), dim3(512), lds, stream, a);
+      hipLaunchKernelGGL(gemm256x192r_kernel, dim3((unsigned)ncu), dim3(512), lds, stream, a);
       CVMI_LAUNCH_CHECK();
       return 0;
     }
