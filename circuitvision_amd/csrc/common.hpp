@@ -132,6 +132,79 @@ __device__ __forceinline__ f16x2 gelu_fast_pk(float a, float b) {
 __device__ __forceinline__ f16x2 gelu_fast_pk(float a, float b) { return (f16x2){(f16)gelu_fast(a), (f16)gelu_fast(b)}; }
 #endif
 
+// gelu_fast_pk of TWO value pairs cut into four short steps, for a loop that issues them between MFMAs:   s0(a0, a1, b0, b1);  s1();  s2();  s3();
+// then ra / rb hold the two packed results.  fp16 build: the instruction sequence hipcc emits for gelu_fast_pk (identical bits), written out with the
+// two pairs' chains alternating -- a packed-fp16 or transcendental result must not be read by the next instruction on gfx950 (one wait state), and
+// alternating provides it without the s_nop hipcc puts there (9 per pair) -- and as asm blocks so that their place in the program order of the
+// volatile asm statements around them is fixed (hipcc's instruction selection otherwise moves pure arithmetic across those, e.g. every s0 to the front).
+struct GeluPk2Steps {
+#ifndef CVMI_OPERAND_BF16
+  uint32_t ra, rb, ta, tb;
+  __device__ __forceinline__ void s0(float a0, float a1, float b0, float b1) {
+    asm volatile("v_cvt_pk_f16_f32 %0, %4, %5\n\tv_cvt_pk_f16_f32 %2, %6, %7\n\t"
+                 "v_pk_mul_f16 %1, %0, %0\n\tv_pk_mul_f16 %3, %2, %2\n\t"
+                 "v_pk_min_f16 %1, %1, %8 op_sel_hi:[1,0]\n\tv_pk_min_f16 %3, %3, %8 op_sel_hi:[1,0]"
+                 : "=&v"(ra), "=&v"(ta), "=&v"(rb), "=&v"(tb) : "v"(a0), "v"(a1), "v"(b0), "v"(b1), "s"(0x5400u));                       // 64.0
+  }
+  __device__ __forceinline__ void s1(uint32_t c1_vgpr) {                      // c1_vgpr: -1.06775760e-01 as fp16 in the low half of a VGPR (one SGPR per instruction)
+    uint32_t ua, ub;
+    asm volatile("v_pk_fma_f16 %2, %0, %6, %7 op_sel_hi:[1,0,0]\n\tv_pk_fma_f16 %3, %1, %6, %7 op_sel_hi:[1,0,0]\n\t"
+                 "v_pk_fma_f16 %0, %0, %2, %8 op_sel_hi:[1,1,0]\n\tv_pk_fma_f16 %1, %1, %3, %8 op_sel_hi:[1,1,0]\n\t"
+                 "v_pk_mul_f16 %0, %4, %0\n\tv_pk_mul_f16 %1, %5, %1"
+                 : "+v"(ta), "+v"(tb), "=&v"(ua), "=&v"(ub) : "v"(ra), "v"(rb), "s"(GELU_C2_H), "v"(c1_vgpr), "s"(GELU_C0_H));
+  }
+  __device__ __forceinline__ void s2() {
+    uint32_t ea, eb;
+    asm volatile("v_exp_f16_e32 %2, %0\n\tv_exp_f16_e32 %3, %1\n\t"
+                 "v_exp_f16_sdwa %0, %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
+                 "v_exp_f16_sdwa %1, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
+                 "v_pack_b32_f16 %0, %2, %0\n\tv_pack_b32_f16 %1, %3, %1\n\t"
+                 "v_pk_add_f16 %0, %0, 1.0 op_sel_hi:[1,0]\n\tv_pk_add_f16 %1, %1, 1.0 op_sel_hi:[1,0]"
+                 : "+v"(ta), "+v"(tb), "=&v"(ea), "=&v"(eb));
+  }
+  __device__ __forceinline__ void s3() {
+    uint32_t ea, eb;
+    asm volatile("v_rcp_f16_e32 %4, %2\n\tv_rcp_f16_e32 %5, %3\n\t"
+                 "v_rcp_f16_sdwa %2, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
+                 "v_rcp_f16_sdwa %3, %3 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
+                 "v_pack_b32_f16 %2, %4, %2\n\tv_pack_b32_f16 %3, %5, %3\n\t"
+                 "v_pk_mul_f16 %0, %0, %2\n\tv_pk_mul_f16 %1, %1, %3"
+                 : "+v"(ra), "+v"(rb), "+v"(ta), "+v"(tb), "=&v"(ea), "=&v"(eb));
+  }
+  static constexpr uint32_t GELU_C2_H = 0x1428u, GELU_C0_H = 0xC09Au;        // fp16(1.01426788e-03), fp16(-2.30112128e+00): checked against the
+  static constexpr uint32_t GELU_C1_H = 0xAED5u;                              // compiler's constants by tests/test_ops_gpu.py (bit-identity with gelu_fast_pk)
+#else
+  uint32_t ra, rb;
+  float v[4], t[4];
+  __device__ __forceinline__ void fence() { asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3])); }
+  __device__ __forceinline__ void s0(float a0, float a1, float b0, float b1) {
+    v[0] = a0; v[1] = a1; v[2] = b0; v[3] = b1;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) t[e] = fminf(v[e] * v[e], 64.0f);
+    fence();
+  }
+  __device__ __forceinline__ void s1(uint32_t) {
+    fence();
+#pragma unroll
+    for (int e = 0; e < 4; ++e) t[e] = v[e] * fmaf(t[e], fmaf(t[e], 1.01426788e-03f, -1.06775760e-01f), -2.30112128e+00f);
+    fence();
+  }
+  __device__ __forceinline__ void s2() {
+    fence();
+#pragma unroll
+    for (int e = 0; e < 4; ++e) t[e] = 1.0f + __builtin_amdgcn_exp2f(t[e]);
+    fence();
+  }
+  __device__ __forceinline__ void s3() {
+    fence();
+    ra = __builtin_bit_cast(uint32_t, (f16x2){(f16)(v[0] * fast_rcp(t[0])), (f16)(v[1] * fast_rcp(t[1]))});
+    rb = __builtin_bit_cast(uint32_t, (f16x2){(f16)(v[2] * fast_rcp(t[2])), (f16)(v[3] * fast_rcp(t[3]))});
+    asm volatile("" : "+v"(ra), "+v"(rb));
+  }
+  static constexpr uint32_t GELU_C1_H = 0u;
+#endif
+};
+
 // FAST = true: v_exp/v_rcp based (fp16 storage mode); false: precise libm (f32 parity mode)
 template <bool FAST> __device__ __forceinline__ float act_apply(float v, int act) {
   switch (act) {

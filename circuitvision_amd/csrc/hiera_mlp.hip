@@ -21,11 +21,35 @@
 // C = 288 (stage 2): the Y^T accumulator (144 registers) + Xn (76) leave room for one wave per SIMD only: 4 waves.
 #include "common.hpp"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
-// VAR bit 0: 4-wave workgroups, two waves per SIMD coming from two INDEPENDENT workgroups (C = 144: instead of one 8-wave workgroup; C = 288:
+// MFMAs of the pipelined loop are inline asm so that the register FILE of every accumulator is fixed by its constraint: the fc2 accumulators
+// ("+a": AGPRs, touched by nothing but MFMAs until the epilogue) and the hidden accumulators ("v": VGPRs, which GELU reads directly).  Written with
+// the builtin, hipcc moves the accumulators between the files around every fc2 MFMA once two chunks are in flight (r04: hundreds of
+// v_accvgpr_* per pair of chunks).  hipcc's hazard recogniser does not look inside inline asm: the waits an MFMA result needs before a
+// non-MFMA instruction reads it (12 wait states on gfx950 for this shape) are provided by the program order below and marked where they are.
+#ifdef CVMI_OPERAND_BF16
+#define CVMI_MFMA_ASM "v_mfma_f32_32x32x16_bf16"
+#else
+#define CVMI_MFMA_ASM "v_mfma_f32_32x32x16_f16"
+#endif
+
+// fragment of a stage (fc2's 2 NT fragments of one chunk, then fc1's N1 of the next) that the pipelined loop consumes i-th: fc1's k-steps, then
+// fc2's k-half 0 of every output tile, then k-half 1
+template <int N1, int NT> constexpr int stage_frag(int i) { return i < N1 ? 2 * NT + i : (i - N1 < NT ? 2 * (i - N1) : 2 * (i - N1 - NT) + 1); }
+
+template <int I, int N, typename F> __device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+
+// VAR 1: 4-wave workgroups, two waves per SIMD coming from two INDEPENDENT workgroups (C = 144: instead of one 8-wave workgroup; C = 288:
 // instead of one wave per SIMD, at 256 registers with ~20 spilled).  SLOTS: depth of the weight ring.  Both measured in r04 (profiles/r04_ab_runs.md).
+// VAR 2: one wave per SIMD with the chunk loop software-pipelined inside the wave (see `pipelined chunk loop` in the kernel).
 template <int C, int VAR = 0, int SLOTS_ = 2> struct MlpCfg {
   static constexpr int KS = C / 16;                 // k-steps of fc1
   static constexpr int KS1 = KS + 1;                // + the bias step
@@ -33,14 +57,16 @@ template <int C, int VAR = 0, int SLOTS_ = 2> struct MlpCfg {
   static constexpr int NCH = 4 * C / 32;            // hidden chunks
   static constexpr int FR = KS1 + 2 * NT;           // 1 KiB fragments per chunk
   static constexpr int CHB = FR * 1024;             // bytes per chunk
-  static constexpr int NW = VAR == 1 ? 4 : (C <= 144 ? 8 : 4);       // waves per workgroup
-  static constexpr int WPS = VAR == 1 ? 2 : (C <= 144 ? 2 : 1);      // waves per SIMD the register budget is set for
+  static constexpr int NW = VAR >= 1 ? 4 : (C <= 144 ? 8 : 4);       // waves per workgroup
+  static constexpr int WPS = VAR == 2 ? (C <= 144 ? 2 : 1) : VAR == 1 ? 2 : (C <= 144 ? 2 : 1);      // waves per SIMD the register budget is set for
   static constexpr int SLOTS = SLOTS_;
   static constexpr int CNT = (FR + NW - 1) / NW;    // LDS-DMA instructions every wave issues per chunk (the same count in every wave: counted waits)
   static constexpr int LDS = SLOTS * CHB + 1024;    // + a dump piece for the padding instructions of the waves with fewer real pieces
 };
 
-template <int C, int VAR = 0, int SLOTS = 2>
+// DIAG (timing-only builds, -DCVMI_MLP_DIAGS; results are wrong by design): 1 no GELU, 2 no MFMAs, 3 no weight DMA inside the loop, 4 no LDS reads,
+// 5 = 1 + 3 + 4 (MFMAs and barriers only).  A template parameter so that the shipped instantiation's code is untouched.
+template <int C, int VAR = 0, int SLOTS = 2, int DIAG = 0>
 __global__ __launch_bounds__((MlpCfg<C, VAR, SLOTS>::NW * 64), (MlpCfg<C, VAR, SLOTS>::WPS)) void hiera_mlp_kernel(float* __restrict__ x, int x_ld, const float* __restrict__ gamma,
                                                                                       const float* __restrict__ beta, float eps,
                                                                                       const char* __restrict__ wp, const float* __restrict__ b2,
@@ -68,8 +94,28 @@ __global__ __launch_bounds__((MlpCfg<C, VAR, SLOTS>::NW * 64), (MlpCfg<C, VAR, S
                                        (__attribute__((address_space(3))) void*)(real ? dst + fi * 1024 : smem + SLOTS * CHB), 16, 0, 0);
     }
   };
+  // Pipelined form (VAR 2): the unit of the stream is a STAGE = the FR consecutive fragments that one loop iteration consumes: fc2's fragments of
+  // chunk s followed by fc1's of chunk s + 1 (contiguous in the packed stream).  Stage -1 is fc1's part of chunk 0 alone, stage NCH - 1 fc2's alone.
+  auto issue_piece = [&](int st, int f) {                            // this wave's f-th DMA instruction of stage st (every wave issues CNT per stage)
+    const int lo = st < 0 ? 2 * NT : 0, hi = st == NCH - 1 ? 2 * NT : FR;
+    const char* src = wp + ((long long)st * FR + KS1) * 1024 + lane * 16;
+    char* dst = smem + ((st + SLOTS) % SLOTS) * CHB;
+    const int fi = f * NW + wv;
+    const bool real = fi >= lo && fi < hi;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (long long)(real ? fi : lo) * 1024),
+                                     (__attribute__((address_space(3))) void*)(real ? dst + fi * 1024 : smem + SLOTS * CHB), 16, 0, 0);
+  };
+  auto issue_stage = [&](int st) {
 #pragma unroll
-  for (int j = 0; j < SLOTS - 1; ++j) issue_chunk(j);
+    for (int f = 0; f < CNT; ++f) issue_piece(st, f);
+  };
+  if constexpr (VAR == 2) {
+#pragma unroll
+    for (int st = -1; st < SLOTS - 1; ++st) issue_stage(st);
+  } else {
+#pragma unroll
+    for (int j = 0; j < SLOTS - 1; ++j) issue_chunk(j);
+  }
 
   // ---- LayerNorm of this lane's half row -> B fragments of fc1 (lane (token lr, half lh) holds channels 16 s + 8 lh .. + 7)
   u32x4 xn[KS1];
@@ -116,6 +162,145 @@ __global__ __launch_bounds__((MlpCfg<C, VAR, SLOTS>::NW * 64), (MlpCfg<C, VAR, S
 #pragma unroll
     for (int r = 0; r < 16; ++r) yacc[t][r] = 0.f;
 
+  if constexpr (VAR == 2) {
+    // ---- pipelined chunk loop.  Iteration j of one wave:   fc1(j + 1) -> hout   ||   GELU(hin = fc1(j)) -> pfv   ||   fc2(j): yacc += W2 . pfv
+    // Left in chunk order, the wave runs fc1's MFMAs, then ~200 issue slots of GELU with the matrix pipe idle, then fc2's MFMAs -- and with one wave per
+    // SIMD nobody else fills the gap.  Here GELU's steps sit between the MFMAs of the NEXT chunk's fc1 and of this chunk's first fc2 half (fc2 runs the
+    // k-half-0 MFMAs of every tile first: they need only the first eight GELU values).  One wave issues one instruction per ~4 - 5 cycles and an MFMA
+    // occupies the pipe for 32: the loop is written as asm blocks -- {counted LDS wait, MFMA, refill of the ring register it read} and the GELU steps of
+    // GeluPk2Steps -- because what hipcc makes of the same source carries ~150 s_nop and waits per chunk, each an issue slot (r04: 423 slots per chunk
+    // for 37 MFMAs; timing-only builds, profiles/r04_ab_runs.md).
+    // Register files are fixed by the constraints: yacc in AGPRs ("+a"), the hidden accumulators in VGPRs (GELU reads them directly).
+    // hipcc's hazard recogniser does not look inside asm: what the hardware needs around these MFMAs is provided here by construction --
+    //   * a VGPR a VALU instruction wrote needs wait states before an MFMA reads it (measured: an LayerNorm conversion that hipcc had sunk to
+    //     right in front of the consuming block gave wrong results in whole waves): xn and pfv pass through an `s_nop 1` asm statement first;
+    //   * an MFMA's result needs 12 wait states before a VALU instruction reads it: GELU reads hin >= 18 MFMAs after its last MFMA, the epilogue
+    //     reads yacc behind s_nop 15;
+    //   * dependent MFMAs on one accumulator may follow each other directly.
+    constexpr int PF = 6;
+    constexpr bool NO_GELU = DIAG == 1 || DIAG == 5, NO_MFMA = DIAG == 2, NO_DMA = DIAG == 3 || DIAG == 5, NO_LDS = DIAG == 4 || DIAG == 5;
+    f32x16 hA, hB;
+    // The PF registers the weight fragments pass through belong to the loop from here to its end ("+v" everywhere: a block reads its fragment and
+    // refills the same registers).
+    u32x4 ring_[PF];
+#pragma unroll
+    for (int f = 0; f < PF; ++f) asm volatile("" : "=v"(ring_[f]));
+#pragma unroll
+    for (int k = 0; k < KS1; ++k) asm volatile("s_nop 1" : "+v"(xn[k]));
+    GeluPk2Steps gs[4];                                                 // couple c = value pairs 2 c, 2 c + 1 of the lane's 16 hidden values
+    u32x4 pfv[2] = {};                                                  // GELU's output = fc2's B operands: dword p & 3 of pfv[p >> 2] is pair p
+    uint32_t c1v = GeluPk2Steps::GELU_C1_H;
+    asm volatile("" : "+v"(c1v));
+    auto gelu_step = [&](f32x16& h, auto kc) {                          // step k = 4 c + s of 16
+      constexpr int k = decltype(kc)::value, c = k >> 2;
+      if constexpr (NO_GELU) return;
+      GeluPk2Steps& g = gs[c];
+      if constexpr ((k & 3) == 0) g.s0(h[4 * c], h[4 * c + 1], h[4 * c + 2], h[4 * c + 3]);
+      else if constexpr ((k & 3) == 1) g.s1(c1v);
+      else if constexpr ((k & 3) == 2) g.s2();
+      else {
+        g.s3();
+        pfv[c >> 1][2 * (c & 1)] = g.ra;
+        pfv[c >> 1][2 * (c & 1) + 1] = g.rb;
+      }
+    };
+    // mode 0: fc1(0) alone out of stage -1;  1: steady state;  3: steady state with no stage left to fetch;  2: the last iteration (no next chunk)
+    auto iter = [&](auto mode_, int slot, int nst, f32x16& hin, f32x16& hout) {
+      constexpr int MODE = decltype(mode_)::value == 3 ? 1 : decltype(mode_)::value;
+      constexpr bool ISSUE = SLOTS == 3 && decltype(mode_)::value == 1 && !NO_DMA;       // this iteration carries the DMA of stage nst between its MFMAs
+      constexpr int N1 = MODE == 2 ? 0 : KS1, N2 = MODE == 0 ? 0 : 2 * NT, NF = N1 + N2;
+      const char* const nsrc = wp + ((long long)nst * FR + KS1) * 1024 + lane * 16;      // stage nst (>= 1): source, slot, pieces that exist
+      char* const ndst = smem + (nst % SLOTS) * CHB;
+      const int nhi = nst == NCH - 1 ? 2 * NT : FR;
+      const unsigned lbase_ = (unsigned)(size_t)((const __attribute__((address_space(3))) char*)(smem + slot * CHB + lane * 16));
+      static_for<0, PF>([&](auto fc) {
+        constexpr int f = decltype(fc)::value;
+        u32x4(&ring)[PF] = ring_;                                       // (clang does not capture a variable that only asm operands name)
+        const unsigned lbase = lbase_;
+        if constexpr (!NO_LDS) asm volatile("ds_read_b128 %0, %1 offset:%2" : "+v"(ring[f]) : "v"(lbase), "n"(stage_frag<N1, NT>(f) * 1024));
+      });
+      if constexpr (MODE != 0) asm volatile("" : "+v"(hin));          // (hin's last MFMA is >= 18 MFMAs back: no wait needed before GELU reads it)
+      static_for<0, NF>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        u32x4(&ring)[PF] = ring_;
+        const unsigned lbase = lbase_;
+        f32x16 &hi_ = hin, &ho_ = hout;
+        u32x4(&pfw)[2] = pfv;
+        u32x4(&xf)[KS1] = xn;
+        f32x16(&ya)[NT] = yacc;
+        constexpr int young = NO_LDS ? 15 : ((NF - 1 - i) < (PF - 1) ? (NF - 1 - i) : (PF - 1));
+        constexpr bool refill = i + PF < NF && !NO_LDS;
+        constexpr int off = refill ? stage_frag<N1, NT>(i + PF) * 1024 : 0;
+        if constexpr (i == N1 && MODE != 0) asm volatile("s_nop 1" : "+v"(pfw[0]));            // VALU result -> MFMA operand
+        if constexpr (i == N1 + NT && MODE != 0) asm volatile("s_nop 1" : "+v"(pfw[1]));
+#define CVMI_MLP_BLK(TAIL, ACCC, ACC, B)                                                                                                              \
+  if constexpr (refill)                                                                                                                                \
+    asm volatile("s_waitcnt lgkmcnt(%[n])\n\t" CVMI_MFMA_ASM " %[acc], %[a], %[b], " TAIL "\n\tds_read_b128 %[a], %[lb] offset:%[off]"               \
+                 : [acc] ACCC(ACC), [a] "+v"(ring[i % PF]) : [b] "v"(B), [lb] "v"(lbase), [n] "n"(young), [off] "n"(off));                             \
+  else                                                                                                                                                 \
+    asm volatile("s_waitcnt lgkmcnt(%[n])\n\t" CVMI_MFMA_ASM " %[acc], %[a], %[b], " TAIL : [acc] ACCC(ACC), [a] "+v"(ring[i % PF]) : [b] "v"(B), [n] "n"(young))
+        if constexpr (NO_MFMA) {
+          if constexpr (i == 0 && N1 > 0) asm volatile("" : "=v"(ho_));
+          if constexpr (refill) asm volatile("s_waitcnt lgkmcnt(%2)\n\tds_read_b128 %0, %1 offset:%3" : "+v"(ring[i % PF]) : "v"(lbase), "n"(young), "n"(off));
+        } else if constexpr (i < N1) {
+          if constexpr (i == 0) { CVMI_MLP_BLK("0", "=&v", ho_, xf[i]); }
+          else { CVMI_MLP_BLK("%[acc]", "+v", ho_, xf[i]); }
+        } else {
+          constexpr int t = (i - N1) % NT, s2 = (i - N1) / NT;
+          CVMI_MLP_BLK("%[acc]", "+a", ya[t], pfw[s2]);
+        }
+#undef CVMI_MLP_BLK
+        // GELU steps behind this MFMA.  Steady state: the 16 steps spread evenly over fc1's MFMAs and fc2's first half (pfv[0] = steps 0 - 7 is
+        // complete well inside fc1, pfv[1] before fc2's second half).  Last iteration: steps 0 - 7 came up front, 8 - 15 sit under fc2's first half.
+        constexpr int SL = MODE == 1 ? N1 + NT : NT, K0 = MODE == 1 ? 0 : 8;
+        if constexpr (MODE != 0 && i < SL)
+          static_for<K0, 16>([&](auto kc) {
+            if constexpr ((decltype(kc)::value - K0) * SL / (16 - K0) == i) gelu_step(hi_, kc);
+          });
+        // Three slots: the DMA instructions of the stage after next go out one at a time between the MFMAs (an LDS-DMA instruction holds the
+        // wave's issue for ~60 - 100 cycles: ten in a row at the top of the iteration are ~0.4 us with the matrix pipe idle).
+        if constexpr (ISSUE)
+          static_for<0, CNT>([&](auto fc) {
+            constexpr int f = decltype(fc)::value;
+            if constexpr (f * NF / CNT == i) {
+              const int fi = f * NW + wv;
+              const bool real = fi < nhi;                                // (scalar: wave-uniform)
+              __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(nsrc + (real ? fi : 0) * 1024),
+                                               (__attribute__((address_space(3))) void*)(real ? ndst + fi * 1024 : smem + SLOTS * CHB), 16, 0, 0);
+            }
+          });
+      });
+    };
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((SLOTS - 1) * CNT) : "memory");   // stage -1 (all but the youngest stages' DMA instructions of this wave)
+    __syncthreads();
+    iter(std::integral_constant<int, 0>{}, SLOTS - 1, 0, hA, hA);
+    auto step = [&](auto mode, int j, f32x16& hin, f32x16& hout) {
+      // own pieces of stage j (three slots: stage j + 1 may still be in flight); the barrier publishes them and retires stage j - 1, whose slot
+      // the next fetch overwrites
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((SLOTS - 2) * CNT) : "memory");
+      __syncthreads();
+      if (SLOTS == 2 && j + 1 < NCH && !NO_DMA) issue_stage(j + 1);
+      iter(mode, j % SLOTS, j + 2, hin, hout);
+    };
+    static_assert(NCH % 2 == 0, "pairs of iterations");
+#pragma unroll 1
+    for (int j = 0; j < NCH - 2; j += 2) {
+      step(std::integral_constant<int, 1>{}, j, hA, hB);
+      step(std::integral_constant<int, 1>{}, j + 1, hB, hA);
+    }
+    step(std::integral_constant<int, 3>{}, NCH - 2, hA, hB);
+    {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      asm volatile("" : "+v"(hB));
+      static_for<0, 8>([&](auto kc) { gelu_step(hB, kc); });
+      iter(std::integral_constant<int, 2>{}, (NCH - 1) % SLOTS, 0, hB, hB);
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) asm volatile("s_nop 15" : "+a"(yacc[t]));   // the epilogue's v_accvgpr_read after the last MFMAs
+#pragma unroll
+    for (int f = 0; f < PF; ++f) asm volatile("" ::"v"(ring_[f]));
+  } else
 #pragma unroll 1
   for (int j = 0; j < NCH; ++j) {
     // Every wave waits for its OWN DMA pieces (hipcc puts no vmcnt wait in front of a barrier for LDS-DMA writes: without this
@@ -209,15 +394,15 @@ __global__ __launch_bounds__((MlpCfg<C, VAR, SLOTS>::NW * 64), (MlpCfg<C, VAR, S
   }
 }
 
-template <int C, int VAR = 0, int SLOTS = 2>
+template <int C, int VAR = 0, int SLOTS = 2, int DIAG = 0>
 int launch_mlp(float* x, int x_ld, const float* gamma, const float* beta, float eps, const void* wp, const float* b2, long long rows, hipStream_t s,
                float* stats_out, float stats_eps) {
   using Cfg = MlpCfg<C, VAR, SLOTS>;
-  static hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&hiera_mlp_kernel<C, VAR, SLOTS>), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
+  static hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&hiera_mlp_kernel<C, VAR, SLOTS, DIAG>), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
   CVMI_HIP(attr);
   const long long per = (long long)Cfg::NW * 32;
   cvmi_note_kernel("hiera_mlp_kernel<%d, %d, %d>", C, VAR, SLOTS);
-  hipLaunchKernelGGL((hiera_mlp_kernel<C, VAR, SLOTS>), dim3((unsigned)((rows + per - 1) / per)), dim3(Cfg::NW * 64), Cfg::LDS, s, x, x_ld, gamma, beta, eps,
+  hipLaunchKernelGGL((hiera_mlp_kernel<C, VAR, SLOTS, DIAG>), dim3((unsigned)((rows + per - 1) / per)), dim3(Cfg::NW * 64), Cfg::LDS, s, x, x_ld, gamma, beta, eps,
                      (const char*)wp, b2, rows, stats_out, stats_eps);
   CVMI_LAUNCH_CHECK();
   return 0;
@@ -257,13 +442,23 @@ extern "C" int CVMI_ENTRY(cvmi_hiera_mlp_stats)(void* x, int x_ld, const float* 
   // A/B switches (measured r04, profiles/r04_ab_runs.md): CVMI_MLP_VAR bit 0 -> C = 144, bit 1 -> C = 288 in 4-wave workgroups at two waves per
   // SIMD; CVMI_MLP_SLOTS = 2 | 3, the ring depth
   static const int var = getenv("CVMI_MLP_VAR") ? atoi(getenv("CVMI_MLP_VAR")) : 1;
-  static const int slots = getenv("CVMI_MLP_SLOTS") ? atoi(getenv("CVMI_MLP_SLOTS")) : 2;
+  const char* const slots_env = getenv("CVMI_MLP_SLOTS");
+  const int slots = slots_env ? atoi(slots_env) : 2;
+  const char* const pipe_env = getenv("CVMI_MLP_PIPE");        // (read per call: tests/test_ops_gpu.py switches it between two launches)
+  const int pipe = pipe_env ? atoi(pipe_env) : 0;
 #define CVMI_MLP_GO(CC, VV, SS) return launch_mlp<CC, VV, SS>(xf, x_ld, gamma, beta, eps, w_packed, b2, rows, s, ln_stats_out, ln_stats_eps)
   if (C == 144) {
+    if (pipe & 1) CVMI_MLP_GO(144, 2, 2);
     if (var & 1) { if (slots == 3) CVMI_MLP_GO(144, 1, 3); CVMI_MLP_GO(144, 1, 2); }
     if (slots == 3) CVMI_MLP_GO(144, 0, 3);
     CVMI_MLP_GO(144, 0, 2);
   }
+#ifdef CVMI_MLP_DIAGS
+  static const int diag = getenv("CVMI_MLP_DIAG") ? atoi(getenv("CVMI_MLP_DIAG")) : 0;
+#define CVMI_MLP_DIAG_GO(D) if (C == 288 && diag == D) return launch_mlp<288, 2, 3, D>(xf, x_ld, gamma, beta, eps, w_packed, b2, rows, s, ln_stats_out, ln_stats_eps)
+  CVMI_MLP_DIAG_GO(1); CVMI_MLP_DIAG_GO(2); CVMI_MLP_DIAG_GO(3); CVMI_MLP_DIAG_GO(4); CVMI_MLP_DIAG_GO(5);
+#endif
+  if (pipe & 2) { if (slots == 3) CVMI_MLP_GO(288, 2, 3); CVMI_MLP_GO(288, 2, 2); }
   if (var & 2) CVMI_MLP_GO(288, 1, 2);                  // (two workgroups per CU leave room for two slots of 37 KiB each only)
   if (slots == 3) CVMI_MLP_GO(288, 0, 3);
   CVMI_MLP_GO(288, 0, 2);

@@ -634,6 +634,34 @@ def test_hiera_mlp_fused_vs_torch(C_, rows, dt):
     assert torch.equal(xb.t.view(rows + 3, C_).cpu(), got)
 
 
+@pytest.mark.parametrize("dt", [F16, BF16])
+@pytest.mark.parametrize("rows", [777, 128 * 40 + 5])
+def test_hiera_mlp_pipelined_loop_equals_chunk_order_loop(rows, dt, monkeypatch):
+    """C = 288: the software-pipelined chunk loop (asm blocks; GELU of chunk j between the MFMAs of fc1(j + 1) and fc2(j)) computes every value with
+    the same operations in the same order as the chunk-order loop it replaces: outputs and forwarded LayerNorm statistics must be bit-identical.
+    (A scheduling hazard inside the asm blocks -- nothing hipcc checks -- shows up here as a difference.)"""
+    from circuitvision_amd.engine import PackedHieraMlp, op_hiera_mlp
+    C_ = 288
+    g = torch.Generator().manual_seed(rows)
+    x = torch.randn(rows, C_, generator=g) * 1.5 + 0.3
+    gam, bet = torch.rand(C_, generator=g) + 0.5, torch.randn(C_, generator=g) * 0.2
+    pm = PackedHieraMlp(torch.randn(4 * C_, C_, generator=g) / C_ ** 0.5, torch.randn(4 * C_, generator=g) * 0.3,
+                        torch.randn(C_, 4 * C_, generator=g) / (4 * C_) ** 0.5, torch.randn(C_, generator=g) * 0.3, dtype=dt)
+    outs = []
+    for pipe in ("0", "2"):
+        monkeypatch.setenv("CVMI_MLP_PIPE", pipe)
+        xb = Buf(1, 1, rows, C_, F32)
+        xb.t.copy_(x.view(1, 1, rows, C_))
+        stats = torch.zeros((rows, 2), device="cuda")
+        plan = Plan(stream())
+        op_hiera_mlp(plan, "mlp", pm, xb.images(0, 1).view(), gam.cuda(), bet.cuda(), 1e-6, stats_out=stats, stats_eps=1e-6)
+        torch.cuda.synchronize()
+        kern = plan.timed_eager(with_kernels=True)[0][5]
+        outs.append((xb.t.cpu().clone(), stats.cpu().clone(), kern))
+    assert outs[0][2] != outs[1][2], outs[0][2]                     # (two different kernels ran)
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
 @pytest.mark.parametrize("K,N,ln,res,act", [(144, 432, True, False, ACT_NONE), (288, 864, True, False, ACT_NONE), (576, 1728, True, False, ACT_NONE),
                                             (576, 2304, True, False, ACT_GELU), (576, 576, False, True, ACT_NONE), (144, 144, False, True, ACT_NONE),
                                             (288, 104, False, False, ACT_GELU), (576, 40, True, True, ACT_NONE), (144, 432, True, False, ACT_GELU), (288, 288, True, True, ACT_NONE),
