@@ -177,6 +177,7 @@ __global__ __launch_bounds__((MlpCfg<C, VAR, SLOTS>::NW * 64), (MlpCfg<C, VAR, S
     //   * an MFMA's result needs 12 wait states before a VALU instruction reads it: GELU reads hin >= 18 MFMAs after its last MFMA, the epilogue
     //     reads yacc behind s_nop 15;
     //   * dependent MFMAs on one accumulator may follow each other directly.
+    static_assert(SLOTS == 2, "two stages in LDS");
     constexpr int PF = 6;
     constexpr bool NO_GELU = DIAG == 1 || DIAG == 5, NO_MFMA = DIAG == 2, NO_DMA = DIAG == 3 || DIAG == 5, NO_LDS = DIAG == 4 || DIAG == 5;
     f32x16 hA, hB;
@@ -204,14 +205,10 @@ __global__ __launch_bounds__((MlpCfg<C, VAR, SLOTS>::NW * 64), (MlpCfg<C, VAR, S
         pfv[c >> 1][2 * (c & 1) + 1] = g.rb;
       }
     };
-    // mode 0: fc1(0) alone out of stage -1;  1: steady state;  3: steady state with no stage left to fetch;  2: the last iteration (no next chunk)
-    auto iter = [&](auto mode_, int slot, int nst, f32x16& hin, f32x16& hout) {
-      constexpr int MODE = decltype(mode_)::value == 3 ? 1 : decltype(mode_)::value;
-      constexpr bool ISSUE = SLOTS == 3 && decltype(mode_)::value == 1 && !NO_DMA;       // this iteration carries the DMA of stage nst between its MFMAs
+    // mode 0: fc1(0) alone out of stage -1;  1: steady state;  2: the last iteration (no next chunk)
+    auto iter = [&](auto mode_, int slot, f32x16& hin, f32x16& hout) {
+      constexpr int MODE = decltype(mode_)::value;
       constexpr int N1 = MODE == 2 ? 0 : KS1, N2 = MODE == 0 ? 0 : 2 * NT, NF = N1 + N2;
-      const char* const nsrc = wp + ((long long)nst * FR + KS1) * 1024 + lane * 16;      // stage nst (>= 1): source, slot, pieces that exist
-      char* const ndst = smem + (nst % SLOTS) * CHB;
-      const int nhi = nst == NCH - 1 ? 2 * NT : FR;
       const unsigned lbase_ = (unsigned)(size_t)((const __attribute__((address_space(3))) char*)(smem + slot * CHB + lane * 16));
       static_for<0, PF>([&](auto fc) {
         constexpr int f = decltype(fc)::value;
@@ -257,30 +254,18 @@ __global__ __launch_bounds__((MlpCfg<C, VAR, SLOTS>::NW * 64), (MlpCfg<C, VAR, S
           static_for<K0, 16>([&](auto kc) {
             if constexpr ((decltype(kc)::value - K0) * SL / (16 - K0) == i) gelu_step(hi_, kc);
           });
-        // Three slots: the DMA instructions of the stage after next go out one at a time between the MFMAs (an LDS-DMA instruction holds the
-        // wave's issue for ~60 - 100 cycles: ten in a row at the top of the iteration are ~0.4 us with the matrix pipe idle).
-        if constexpr (ISSUE)
-          static_for<0, CNT>([&](auto fc) {
-            constexpr int f = decltype(fc)::value;
-            if constexpr (f * NF / CNT == i) {
-              const int fi = f * NW + wv;
-              const bool real = fi < nhi;                                // (scalar: wave-uniform)
-              __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(nsrc + (real ? fi : 0) * 1024),
-                                               (__attribute__((address_space(3))) void*)(real ? ndst + fi * 1024 : smem + SLOTS * CHB), 16, 0, 0);
-            }
-          });
       });
     };
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"((SLOTS - 1) * CNT) : "memory");   // stage -1 (all but the youngest stages' DMA instructions of this wave)
     __syncthreads();
-    iter(std::integral_constant<int, 0>{}, SLOTS - 1, 0, hA, hA);
+    iter(std::integral_constant<int, 0>{}, SLOTS - 1, hA, hA);
     auto step = [&](auto mode, int j, f32x16& hin, f32x16& hout) {
-      // own pieces of stage j (three slots: stage j + 1 may still be in flight); the barrier publishes them and retires stage j - 1, whose slot
-      // the next fetch overwrites
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((SLOTS - 2) * CNT) : "memory");
+      // own pieces of stage j; the barrier publishes them and retires stage j - 1, whose slot the next fetch overwrites.  (Measured r04 and not kept:
+      // three slots with the DMA instructions of stage j + 2 spread one by one between this iteration's MFMAs -- 587 us against 580.)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
-      if (SLOTS == 2 && j + 1 < NCH && !NO_DMA) issue_stage(j + 1);
-      iter(mode, j % SLOTS, j + 2, hin, hout);
+      if (j + 1 < NCH && !NO_DMA) issue_stage(j + 1);
+      iter(mode, j % SLOTS, hin, hout);
     };
     static_assert(NCH % 2 == 0, "pairs of iterations");
 #pragma unroll 1
@@ -288,13 +273,13 @@ __global__ __launch_bounds__((MlpCfg<C, VAR, SLOTS>::NW * 64), (MlpCfg<C, VAR, S
       step(std::integral_constant<int, 1>{}, j, hA, hB);
       step(std::integral_constant<int, 1>{}, j + 1, hB, hA);
     }
-    step(std::integral_constant<int, 3>{}, NCH - 2, hA, hB);
+    step(std::integral_constant<int, 1>{}, NCH - 2, hA, hB);
     {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       asm volatile("" : "+v"(hB));
       static_for<0, 8>([&](auto kc) { gelu_step(hB, kc); });
-      iter(std::integral_constant<int, 2>{}, (NCH - 1) % SLOTS, 0, hB, hB);
+      iter(std::integral_constant<int, 2>{}, (NCH - 1) % SLOTS, hB, hB);
     }
 #pragma unroll
     for (int t = 0; t < NT; ++t) asm volatile("s_nop 15" : "+a"(yacc[t]));   // the epilogue's v_accvgpr_read after the last MFMAs
@@ -439,26 +424,26 @@ extern "C" int CVMI_ENTRY(cvmi_hiera_mlp_stats)(void* x, int x_ld, const float* 
              "hiera_mlp: pointers / ld must be 16-byte aligned");
   hipStream_t s = (hipStream_t)stream_;
   float* xf = (float*)x;
-  // A/B switches (measured r04, profiles/r04_ab_runs.md): CVMI_MLP_VAR bit 0 -> C = 144, bit 1 -> C = 288 in 4-wave workgroups at two waves per
-  // SIMD; CVMI_MLP_SLOTS = 2 | 3, the ring depth
+  // A/B switches (measured r04, profiles/r04_ab_runs.md): CVMI_MLP_PIPE bit 1 (default on) -> C = 288 on the software-pipelined loop (VAR 2);
+  // CVMI_MLP_VAR bit 0 -> C = 144, bit 1 -> C = 288 (with PIPE = 0) in 4-wave workgroups at two waves per SIMD; CVMI_MLP_SLOTS = 2 | 3, the ring
+  // depth of the chunk-order loops
   static const int var = getenv("CVMI_MLP_VAR") ? atoi(getenv("CVMI_MLP_VAR")) : 1;
   const char* const slots_env = getenv("CVMI_MLP_SLOTS");
   const int slots = slots_env ? atoi(slots_env) : 2;
   const char* const pipe_env = getenv("CVMI_MLP_PIPE");        // (read per call: tests/test_ops_gpu.py switches it between two launches)
-  const int pipe = pipe_env ? atoi(pipe_env) : 0;
+  const int pipe = pipe_env ? atoi(pipe_env) : 2;
 #define CVMI_MLP_GO(CC, VV, SS) return launch_mlp<CC, VV, SS>(xf, x_ld, gamma, beta, eps, w_packed, b2, rows, s, ln_stats_out, ln_stats_eps)
   if (C == 144) {
-    if (pipe & 1) CVMI_MLP_GO(144, 2, 2);
     if (var & 1) { if (slots == 3) CVMI_MLP_GO(144, 1, 3); CVMI_MLP_GO(144, 1, 2); }
     if (slots == 3) CVMI_MLP_GO(144, 0, 3);
     CVMI_MLP_GO(144, 0, 2);
   }
 #ifdef CVMI_MLP_DIAGS
   static const int diag = getenv("CVMI_MLP_DIAG") ? atoi(getenv("CVMI_MLP_DIAG")) : 0;
-#define CVMI_MLP_DIAG_GO(D) if (C == 288 && diag == D) return launch_mlp<288, 2, 3, D>(xf, x_ld, gamma, beta, eps, w_packed, b2, rows, s, ln_stats_out, ln_stats_eps)
+#define CVMI_MLP_DIAG_GO(D) if (C == 288 && diag == D) return launch_mlp<288, 2, 2, D>(xf, x_ld, gamma, beta, eps, w_packed, b2, rows, s, ln_stats_out, ln_stats_eps)
   CVMI_MLP_DIAG_GO(1); CVMI_MLP_DIAG_GO(2); CVMI_MLP_DIAG_GO(3); CVMI_MLP_DIAG_GO(4); CVMI_MLP_DIAG_GO(5);
 #endif
-  if (pipe & 2) { if (slots == 3) CVMI_MLP_GO(288, 2, 3); CVMI_MLP_GO(288, 2, 2); }
+  if (pipe & 2) CVMI_MLP_GO(288, 2, 2);
   if (var & 2) CVMI_MLP_GO(288, 1, 2);                  // (two workgroups per CU leave room for two slots of 37 KiB each only)
   if (slots == 3) CVMI_MLP_GO(288, 0, 3);
   CVMI_MLP_GO(288, 0, 2);
