@@ -237,3 +237,28 @@ def test_asm_loads_of_the_persistent_fc2_kernel_are_not_touched_before_their_wai
     assert body is not None
     seen, hits = m.check(body)
     assert seen == 30 and hits == [], hits[:3]
+
+
+def test_asm_mfmas_of_the_pipelined_mlp_loop_keep_their_wait_states():
+    """hiera_mlp_kernel<288, 2, 2> issues its MFMAs from inline asm, where hipcc's hazard recogniser sees nothing: a VALU result needs wait states
+    before an MFMA reads it, an MFMA result before anything else reads it.  The source provides them by construction (`s_nop` statements the operands
+    pass through); tools/check_asm_mfma.py verifies on the device assembly of both operand-type builds that hipcc left them intact -- it moved a
+    LayerNorm conversion to 0 wait states in front of a consuming block in r04 (wrong results in whole waves).  The checker is exercised on
+    synthetic streams first."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("check_asm_mfma", os.path.join(ROOT, "tools", "check_asm_mfma.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    mfma = "v_mfma_f32_32x32x16_f16 v[2:17], v[46:49], v[90:93], v[2:17]"
+    good = ["v_cvt_pk_f16_f32 v93, v36, v37", "s_nop 1", mfma] + ["s_nop 3"] * 3 + ["v_add_f32_e32 v40, v2, v3"]
+    assert m.check(good) == (1, [])
+    n, bad = m.check(["v_cvt_pk_f16_f32 v93, v36, v37", "s_waitcnt lgkmcnt(5)", mfma])
+    assert n == 1 and len(bad) == 1 and bad[0].startswith("VALU -> MFMA, 1 wait states")
+    n, bad = m.check([mfma, "s_nop 7", "v_add_f32_e32 v40, v2, v3"])
+    assert n == 1 and len(bad) == 1 and bad[0].startswith("MFMA -> read, 8 wait states")
+    assert m.check([mfma, mfma.replace("v[46:49]", "v[50:53]"), "s_nop 15", "v_add_f32_e32 v40, v2, v3"]) == (2, [])       # the chain restarts the count
+    if not os.path.exists(m.HIPCC):
+        pytest.skip("hipcc not available")
+    for extra in ((), ("-DCVMI_OPERAND_BF16",)):
+        n, bad = m.check(m.kernel_body(m.device_asm("hiera_mlp.hip", extra), m.KERNEL))
+        assert n == 148 and bad == [], bad[:3]
