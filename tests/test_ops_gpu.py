@@ -635,7 +635,7 @@ def test_hiera_mlp_fused_vs_torch(C_, rows, dt):
 
 
 @pytest.mark.parametrize("dt", [F16, BF16])
-@pytest.mark.parametrize("rows", [777, 128 * 40 + 5])
+@pytest.mark.parametrize("rows", [5, 777, 128 * 40 + 5])
 def test_hiera_mlp_pipelined_loop_equals_chunk_order_loop(rows, dt, monkeypatch):
     """C = 288: the software-pipelined chunk loop (asm blocks; GELU of chunk j between the MFMAs of fc1(j + 1) and fc2(j)) computes every value with
     the same operations in the same order as the chunk-order loop it replaces: outputs and forwarded LayerNorm statistics must be bit-identical.
