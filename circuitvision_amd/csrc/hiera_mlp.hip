@@ -18,7 +18,8 @@
 //     two-slot ring, one barrier per chunk; every ds_read_b128 is lane-linear (conflict-free);
 //   * epilogue: + fc2 bias + the old x, 16-byte f32 stores.
 // C = 144 (stage 1): 8 waves / workgroup, two waves per SIMD (the GELU VALU of one overlaps the MFMAs of the other).
-// C = 288 (stage 2): the Y^T accumulator (144 registers) + Xn (76) leave room for one wave per SIMD only: 4 waves.
+// C = 288 (stage 2): the Y^T accumulator (144 registers) + Xn (76) leave room for one wave per SIMD only: 4 waves.  Its chunk loop is
+// software-pipelined inside the wave and written as asm blocks (VAR 2, below): nobody else is there to fill the matrix pipe while GELU issues.
 #include "common.hpp"
 #include <stdlib.h>
 #include <type_traits>
@@ -172,7 +173,7 @@ __global__ __launch_bounds__((MlpCfg<C, VAR, SLOTS>::NW * 64), (MlpCfg<C, VAR, S
     // for 37 MFMAs; timing-only builds, profiles/r04_ab_runs.md).
     // Register files are fixed by the constraints: yacc in AGPRs ("+a"), the hidden accumulators in VGPRs (GELU reads them directly).
     // hipcc's hazard recogniser does not look inside asm: what the hardware needs around these MFMAs is provided here by construction --
-    //   * a VGPR a VALU instruction wrote needs wait states before an MFMA reads it (measured: an LayerNorm conversion that hipcc had sunk to
+    //   * a VGPR a VALU instruction wrote needs wait states before an MFMA reads it (measured: a LayerNorm conversion that hipcc had sunk to
     //     right in front of the consuming block gave wrong results in whole waves): xn and pfv pass through an `s_nop 1` asm statement first;
     //   * an MFMA's result needs 12 wait states before a VALU instruction reads it: GELU reads hin >= 18 MFMAs after its last MFMA, the epilogue
     //     reads yacc behind s_nop 15;
