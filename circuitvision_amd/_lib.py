@@ -5,7 +5,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcvmi355.so")
+# CVMI_LIB_PATH: A/B measurements load an alternative build of the same library (tools/ab_env.sh) instead of overwriting the shipped file
+LIB_PATH = os.environ.get("CVMI_LIB_PATH") or os.path.join(_HERE, "libcvmi355.so")
 
 F16, F32, BF16 = 0, 1, 2
 ACT_NONE, ACT_SILU, ACT_RELU, ACT_GELU, ACT_SIGMOID = 0, 1, 2, 3, 4
